@@ -1,0 +1,246 @@
+/* omk.h -- C ABI of libomnimamba_hip.so: the MI355X (gfx950) kernels behind OmniMamba's Mamba-2 hot path.
+ *
+ * The reference has NO native boundary of its own: every hot op is a Python import from the third-party
+ * packages mamba_ssm==2.2.2 / causal-conv1d==1.4.0 (/root/reference/requirements.txt:12-13), whose pybind11
+ * Torch extensions take at::Tensor.  This header is the drop-in boundary this repo defines instead: plain
+ * pointers, sizes and element strides, no torch types, no exceptions.  Each entry point names the reference
+ * call site it serves (paths relative to /root/reference) and the upstream Python symbol it stands behind.
+ *
+ * Conventions
+ *   - every function returns 0 (OMK_OK) or a negative omk_status; omk_last_error() gives thread-local text.
+ *   - all launches are asynchronous on the hipStream_t passed as `stream` (0 = default stream); the library
+ *     never allocates or frees device memory, never synchronises, keeps no mutable global state -> safe
+ *     under hipGraph capture and one-process-per-GPU data parallelism.
+ *   - tensors are described by OmkTensor (device pointer + dtype + shape + ELEMENT strides); data == NULL
+ *     marks an absent optional tensor.  Scratch is caller-owned: ask omk_*_workspace_bytes first.
+ *   - all arithmetic is fp32 internally; dtype says how a tensor is stored.
+ */
+#ifndef OMK_H
+#define OMK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMK_ABI_VERSION 1
+#define OMK_MAX_DIMS 5
+
+typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
+typedef enum { OMK_F32 = 0, OMK_BF16 = 1, OMK_F16 = 2 } omk_dtype;
+typedef void* omk_stream; /* hipStream_t */
+
+typedef struct {
+  void* data;
+  int32_t dtype; /* omk_dtype */
+  int32_t ndim;
+  int64_t shape[OMK_MAX_DIMS];
+  int64_t stride[OMK_MAX_DIMS]; /* elements */
+} OmkTensor;
+
+int omk_abi_version(void);
+const char* omk_last_error(void);
+/* 1 when the library was built for the emulator (tests only), 0 for the real gfx950 build */
+int omk_is_emulated(void);
+/* sizeof() of the named parameter struct ("OmkTensor", "OmkSsdFwd", ...), 0 when unknown: lets a foreign-language
+ * binding check its own struct layout against the library at load time */
+size_t omk_sizeof(const char* struct_name);
+
+/* ---- fused residual-add + RMSNorm/LayerNorm -------------------------------------------------------------
+ * upstream mamba_ssm.ops.triton.layer_norm.layer_norm_fn / rms_norm_fn / RMSNorm
+ * reference call sites: models/stage2/block.py:10,86-95 ; models/stage2/mixer_seq_simple.py:30,428-437      */
+typedef struct {
+  OmkTensor x;            /* (rows, cols) activation */
+  OmkTensor residual;     /* optional (rows, cols) */
+  OmkTensor weight;       /* (cols) */
+  OmkTensor bias;         /* optional (cols) */
+  OmkTensor y;            /* out (rows, cols), dtype of x */
+  OmkTensor residual_out; /* optional out (rows, cols): x + residual, its own dtype (fp32 when residual_in_fp32) */
+  OmkTensor rstd;         /* optional out (rows) f32 */
+  OmkTensor mean;         /* optional out (rows) f32, LayerNorm only */
+  float eps;
+  int32_t is_rms_norm;
+} OmkAddNormFwd;
+int omk_add_norm_fwd(const OmkAddNormFwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor dy;            /* (rows, cols) */
+  OmkTensor dresidual_out; /* optional incoming grad of the prenorm residual output */
+  OmkTensor xsum;          /* (rows, cols) the pre-norm sum saved by forward (residual_out, or x when no residual) */
+  OmkTensor weight;
+  OmkTensor rstd;          /* (rows) f32 */
+  OmkTensor mean;          /* optional (rows) f32 */
+  OmkTensor dx;            /* out (rows, cols) */
+  OmkTensor dresidual_in;  /* optional out (rows, cols): same value as dx in the residual's dtype */
+  OmkTensor dweight;       /* out (cols) f32 */
+  OmkTensor dbias;         /* optional out (cols) f32 */
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t is_rms_norm;
+  int32_t has_bias;
+} OmkAddNormBwd;
+size_t omk_add_norm_bwd_workspace_bytes(const OmkAddNormBwd* p);
+int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream);
+
+/* ---- gated RMSNorm -----------------------------------------------------------------------------------------
+ * upstream mamba_ssm.ops.triton.layernorm_gated.{RMSNorm, rmsnorm_fn}; used as Mamba2.norm(y, z)
+ * reference reach: models/stage2/block.py:117 -> Mamba2.forward / Mamba2.step                                 */
+typedef struct {
+  OmkTensor x;      /* (rows, cols) */
+  OmkTensor z;      /* optional gate (rows, cols) */
+  OmkTensor weight; /* (cols) */
+  OmkTensor bias;   /* optional */
+  OmkTensor y;      /* out (rows, cols) */
+  OmkTensor rstd;   /* optional out (rows, ngroups) f32 */
+  int64_t group_size;
+  float eps;
+  int32_t norm_before_gate;
+} OmkNormGatedFwd;
+int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor dy, x, z, weight; /* z optional */
+  OmkTensor dx, dz;           /* out; dz optional */
+  OmkTensor dweight;          /* out (cols) f32 */
+  void* workspace;
+  size_t workspace_bytes;
+  int64_t group_size;
+  float eps;
+  int32_t norm_before_gate;
+} OmkNormGatedBwd;
+size_t omk_norm_gated_bwd_workspace_bytes(const OmkNormGatedBwd* p);
+int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream);
+
+/* ---- causal depthwise conv1d ---------------------------------------------------------------------------
+ * upstream causal_conv1d.{causal_conv1d_fn, causal_conv1d_update}
+ * reference reach: models/stage2/mixer_seq_simple.py:17,200-205 (Mamba2) ; decode via
+ * models/stage2/generation.py:195-211,412-431.  Logical shape (batch, channels, seqlen); strides make both the
+ * channel-last (B, L, C) storage the Mamba-2 block uses and channel-first storage legal.                    */
+typedef struct {
+  OmkTensor x;              /* (B, C, L) logical */
+  OmkTensor weight;         /* (C, W), W in 2..4 */
+  OmkTensor bias;           /* optional (C) */
+  OmkTensor initial_states; /* optional (B, C, W-1) */
+  OmkTensor out;            /* (B, C, L) logical */
+  OmkTensor final_states;   /* optional out (B, C, W-1) */
+  int32_t silu;
+} OmkConv1dFwd;
+int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor x, weight, bias, initial_states; /* bias / initial_states optional */
+  OmkTensor dout;                            /* (B, C, L) */
+  OmkTensor dx;                              /* out (B, C, L) */
+  OmkTensor dweight;                         /* out (C, W) f32, ACCUMULATED into (caller zeroes) */
+  OmkTensor dbias;                           /* optional out (C) f32, accumulated */
+  OmkTensor dinitial_states;                 /* optional out (B, C, W-1) */
+  int32_t silu;
+} OmkConv1dBwd;
+int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor x;          /* (B, C, T), T small (1 for decode) */
+  OmkTensor conv_state; /* (B, C, S), S >= W-1, updated in place */
+  OmkTensor weight, bias;
+  OmkTensor out;        /* (B, C, T) */
+  int32_t silu;
+} OmkConv1dUpdate;
+int omk_causal_conv1d_update(const OmkConv1dUpdate* p, omk_stream stream);
+
+/* ---- single-token SSM state update ---------------------------------------------------------------------
+ * upstream mamba_ssm.ops.triton.selective_state_update.selective_state_update (Mamba2.step)
+ * reference reach: models/stage2/generation.py:195-211,412-424 -> MixerModel.forward -> Block -> Mamba2.step */
+typedef struct {
+  OmkTensor state;   /* (B, H, P, N) in place */
+  OmkTensor x;       /* (B, H, P) */
+  OmkTensor dt;      /* (B, H, P) stride 0 on P allowed */
+  OmkTensor A;       /* (H, P, N) stride 0 on P,N allowed */
+  OmkTensor Bm, Cm;  /* (B, G, N) */
+  OmkTensor D;       /* optional (H, P) */
+  OmkTensor z;       /* optional (B, H, P) */
+  OmkTensor dt_bias; /* optional (H, P) */
+  OmkTensor out;     /* (B, H, P) */
+  int32_t dt_softplus;
+} OmkStateUpdate;
+int omk_selective_state_update(const OmkStateUpdate* p, omk_stream stream);
+
+/* ---- Mamba-1 selective scan ----------------------------------------------------------------------------
+ * upstream mamba_ssm.ops.selective_scan_interface.selective_scan_fn (BASELINE.json configs[0] signature)
+ * reference reach: models/stage2/mixer_seq_simple.py:16,197-201 (ssm_cfg.layer == "Mamba1")                  */
+typedef struct {
+  OmkTensor u, delta;   /* (B, D, L) logical, any strides */
+  OmkTensor A;          /* (D, N) f32 */
+  OmkTensor Bm, Cm;     /* (B, G, N, L) logical (G=1 for the 3-d form) or (D, N) constant (ndim == 2) */
+  OmkTensor D;          /* optional (D) */
+  OmkTensor z;          /* optional (B, D, L) */
+  OmkTensor delta_bias; /* optional (D) */
+  OmkTensor out;        /* (B, D, L) */
+  OmkTensor last_state; /* optional out (B, D, N) f32 */
+  int32_t delta_softplus;
+} OmkSelScanFwd;
+int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor u, delta, A, Bm, Cm, D, z, delta_bias; /* as forward */
+  OmkTensor dout;                                  /* (B, D, L) */
+  OmkTensor du, ddelta;                            /* out (B, D, L) */
+  OmkTensor dA;                                    /* out (D, N) f32 accumulated */
+  OmkTensor dB, dC;                                /* out (B, G, N, L) f32 accumulated (variable B/C only) */
+  OmkTensor dD;                                    /* optional out (D) f32 accumulated */
+  OmkTensor dz;                                    /* optional out (B, D, L) */
+  OmkTensor ddelta_bias;                           /* optional out (D) f32 accumulated */
+  int32_t delta_softplus;
+} OmkSelScanBwd;
+int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);
+
+/* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------
+ * upstream mamba_ssm.ops.triton.ssd_combined.mamba_chunk_scan_combined (+ the scan stage of
+ * mamba_split_conv1d_scan_combined); reference reach: models/stage2/block.py:117 -> Mamba2.forward              */
+typedef struct {
+  OmkTensor x;              /* (B, L, H, P) */
+  OmkTensor dt;             /* (B, L, H) raw dt (before bias/softplus/clamp) */
+  OmkTensor A;              /* (H) f32, negative */
+  OmkTensor Bm, Cm;         /* (B, L, G, N) */
+  OmkTensor D;              /* optional (H) or (H, P) */
+  OmkTensor z;              /* optional (B, L, H, P): out = y * silu(z) */
+  OmkTensor dt_bias;        /* optional (H) */
+  OmkTensor initial_states; /* optional (B, H, P, N) */
+  OmkTensor out;            /* (B, L, H, P) */
+  OmkTensor final_states;   /* optional out (B, H, P, N) f32 */
+  void* workspace;
+  size_t workspace_bytes;
+  float dt_min, dt_max;     /* clamp (dt_limit); (0, +inf) = none */
+  int32_t dt_softplus;
+  int32_t chunk_size;       /* API parity only: the result does not depend on it */
+  int32_t force_generic;    /* 1 = use the shape-generic fp32 VALU kernel even when the MFMA kernel applies */
+} OmkSsdFwd;
+size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p);
+int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream);
+
+typedef struct {
+  OmkTensor x, dt, A, Bm, Cm, D, z, dt_bias, initial_states; /* as forward */
+  OmkTensor dout;            /* (B, L, H, P) grad of out */
+  OmkTensor dfinal_states;   /* optional (B, H, P, N) */
+  OmkTensor dx;              /* out (B, L, H, P) */
+  OmkTensor ddt;             /* out (B, L, H) f32: grad wrt RAW dt */
+  OmkTensor dA;              /* out (H) f32 */
+  OmkTensor dB, dC;          /* out (B, L, G, N) */
+  OmkTensor dD;              /* optional out (H) or (H, P) f32 */
+  OmkTensor dz;              /* optional out (B, L, H, P) */
+  OmkTensor ddt_bias;        /* optional out (H) f32 */
+  OmkTensor dinitial_states; /* optional out (B, H, P, N) f32 */
+  void* workspace;
+  size_t workspace_bytes;
+  float dt_min, dt_max;
+  int32_t dt_softplus;
+  int32_t chunk_size;
+  int32_t force_generic;
+} OmkSsdBwd;
+size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p);
+int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMK_H */

@@ -1,0 +1,145 @@
+"""ctypes mirror of include/omk.h: struct layouts + one thin `call_*` marshaller per entry point.
+
+Nothing here computes: tensors are described by (data_ptr, dtype, shape, element strides) and handed to the
+C ABI.  `lib` is always passed in explicitly (omnimamba_amd._lib.get_lib() for the product; the CPU test-suite
+passes its emulator build of the same sources).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+OMK_ABI_VERSION = 1
+OMK_MAX_DIMS = 5
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class OmkTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * OMK_MAX_DIMS), ("stride", C.c_int64 * OMK_MAX_DIMS)]
+
+
+def T(t: Optional[torch.Tensor]) -> OmkTensor:
+    o = OmkTensor()
+    if t is None:
+        return o
+    if t.dtype not in _DT:
+        raise TypeError(f"unsupported dtype {t.dtype} (f32/bf16/f16 only)")
+    if t.dim() > OMK_MAX_DIMS:
+        raise ValueError("too many dims")
+    o.data = t.data_ptr()
+    o.dtype = _DT[t.dtype]
+    o.ndim = t.dim()
+    for i in range(t.dim()):
+        o.shape[i] = t.shape[i]
+        o.stride[i] = t.stride(i)
+    return o
+
+
+def _S(name, fields):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+_t, _f, _i, _i64 = OmkTensor, C.c_float, C.c_int32, C.c_int64
+_ws = [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+AddNormFwd = _S("OmkAddNormFwd", [(n, _t) for n in ("x", "residual", "weight", "bias", "y", "residual_out", "rstd", "mean")]
+                + [("eps", _f), ("is_rms_norm", _i)])
+AddNormBwd = _S("OmkAddNormBwd", [(n, _t) for n in ("dy", "dresidual_out", "xsum", "weight", "rstd", "mean", "dx",
+                                                    "dresidual_in", "dweight", "dbias")] + _ws
+                + [("is_rms_norm", _i), ("has_bias", _i)])
+NormGatedFwd = _S("OmkNormGatedFwd", [(n, _t) for n in ("x", "z", "weight", "bias", "y", "rstd")]
+                  + [("group_size", _i64), ("eps", _f), ("norm_before_gate", _i)])
+NormGatedBwd = _S("OmkNormGatedBwd", [(n, _t) for n in ("dy", "x", "z", "weight", "dx", "dz", "dweight")] + _ws
+                  + [("group_size", _i64), ("eps", _f), ("norm_before_gate", _i)])
+Conv1dFwd = _S("OmkConv1dFwd", [(n, _t) for n in ("x", "weight", "bias", "initial_states", "out", "final_states")]
+               + [("silu", _i)])
+Conv1dBwd = _S("OmkConv1dBwd", [(n, _t) for n in ("x", "weight", "bias", "initial_states", "dout", "dx", "dweight",
+                                                  "dbias", "dinitial_states")] + [("silu", _i)])
+Conv1dUpdate = _S("OmkConv1dUpdate", [(n, _t) for n in ("x", "conv_state", "weight", "bias", "out")] + [("silu", _i)])
+StateUpdate = _S("OmkStateUpdate", [(n, _t) for n in ("state", "x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "out")]
+                 + [("dt_softplus", _i)])
+SelScanFwd = _S("OmkSelScanFwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "out",
+                                                    "last_state")] + [("delta_softplus", _i)])
+SelScanBwd = _S("OmkSelScanBwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "dout", "du",
+                                                    "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")]
+                + [("delta_softplus", _i)])
+SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
+                                            "final_states")] + _ws
+            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
+SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "dout",
+                                            "dfinal_states", "dx", "ddt", "dA", "dB", "dC", "dD", "dz", "ddt_bias",
+                                            "dinitial_states")] + _ws
+            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
+
+STRUCTS = {s.__name__: s for s in (OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
+                                   Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, SsdFwd, SsdBwd)}
+
+# every symbol include/omk.h declares
+SYMBOLS = [
+    "omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof",
+    "omk_add_norm_fwd", "omk_add_norm_bwd_workspace_bytes", "omk_add_norm_bwd",
+    "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
+    "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
+    "omk_selective_state_update",
+    "omk_selective_scan_fwd", "omk_selective_scan_bwd",
+    "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
+]
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Declare prototypes on a freshly dlopen'ed library and check ABI version + struct sizes."""
+    lib.omk_abi_version.restype = C.c_int
+    lib.omk_last_error.restype = C.c_char_p
+    lib.omk_is_emulated.restype = C.c_int
+    lib.omk_sizeof.restype = C.c_size_t
+    lib.omk_sizeof.argtypes = [C.c_char_p]
+    for s in SYMBOLS:
+        fn = getattr(lib, s)  # raises AttributeError when a declared symbol is missing
+        if s.endswith("_workspace_bytes"):
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p]
+        elif s not in ("omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof"):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_void_p]
+    if lib.omk_abi_version() != OMK_ABI_VERSION:
+        raise RuntimeError(f"libomnimamba_hip ABI {lib.omk_abi_version()} != python {OMK_ABI_VERSION}")
+    for name, s in STRUCTS.items():
+        n = lib.omk_sizeof(name.encode())
+        if n != C.sizeof(s):
+            raise RuntimeError(f"struct {name}: C sizeof {n} != ctypes {C.sizeof(s)}")
+    return lib
+
+
+def check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.omk_last_error()
+        raise RuntimeError(f"{what} failed (omk_status {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_of(lib, t: torch.Tensor):
+    if lib.omk_is_emulated():
+        return None
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def run(lib, fn_name: str, params, ref: torch.Tensor):
+    """Call `fn_name(&params, stream)` with the current stream of `ref`'s device selected."""
+    fn = getattr(lib, fn_name)
+    if lib.omk_is_emulated():
+        check(lib, fn(C.byref(params), None), fn_name)
+    else:
+        with torch.cuda.device(ref.device):
+            check(lib, fn(C.byref(params), stream_of(lib, ref)), fn_name)
+
+
+def workspace(lib, fn_name: str, params, ref: torch.Tensor) -> Optional[torch.Tensor]:
+    n = getattr(lib, fn_name)(C.byref(params))
+    if n == 0:
+        return None
+    ws = torch.empty(n, dtype=torch.uint8, device=ref.device)
+    params.workspace = ws.data_ptr()
+    params.workspace_bytes = n
+    return ws

@@ -1,0 +1,434 @@
+// conv1d.hip -- causal depthwise conv1d (width 2..4) + bias + SiLU: forward, backward, single-step update.
+//
+// HBM-bound (2 * tok * C * s bytes).  The Mamba-2 block stores xBC channel-last
+// ((B, L, C) view of the in_proj output, row stride 8512), so the fast path gives each lane 8 adjacent channels
+// (one 16-byte load per token, a wave covers 1 KB of one token row) and walks TL consecutive tokens with the
+// W-1 previous inputs held in registers: every input byte is fetched once per tile (+ a W-1 token halo that
+// hits L2).  Any other layout (channel-first, odd sizes, fp32 rows not 16-byte aligned) takes the strided
+// scalar kernel, whose fastest thread index follows the unit-stride dimension.
+#include "omk_common.h"
+
+namespace omk {
+
+constexpr int CONV_MAXW = 4;
+
+struct ConvArgs {
+  const void* x; const void* w; const void* bias; const void* init; const void* dout;
+  void* out; void* fin; void* dx; float* dw; float* db; void* dinit;
+  int64_t xsb, xsc, xsl, osb, osc, osl, isb, isc, isl, fsb, fsc, fsl, dosb, dosc, dosl, dxsb, dxsc, dxsl, disb, disc, disl;
+  int64_t wsc, wsk;
+  int B, C, L, W, silu, wdt, bdt, idt, fdt;
+};
+
+__device__ __forceinline__ float silu_grad(float pre) {
+  float s = sigmoid_f(pre);
+  return s * (1.f + pre * (1.f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// channel-last vectorised forward: thread = (b, token tile, 8-channel vector)
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int VEC, int TL, int W>
+__global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
+  const int CV = a.C / VEC, NT = (a.L + TL - 1) / TL;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * NT * CV) return;
+  const int cv = (int)(g % CV), tile = (int)((g / CV) % NT), b = (int)(g / ((int64_t)CV * NT));
+  const int c0 = cv * VEC, l0 = tile * TL;
+  const T* x = (const T*)a.x + (int64_t)b * a.xsb + c0;
+  T* out = (T*)a.out + (int64_t)b * a.osb + c0;
+  // win[k] holds the input at position l - (W-1) + k  (k = W-1 is the current token)
+  float w[W][VEC], bias[VEC], win[W][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    bias[i] = a.bias ? load_rt(a.bias, c0 + i, a.bdt) : 0.f;
+#pragma unroll
+    for (int k = 0; k < W; k++) w[k][i] = load_rt(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+  }
+  // before the first shift slot s (1..W-1) holds position l0 - W + s
+#pragma unroll
+  for (int s = 1; s < W; s++) {
+    const int l = l0 - W + s;
+    if (l >= 0) {
+      load_vec<T, VEC>(x + (int64_t)l * a.xsl, win[s]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; i++)
+        win[s][i] = a.init ? load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt) : 0.f;
+    }
+  }
+  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
+  for (int l = l0; l < lend; l++) {
+#pragma unroll
+    for (int s = 0; s + 1 < W; s++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) win[s][i] = win[s + 1][i];
+    load_vec<T, VEC>(x + (int64_t)l * a.xsl, win[W - 1]);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      float acc = bias[i];
+#pragma unroll
+      for (int k = 0; k < W; k++) acc += w[k][i] * win[k][i];
+      o[i] = a.silu ? silu_f(acc) : acc;
+    }
+    store_vec<T, VEC>(out + (int64_t)l * a.osl, o);
+  }
+  if (a.fin && lend == a.L) {
+    // final_states[j] = xpad[L + j], xpad = [init | x]
+    for (int j = 0; j < W - 1; j++) {
+      const int l = a.L + j - (W - 1);
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        float v = 0.f;
+        if (l >= 0) v = to_f32(x[(int64_t)l * a.xsl + i]);
+        else if (a.init) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt);
+        store_rt(a.fin, (int64_t)b * a.fsb + (int64_t)(c0 + i) * a.fsc + (int64_t)j * a.fsl, a.fdt, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// strided scalar forward: thread = one output element; fastest thread index along the unit-stride dim
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ float conv_in(const ConvArgs& a, const T* x, int b, int c, int l) {
+  if (l >= 0) return to_f32(x[(int64_t)b * a.xsb + (int64_t)c * a.xsc + (int64_t)l * a.xsl]);
+  if (a.init) return load_rt(a.init, (int64_t)b * a.isb + (int64_t)c * a.isc + (int64_t)(a.W - 1 + l) * a.isl, a.idt);
+  return 0.f;
+}
+
+template <class T>
+__global__ void conv1d_fwd_generic_kernel(ConvArgs a, int l_fastest) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * a.C * a.L) return;
+  int b, c, l;
+  if (l_fastest) { l = (int)(g % a.L); c = (int)((g / a.L) % a.C); b = (int)(g / ((int64_t)a.L * a.C)); }
+  else { c = (int)(g % a.C); l = (int)((g / a.C) % a.L); b = (int)(g / ((int64_t)a.L * a.C)); }
+  const T* x = (const T*)a.x;
+  float acc = a.bias ? load_rt(a.bias, c, a.bdt) : 0.f;
+  for (int k = 0; k < a.W; k++) acc += load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt) * conv_in<T>(a, x, b, c, l - (a.W - 1) + k);
+  if (a.silu) acc = silu_f(acc);
+  ((T*)a.out)[(int64_t)b * a.osb + (int64_t)c * a.osc + (int64_t)l * a.osl] = from_f32<T>(acc);
+}
+
+template <class T>
+__global__ void conv1d_final_states_kernel(ConvArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Wm = a.W - 1;
+  if (g >= (int64_t)a.B * a.C * Wm) return;
+  const int c = (int)(g % a.C), j = (int)((g / a.C) % Wm), b = (int)(g / ((int64_t)a.C * Wm));
+  float v = conv_in<T>(a, (const T*)a.x, b, c, a.L + j - Wm);
+  store_rt(a.fin, (int64_t)b * a.fsb + (int64_t)c * a.fsc + (int64_t)j * a.fsl, a.fdt, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward.  pre[l] = bias + sum_k w[k] xpad[l+k] ; dpre = dout * silu'(pre)
+//   dx[l] = sum_k w[k] dpre[l + (W-1) - k]   (terms with index >= L vanish)
+//   dw[k] = sum_{b,l} dpre[l] xpad[l+k] ; db = sum dpre ; dinit[j] = sum_k w[k] dpre[j - k] (j-k >= 0, < L)
+// channel-last vectorised: thread = (b, tile of TL tokens, 8 channels); dw/db reduced with one atomic per thread.
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int VEC, int TL, int W>
+__global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
+  const int CV = a.C / VEC, NT = (a.L + TL - 1) / TL;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * NT * CV) return;
+  const int cv = (int)(g % CV), tile = (int)((g / CV) % NT), b = (int)(g / ((int64_t)CV * NT));
+  const int c0 = cv * VEC, l0 = tile * TL;
+  const T* x = (const T*)a.x;
+  const T* dout = (const T*)a.dout + (int64_t)b * a.dosb + c0;
+  T* dx = (T*)a.dx + (int64_t)b * a.dxsb + c0;
+  float w[W][VEC], bias[VEC], dwacc[W][VEC], dbacc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    bias[i] = a.bias ? load_rt(a.bias, c0 + i, a.bdt) : 0.f;
+    dbacc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      w[k][i] = load_rt(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+      dwacc[k][i] = 0.f;
+    }
+  }
+  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
+  // walking p = l0 .. lend+W-2: xw[k] = xpad at position p-(W-1)+k, dp[k] = dpre[p-(W-1)+k];
+  // at step p dpre[p] becomes known and dx[p-(W-1)] = sum_k w[k] dpre[p-k] = sum_k w[k] dp[W-1-k] is complete.
+  float xw[W][VEC], dp[W][VEC];
+#pragma unroll
+  for (int s = 0; s < W; s++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { xw[s][i] = 0.f; dp[s][i] = 0.f; }
+#pragma unroll
+  for (int s = 1; s < W; s++) {
+    const int l = l0 - W + s;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) xw[s][i] = conv_in<T>(a, x, b, c0 + i, l);
+  }
+  // dpre of the W-1 positions before l0 is NOT needed: dx[lo] only uses dpre[lo .. lo+W-1], lo >= l0.
+  for (int p = l0; p < lend + W - 1; p++) {
+#pragma unroll
+    for (int s = 0; s + 1 < W; s++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) { xw[s][i] = xw[s + 1][i]; dp[s][i] = dp[s + 1][i]; }
+    const bool inside = p < a.L;
+    float go[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { xw[W - 1][i] = 0.f; go[i] = 0.f; }
+    if (inside) {
+      load_vec<T, VEC>(x + (int64_t)b * a.xsb + c0 + (int64_t)p * a.xsl, xw[W - 1]);
+      load_vec<T, VEC>(dout + (int64_t)p * a.dosl, go);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      float d = go[i];
+      if (a.silu && inside) {
+        float pre = bias[i];
+#pragma unroll
+        for (int k = 0; k < W; k++) pre += w[k][i] * xw[k][i];
+        d *= silu_grad(pre);
+      }
+      dp[W - 1][i] = inside ? d : 0.f;
+      if (inside && p < lend) {   // dw/db: each position is counted by exactly one tile
+        dbacc[i] += d;
+#pragma unroll
+        for (int k = 0; k < W; k++) dwacc[k][i] += d * xw[k][i];
+      }
+    }
+    const int lo = p - (W - 1);
+    if (lo >= l0 && lo < lend) {
+      float o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < W; k++) acc += w[k][i] * dp[W - 1 - k][i];
+        o[i] = acc;
+      }
+      store_vec<T, VEC>(dx + (int64_t)lo * a.dxsl, o);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    if (a.db) atomic_add_f32(a.db + c0 + i, dbacc[i]);
+#pragma unroll
+    for (int k = 0; k < W; k++) atomic_add_f32(a.dw + (int64_t)(c0 + i) * W + k, dwacc[k][i]);
+  }
+}
+
+// strided scalar backward: thread = (b, c), sequential over L (fallback for channel-first / odd layouts)
+template <class T>
+__global__ void conv1d_bwd_generic_kernel(ConvArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * a.C) return;
+  const int c = (int)(g % a.C), b = (int)(g / a.C), W = a.W;
+  const T* x = (const T*)a.x;
+  const T* dout = (const T*)a.dout;
+  float w[CONV_MAXW], dwacc[CONV_MAXW] = {0.f, 0.f, 0.f, 0.f}, dbacc = 0.f;
+  for (int k = 0; k < CONV_MAXW; k++) w[k] = k < W ? load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt) : 0.f;
+  const float bias = a.bias ? load_rt(a.bias, c, a.bdt) : 0.f;
+  auto dpre = [&](int l) -> float {
+    if (l < 0 || l >= a.L) return 0.f;
+    float d = to_f32(dout[(int64_t)b * a.dosb + (int64_t)c * a.dosc + (int64_t)l * a.dosl]);
+    if (a.silu) {
+      float pre = bias;
+      for (int k = 0; k < W; k++) pre += w[k] * conv_in<T>(a, x, b, c, l - (W - 1) + k);
+      d *= silu_grad(pre);
+    }
+    return d;
+  };
+  for (int l = 0; l < a.L; l++) {
+    float acc = 0.f;
+    for (int k = 0; k < W; k++) acc += w[k] * dpre(l + (W - 1) - k);
+    ((T*)a.dx)[(int64_t)b * a.dxsb + (int64_t)c * a.dxsc + (int64_t)l * a.dxsl] = from_f32<T>(acc);
+    float d = dpre(l);
+    dbacc += d;
+    for (int k = 0; k < W; k++) dwacc[k] += d * conv_in<T>(a, x, b, c, l - (W - 1) + k);
+  }
+  if (a.db) atomic_add_f32(a.db + c, dbacc);
+  for (int k = 0; k < W; k++) atomic_add_f32(a.dw + (int64_t)c * W + k, dwacc[k]);
+}
+
+// dinitial_states[b, c, j] = sum_k w[k] dpre[j - k] over 0 <= j-k < L  (tiny: B*C*(W-1) threads)
+template <class T>
+__global__ void conv1d_dinit_kernel(ConvArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Wm = a.W - 1, W = a.W;
+  if (g >= (int64_t)a.B * a.C * Wm) return;
+  const int c = (int)(g % a.C), j = (int)((g / a.C) % Wm), b = (int)(g / ((int64_t)a.C * Wm));
+  const T* x = (const T*)a.x;
+  const T* dout = (const T*)a.dout;
+  const float bias = a.bias ? load_rt(a.bias, c, a.bdt) : 0.f;
+  float acc = 0.f;
+  for (int k = 0; k < W; k++) {
+    int l = j - k;   // xpad index j feeds pre[l] through weight k when l + k == j
+    if (l < 0 || l >= a.L) continue;
+    float d = to_f32(dout[(int64_t)b * a.dosb + (int64_t)c * a.dosc + (int64_t)l * a.dosl]);
+    if (a.silu) {
+      float pre = bias;
+      for (int kk = 0; kk < W; kk++) pre += load_rt(a.w, (int64_t)c * a.wsc + kk * a.wsk, a.wdt) * conv_in<T>(a, x, b, c, l - (W - 1) + kk);
+      d *= silu_grad(pre);
+    }
+    acc += load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt) * d;
+  }
+  store_rt(a.dinit, (int64_t)b * a.disb + (int64_t)c * a.disc + (int64_t)j * a.disl, a.idt, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode update: thread = (b, c); state (B, C, S) shifted left by T, new inputs appended
+// ---------------------------------------------------------------------------------------------------------
+struct ConvUpdArgs {
+  const void* x; void* state; const void* w; const void* bias; void* out;
+  int64_t xsb, xsc, xsl, ssb, ssc, ssl, osb, osc, osl, wsc, wsk;
+  int B, C, T, S, W, silu, xdt, sdt, wdt, bdt;
+};
+__global__ void conv1d_update_kernel(ConvUpdArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * a.C) return;
+  const int c = (int)(g % a.C), b = (int)(g / a.C);
+  float w[CONV_MAXW], win[CONV_MAXW];
+  for (int k = 0; k < CONV_MAXW; k++) w[k] = k < a.W ? load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt) : 0.f;
+  const float bias = a.bias ? load_rt(a.bias, c, a.bdt) : 0.f;
+  const int64_t sbase = (int64_t)b * a.ssb + (int64_t)c * a.ssc;
+  // window = last W-1 state entries
+  for (int k = 0; k < CONV_MAXW; k++) win[k] = 0.f;
+  for (int k = 0; k + 1 < a.W; k++) win[k] = load_rt(a.state, sbase + (int64_t)(a.S - (a.W - 1) + k) * a.ssl, a.sdt);
+  // shift the stored state left by T (S is tiny: W-1 or W)
+  if (a.T < a.S) {
+    for (int s = 0; s + a.T < a.S; s++) store_rt(a.state, sbase + (int64_t)s * a.ssl, a.sdt, load_rt(a.state, sbase + (int64_t)(s + a.T) * a.ssl, a.sdt));
+  }
+  for (int t = 0; t < a.T; t++) {
+    float xv = load_rt(a.x, (int64_t)b * a.xsb + (int64_t)c * a.xsc + (int64_t)t * a.xsl, a.xdt);
+    win[a.W - 1] = xv;
+    float acc = bias;
+    for (int k = 0; k < a.W; k++) acc += w[k] * win[k];
+    if (a.silu) acc = silu_f(acc);
+    store_rt(a.out, (int64_t)b * a.osb + (int64_t)c * a.osc + (int64_t)t * a.osl, a.xdt, acc);
+    for (int k = 0; k + 1 < a.W; k++) win[k] = win[k + 1];
+    int spos = a.S - a.T + t;
+    if (spos >= 0) store_rt(a.state, sbase + (int64_t)spos * a.ssl, a.sdt, xv);
+  }
+}
+
+static bool cl_fast_ok(const OmkTensor& t, int C) {   // (B, C, L) logical, channel contiguous, 16-byte rows (8 x 2-byte)
+  return t.stride[1] == 1 && (t.stride[0] % 8) == 0 && (t.stride[2] % 8) == 0 && aligned16(t) && (C % 8) == 0;
+}
+
+static int fill_common(ConvArgs& a, const OmkTensor& x, const OmkTensor& w, const OmkTensor& bias, const OmkTensor& init, const char* who) {
+  OMK_REQUIRE(x.ndim == 3 && w.ndim == 2, "%s: x must be (B, C, L), weight (C, W)", who);
+  a.B = (int)x.shape[0]; a.C = (int)x.shape[1]; a.L = (int)x.shape[2]; a.W = (int)w.shape[1];
+  OMK_REQUIRE(w.shape[0] == a.C && a.W >= 2 && a.W <= CONV_MAXW, "%s: weight must be (C, W) with W in 2..4", who);
+  a.x = x.data; a.xsb = x.stride[0]; a.xsc = x.stride[1]; a.xsl = x.stride[2];
+  a.w = w.data; a.wsc = w.stride[0]; a.wsk = w.stride[1]; a.wdt = w.dtype;
+  a.bias = bias.data; a.bdt = bias.dtype;
+  if (present(bias)) OMK_REQUIRE(numel(bias) == a.C && is_contig_last(bias), "%s: bias must be (C) contiguous", who);
+  a.init = init.data; a.idt = init.dtype;
+  if (present(init)) {
+    OMK_REQUIRE(init.ndim == 3 && init.shape[0] == a.B && init.shape[1] == a.C && init.shape[2] == a.W - 1, "%s: initial_states must be (B, C, W-1)", who);
+    a.isb = init.stride[0]; a.isc = init.stride[1]; a.isl = init.stride[2];
+  }
+  return OMK_OK;
+}
+
+}  // namespace omk
+
+using namespace omk;
+
+extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->x) && present(p->weight) && present(p->out), "causal_conv1d_fwd: x, weight, out required");
+  ConvArgs a = {};
+  int rc = fill_common(a, p->x, p->weight, p->bias, p->initial_states, "causal_conv1d_fwd");
+  if (rc) return rc;
+  OMK_REQUIRE(p->out.ndim == 3 && p->out.shape[0] == a.B && p->out.shape[1] == a.C && p->out.shape[2] == a.L && p->out.dtype == p->x.dtype, "causal_conv1d_fwd: out mismatch");
+  a.out = p->out.data; a.osb = p->out.stride[0]; a.osc = p->out.stride[1]; a.osl = p->out.stride[2];
+  a.silu = p->silu;
+  a.fin = p->final_states.data; a.fdt = p->final_states.dtype;
+  if (present(p->final_states)) {
+    OMK_REQUIRE(p->final_states.ndim == 3 && p->final_states.shape[2] == a.W - 1, "causal_conv1d_fwd: final_states must be (B, C, W-1)");
+    a.fsb = p->final_states.stride[0]; a.fsc = p->final_states.stride[1]; a.fsl = p->final_states.stride[2];
+  }
+  if ((int64_t)a.B * a.C * a.L == 0) return OMK_OK;
+  const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->out, a.C);
+  if (fast) {
+    constexpr int TL = 32;
+    int64_t n = (int64_t)a.B * ((a.L + TL - 1) / TL) * (a.C / 8);
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define CONV_FWD_W(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, 8, TL, 4>), grid, block, 0, stream, a); \
+      else if (a.W == 3) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, 8, TL, 3>), grid, block, 0, stream, a); \
+      else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, 8, TL, 2>), grid, block, 0, stream, a); } while (0)
+    if (p->x.dtype == OMK_BF16) CONV_FWD_W(bf16_t); else CONV_FWD_W(f16_t);
+#undef CONV_FWD_W
+  } else {
+    int64_t n = (int64_t)a.B * a.C * a.L;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    int lf = (a.xsl == 1 && a.xsc != 1) ? 1 : 0;
+    OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_fwd_generic_kernel<T>), grid, block, 0, stream, a, lf));
+    if (a.fin) {
+      int64_t m = (int64_t)a.B * a.C * (a.W - 1);
+      dim3 g2((unsigned)((m + 255) / 256));
+      OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_final_states_kernel<T>), g2, block, 0, stream, a));
+    }
+  }
+  return finish_launch("causal_conv1d_fwd");
+}
+
+extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->x) && present(p->weight) && present(p->dout) && present(p->dx) && present(p->dweight), "causal_conv1d_bwd: x, weight, dout, dx, dweight required");
+  ConvArgs a = {};
+  int rc = fill_common(a, p->x, p->weight, p->bias, p->initial_states, "causal_conv1d_bwd");
+  if (rc) return rc;
+  OMK_REQUIRE(p->dout.dtype == p->x.dtype && p->dx.dtype == p->x.dtype, "causal_conv1d_bwd: dout/dx dtype must equal x dtype");
+  OMK_REQUIRE(p->dweight.dtype == OMK_F32 && p->dweight.stride[1] == 1 && p->dweight.stride[0] == a.W, "causal_conv1d_bwd: dweight must be contiguous f32 (C, W)");
+  OMK_REQUIRE(!present(p->dbias) || p->dbias.dtype == OMK_F32, "causal_conv1d_bwd: dbias must be f32");
+  a.dout = p->dout.data; a.dosb = p->dout.stride[0]; a.dosc = p->dout.stride[1]; a.dosl = p->dout.stride[2];
+  a.dx = p->dx.data; a.dxsb = p->dx.stride[0]; a.dxsc = p->dx.stride[1]; a.dxsl = p->dx.stride[2];
+  a.dw = (float*)p->dweight.data; a.db = (float*)p->dbias.data; a.silu = p->silu;
+  a.dinit = p->dinitial_states.data;
+  if (present(p->dinitial_states)) {
+    OMK_REQUIRE(present(p->initial_states) && p->dinitial_states.dtype == p->initial_states.dtype, "causal_conv1d_bwd: dinitial_states needs initial_states of the same dtype");
+    a.disb = p->dinitial_states.stride[0]; a.disc = p->dinitial_states.stride[1]; a.disl = p->dinitial_states.stride[2];
+  }
+  if ((int64_t)a.B * a.C * a.L == 0) return OMK_OK;
+  const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->dout, a.C) && cl_fast_ok(p->dx, a.C);
+  dim3 block(256);
+  if (fast) {
+    constexpr int TL = 128;
+    int64_t n = (int64_t)a.B * ((a.L + TL - 1) / TL) * (a.C / 8);
+    dim3 grid((unsigned)((n + 255) / 256));
+#define CONV_BWD_W(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 4>), grid, block, 0, stream, a); \
+      else if (a.W == 3) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 3>), grid, block, 0, stream, a); \
+      else OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 2>), grid, block, 0, stream, a); } while (0)
+    if (p->x.dtype == OMK_BF16) CONV_BWD_W(bf16_t); else CONV_BWD_W(f16_t);
+#undef CONV_BWD_W
+  } else {
+    int64_t n = (int64_t)a.B * a.C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_bwd_generic_kernel<T>), grid, block, 0, stream, a));
+  }
+  if (a.dinit) {
+    int64_t m = (int64_t)a.B * a.C * (a.W - 1);
+    dim3 g2((unsigned)((m + 255) / 256));
+    OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_dinit_kernel<T>), g2, block, 0, stream, a));
+  }
+  return finish_launch("causal_conv1d_bwd");
+}
+
+extern "C" int omk_causal_conv1d_update(const OmkConv1dUpdate* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->x) && present(p->conv_state) && present(p->weight) && present(p->out), "causal_conv1d_update: x, conv_state, weight, out required");
+  OMK_REQUIRE(p->x.ndim == 3 && p->conv_state.ndim == 3 && p->out.ndim == 3 && p->weight.ndim == 2, "causal_conv1d_update: x/out (B, C, T), conv_state (B, C, S), weight (C, W)");
+  ConvUpdArgs a = {};
+  a.B = (int)p->x.shape[0]; a.C = (int)p->x.shape[1]; a.T = (int)p->x.shape[2]; a.S = (int)p->conv_state.shape[2]; a.W = (int)p->weight.shape[1];
+  OMK_REQUIRE(a.W >= 2 && a.W <= CONV_MAXW && a.S >= a.W - 1, "causal_conv1d_update: W in 2..4 and state_len >= W-1");
+  OMK_REQUIRE(p->conv_state.shape[0] == a.B && p->conv_state.shape[1] == a.C && p->weight.shape[0] == a.C, "causal_conv1d_update: shape mismatch");
+  OMK_REQUIRE(p->out.dtype == p->x.dtype, "causal_conv1d_update: out dtype");
+  a.x = p->x.data; a.state = p->conv_state.data; a.w = p->weight.data; a.bias = p->bias.data; a.out = p->out.data;
+  a.xsb = p->x.stride[0]; a.xsc = p->x.stride[1]; a.xsl = p->x.stride[2];
+  a.ssb = p->conv_state.stride[0]; a.ssc = p->conv_state.stride[1]; a.ssl = p->conv_state.stride[2];
+  a.osb = p->out.stride[0]; a.osc = p->out.stride[1]; a.osl = p->out.stride[2];
+  a.wsc = p->weight.stride[0]; a.wsk = p->weight.stride[1];
+  a.silu = p->silu; a.xdt = p->x.dtype; a.sdt = p->conv_state.dtype; a.wdt = p->weight.dtype; a.bdt = p->bias.dtype;
+  if ((int64_t)a.B * a.C * a.T == 0) return OMK_OK;
+  int64_t n = (int64_t)a.B * a.C;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  OMK_LAUNCH(conv1d_update_kernel, grid, block, 0, stream, a);
+  return finish_launch("causal_conv1d_update");
+}

@@ -1,0 +1,86 @@
+// omk_common.h -- host-side validation helpers and dtype-generic device load/store shared by all kernels.
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/omk.h"
+#include "omk_platform.h"
+
+namespace omk {
+
+// ---- thread-local error text --------------------------------------------------------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+#define OMK_REQUIRE(cond, ...) \
+  do { if (!(cond)) return ::omk::fail(OMK_EINVAL, __VA_ARGS__); } while (0)
+
+inline bool present(const OmkTensor& t) { return t.data != nullptr; }
+inline int64_t numel(const OmkTensor& t) {
+  int64_t n = 1;
+  for (int i = 0; i < t.ndim; i++) n *= t.shape[i];
+  return n;
+}
+inline bool is_contig_last(const OmkTensor& t) { return t.ndim == 0 || t.shape[t.ndim - 1] == 1 || t.stride[t.ndim - 1] == 1; }
+inline size_t dtype_size(int dt) { return dt == OMK_F32 ? 4 : 2; }
+inline bool aligned16(const OmkTensor& t) { return ((uintptr_t)t.data & 15) == 0; }
+// every stride except the last is a multiple of `elems` (so 16-byte vector rows stay aligned)
+inline bool strides_multiple_of(const OmkTensor& t, int64_t elems) {
+  for (int i = 0; i + 1 < t.ndim; i++)
+    if (t.shape[i] > 1 && (t.stride[i] % elems) != 0) return false;
+  return true;
+}
+int finish_launch(const char* what);
+
+// ---- storage types --------------------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+template <class T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = OMK_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = OMK_BF16; };
+template <> struct dtype_of<f16_t> { static constexpr int value = OMK_F16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v.v); }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v.v; }
+template <class T> __device__ __forceinline__ T from_f32(float f);
+template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return bf16_t{f32_to_bf16(f)}; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return f16_t{(_Float16)f}; }
+
+// runtime-dtype scalar access (parameters: a handful of loads per thread, never in the streaming loop)
+__device__ __forceinline__ float load_rt(const void* p, int64_t i, int dt) {
+  if (dt == OMK_F32) return ((const float*)p)[i];
+  if (dt == OMK_BF16) return bf16_to_f32(((const uint16_t*)p)[i]);
+  return (float)((const _Float16*)p)[i];
+}
+__device__ __forceinline__ void store_rt(void* p, int64_t i, int dt, float v) {
+  if (dt == OMK_F32) ((float*)p)[i] = v;
+  else if (dt == OMK_BF16) ((uint16_t*)p)[i] = f32_to_bf16(v);
+  else ((_Float16*)p)[i] = (_Float16)v;
+}
+
+// vector of VEC elements of storage type T <-> float[VEC]; VEC*sizeof(T) must be 4, 8 or 16 bytes
+template <class T, int VEC> struct alignas((sizeof(T) * VEC) > 16 ? 16 : (sizeof(T) * VEC)) vec_t { T e[VEC]; };
+template <class T, int VEC> __device__ __forceinline__ void load_vec(const T* p, float (&out)[VEC]) {
+  vec_t<T, VEC> v = *reinterpret_cast<const vec_t<T, VEC>*>(p);
+#pragma unroll
+  for (int i = 0; i < VEC; i++) out[i] = to_f32(v.e[i]);
+}
+template <class T, int VEC> __device__ __forceinline__ void store_vec(T* p, const float (&in)[VEC]) {
+  vec_t<T, VEC> v;
+#pragma unroll
+  for (int i = 0; i < VEC; i++) v.e[i] = from_f32<T>(in[i]);
+  *reinterpret_cast<vec_t<T, VEC>*>(p) = v;
+}
+
+// dtype dispatch: calls FN<T>(...) for the storage type matching `dt`
+#define OMK_DISPATCH_DTYPE(dt, T, ...)                                  \
+  do {                                                                  \
+    if ((dt) == OMK_F32) { using T = float; __VA_ARGS__; }              \
+    else if ((dt) == OMK_BF16) { using T = ::omk::bf16_t; __VA_ARGS__; } \
+    else if ((dt) == OMK_F16) { using T = ::omk::f16_t; __VA_ARGS__; }   \
+    else return ::omk::fail(OMK_EINVAL, "bad dtype %d", (int)(dt));     \
+  } while (0)
+
+}  // namespace omk

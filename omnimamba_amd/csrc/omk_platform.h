@@ -1,0 +1,149 @@
+// omk_platform.h -- the one place where the kernels touch the platform.
+//   default build : hipcc --offload-arch=gfx950 (CDNA4 only; no other GPU target is supported)
+//   -DOMK_EMU     : host build against tests/emu/hip_emu.h, used only by the CPU test-suite
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#ifdef OMK_EMU
+#include "hip_emu.h"
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+using emu::dim3;
+#define threadIdx (emu::cur().tIdx)
+#define blockIdx (emu::blk()->bIdx)
+#define blockDim (emu::blk()->bDim)
+#define gridDim (emu::blk()->gDim)
+typedef void* hipStream_t;
+#define OMK_DYN_SMEM(name) char* name = emu::blk()->dyn_smem
+#define OMK_LAUNCH(kern, grid, block, smem, stream, ...) \
+  emu::launch(grid, block, smem, [&] { kern(__VA_ARGS__); })
+#define OMK_LAUNCH_CHECK() 0
+#define OMK_SET_MAX_DYN_SMEM(kern, bytes) 0
+#else
+#include <hip/hip_runtime.h>
+#define OMK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define OMK_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#define OMK_LAUNCH_CHECK() (hipGetLastError() != hipSuccess)
+#define OMK_SET_MAX_DYN_SMEM(kern, bytes) \
+  (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess)
+#endif
+
+namespace omk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- bf16 <-> f32 (round-to-nearest-even; identical bits in both builds) ---------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+#ifdef OMK_EMU
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+#else
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 on gfx950 (RNE)
+  uint16_t r;
+  memcpy(&r, &b, 2);
+  return r;
+#endif
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- wave-level primitives (wave = 64 lanes on CDNA) --------------------------------------------------
+#ifdef OMK_EMU
+__device__ __forceinline__ int lane_id() { return emu::lane_id(); }
+template <class T> __device__ __forceinline__ T shfl(T v, int src) { return emu::shfl_generic(v, src); }
+template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return emu::shfl_generic(v, emu::lane_id() ^ m); }
+template <class T> __device__ __forceinline__ T shfl_up(T v, int d) {
+  int l = emu::lane_id();
+  return emu::shfl_generic(v, l - d >= 0 ? l - d : l);
+}
+template <class T> __device__ __forceinline__ T shfl_down(T v, int d) {
+  int l = emu::lane_id();
+  return emu::shfl_generic(v, l + d < 64 ? l + d : l);
+}
+__device__ __forceinline__ void block_sync() { emu::block_barrier(); }
+__device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+  emu::Wave& w = emu::cur_wave();
+  int l = emu::lane_id();
+  for (int e = 0; e < 8; e++) { w.a16[l][e] = (uint16_t)a[e]; w.b16[l][e] = (uint16_t)b[e]; }
+  for (int r = 0; r < 16; r++) w.c32[l][r] = c[r];
+  emu::wave_collective(emu::op_mfma32);
+  f32x16 d;
+  for (int r = 0; r < 16; r++) d[r] = w.d32[l][r];
+  return d;
+}
+__device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+  emu::Wave& w = emu::cur_wave();
+  int l = emu::lane_id();
+  for (int e = 0; e < 8; e++) { w.a16[l][e] = (uint16_t)a[e]; w.b16[l][e] = (uint16_t)b[e]; }
+  for (int r = 0; r < 4; r++) w.c32[l][r] = c[r];
+  emu::wave_collective(emu::op_mfma16);
+  f32x4 d;
+  for (int r = 0; r < 4; r++) d[r] = w.d32[l][r];
+  return d;
+}
+// ds_read_b64_tr_b16: lane passes the address of ITS 8 bytes; gets column (lane&15) of the 4x16 block that its
+// 16-lane group fetched (rows = lanes t/4, columns = 4*(t%4)+e).
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
+  emu::Wave& w = emu::cur_wave();
+  int l = emu::lane_id();
+  for (int e = 0; e < 4; e++) w.tr_in[l][e] = p[e];
+  emu::wave_collective(emu::op_tr16);
+  s16x4 r;
+  for (int e = 0; e < 4; e++) r[e] = (short)w.tr_out[l][e];
+  return r;
+}
+__device__ __forceinline__ float atomic_add_f32(float* p, float v) { float o = *p; *p = o + v; return o; }
+#else
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+template <class T> __device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src, 64); }
+template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+template <class T> __device__ __forceinline__ T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
+template <class T> __device__ __forceinline__ T shfl_down(T v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ float atomic_add_f32(float* p, float v) { return unsafeAtomicAdd(p, v); }
+#endif
+
+template <class T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+
+// ---- math ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }
+
+}  // namespace omk

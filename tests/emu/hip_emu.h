@@ -17,6 +17,8 @@
 #include <functional>
 #include <vector>
 
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
 namespace emu {
 
 struct dim3 {
