@@ -207,6 +207,7 @@ typedef struct {
   OmkTensor dt_bias;        /* optional (H) */
   OmkTensor initial_states; /* optional (B, H, P, N) */
   OmkTensor out;            /* (B, L, H, P) */
+  OmkTensor out_x;          /* optional out (B, L, H, P): the pre-gate y (only meaningful with z; saved for backward) */
   OmkTensor final_states;   /* optional out (B, H, P, N) f32 */
   void* workspace;
   size_t workspace_bytes;
@@ -219,15 +220,16 @@ size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p);
 int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream);
 
 typedef struct {
-  OmkTensor x, dt, A, Bm, Cm, D, z, dt_bias, initial_states; /* as forward */
-  OmkTensor dout;            /* (B, L, H, P) grad of out */
-  OmkTensor dfinal_states;   /* optional (B, H, P, N) */
+  OmkTensor x, dt, A, Bm, Cm, D, dt_bias, initial_states; /* as forward.  z gating is NOT part of this call: the
+                                caller passes dout * silu(z) and forms dz = dout * out_x * silu'(z) itself (out_x = the
+                                forward's pre-gate output) */
+  OmkTensor dout;            /* (B, L, H, P) grad of the (pre-gate) output */
+  OmkTensor dfinal_states;   /* optional (B, H, P, N) f32 */
   OmkTensor dx;              /* out (B, L, H, P) */
   OmkTensor ddt;             /* out (B, L, H) f32: grad wrt RAW dt */
   OmkTensor dA;              /* out (H) f32 */
   OmkTensor dB, dC;          /* out (B, L, G, N) */
   OmkTensor dD;              /* optional out (H) or (H, P) f32 */
-  OmkTensor dz;              /* optional out (B, L, H, P) */
   OmkTensor ddt_bias;        /* optional out (H) f32 */
   OmkTensor dinitial_states; /* optional out (B, H, P, N) f32 */
   void* workspace;

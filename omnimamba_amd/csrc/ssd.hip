@@ -1,0 +1,450 @@
+// ssd.hip -- Mamba-2 SSD scan: C-ABI entry points, dt preparation, the shape-generic fp32 scan kernel and the
+// backward finishing pass.  The fast MFMA chunked kernel lives in ssd_mfma.hip; both consume GScan (ssd_scan.h).
+//
+// Forward  = 1 scan (GS_Y).  Backward = 3 scans (GS_DC, GS_DX, GS_DB) + a per-(b,h) reverse prefix over tokens
+// that turns the two per-token scalars they emit into d(dt) / dA (see tests/test_bwd_derivation.py):
+//   e_t = dy_t . y~_t            (from GS_DC:  sum_n C_t[n] O_t[n])
+//   w_t = <g_t, x_t (x) B_t>     (from GS_DB:  sum_n B_t[n] O_t[n])
+//   dl_t = e_t - dt'_t w_t + dl_{t+1} ;  d(dt')_t = w_t + A_h dl_t ;  dA_h = sum_t dt'_t dl_t
+#include "ssd_scan.h"
+
+namespace omk {
+
+// ---------------------------------------------------------------------------------------------------------
+// dt' = clamp(softplus(dt + bias)) -> (B, H, L) f32 ; dsoft = d dt' / d dt
+// ---------------------------------------------------------------------------------------------------------
+struct DtPrepArgs {
+  const void* dt; const void* bias; float* dtp; float* dsoft;
+  int64_t sb, sl, sh; int B, L, H, dt_dt, bias_dt, softplus; float lo, hi;
+};
+__global__ void ssd_dt_prep_kernel(DtPrepArgs a) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)a.B * a.L * a.H) return;
+  const int h = (int)(g % a.H), t = (int)((g / a.H) % a.L), b = (int)(g / ((int64_t)a.H * a.L));
+  float v = load_rt(a.dt, (int64_t)b * a.sb + (int64_t)t * a.sl + (int64_t)h * a.sh, a.dt_dt);
+  if (a.bias) v += load_rt(a.bias, h, a.bias_dt);
+  float d = 1.f;
+  if (a.softplus) { d = v > 20.f ? 1.f : sigmoid_f(v); v = softplus_f(v); }
+  if (v < a.lo) { v = a.lo; d = 0.f; }
+  if (v > a.hi) { v = a.hi; d = 0.f; }
+  const int64_t o = ((int64_t)b * a.H + h) * a.L + t;
+  a.dtp[o] = v;
+  if (a.dsoft) a.dsoft[o] = d;
+}
+
+__global__ void zero_f32_kernel(float* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+__global__ void cvt_f32_kernel(const float* src, void* dst, int64_t sb, int64_t sl, int64_t sg, int B, int L, int G, int N, int dt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)B * L * G * N;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int nn = (int)(i % N), g = (int)((i / N) % G), t = (int)((i / ((int64_t)N * G)) % L), b = (int)(i / ((int64_t)N * G * L));
+    store_rt(dst, (int64_t)b * sb + (int64_t)t * sl + (int64_t)g * sg + nn, dt, src[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shape-generic scan: any DU, DK, dtype; fp32 VALU.  256 threads; a state row (one u) is spread over TK lanes
+// with NPT contiguous k each; a workgroup covers RW = 256 / TK rows of one (b, h); tokens move in tiles of TT.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GEN_NPT = 16;
+constexpr int GEN_TT = 16;
+
+__device__ __forceinline__ float src_at(const Src& s, int b, int t, int h, int g, int i) {
+  return load_rt(s.p, (int64_t)b * s.sb + (int64_t)t * s.sl + (int64_t)(s.per_group ? g : h) * s.sh + i, s.dt);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
+  OMK_DYN_SMEM(smem);
+  const int RW = 256 / TK;
+  float* sU = (float*)smem;              // [TT][RW]
+  float* sX = sU + GEN_TT * RW;          // [TT][RW]  X4 rows (DC/DB) -- also Z rows for Y
+  float* sO = sX + GEN_TT * RW;          // [TT][RW]
+  float* sK = sO + GEN_TT * RW;          // [TT][DK]
+  float* sQ = sK + GEN_TT * a.DK;        // [TT][DK]
+  float* sdec = sQ + GEN_TT * a.DK;      // [TT] decay exp(a)
+  float* sw = sdec + GEN_TT;             // [TT] input scale
+  float* sdt = sw + GEN_TT;              // [TT] dt' of the token itself
+  const int ublocks = (a.DU + RW - 1) / RW;
+  const int ub = blockIdx.x % ublocks, h = (blockIdx.x / ublocks) % a.H, b = blockIdx.x / (ublocks * a.H);
+  const int g = h / (a.H / a.G);
+  const int tid = threadIdx.x, r = tid / TK, ks = tid % TK;
+  const int u = ub * RW + r;
+  const bool live = u < a.DU;
+  const int k0 = ks * GEN_NPT;
+  const float Ah = a.A[h];
+  const float* dtp = a.dtp + ((int64_t)b * a.H + h) * a.L;
+  float s[GEN_NPT];
+#pragma unroll
+  for (int j = 0; j < GEN_NPT; j++) {
+    const int k = k0 + j;
+    s[j] = (a.init && live && k < a.DK) ? load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt) : 0.f;
+  }
+  float dDacc = 0.f;
+  const int nT = (a.L + GEN_TT - 1) / GEN_TT;
+  for (int ti = 0; ti < nT; ti++) {
+    const int tile = a.reverse ? nT - 1 - ti : ti;
+    const int t0 = tile * GEN_TT;
+    const int nl = (a.L - t0) < GEN_TT ? (a.L - t0) : GEN_TT;
+    for (int i = tid; i < GEN_TT * RW; i += 256) {
+      const int t = i / RW, rr = i % RW, uu = ub * RW + rr;
+      const bool ok = t < nl && uu < a.DU;
+      sU[i] = ok ? src_at(a.U, b, t0 + t, h, g, uu) : 0.f;
+      if (MODE == GS_DC || MODE == GS_DB) sX[i] = ok ? src_at(a.X4, b, t0 + t, h, g, uu) : 0.f;
+      if (MODE == GS_Y) sX[i] = (ok && a.Z.p) ? src_at(a.Z, b, t0 + t, h, g, uu) : 0.f;
+    }
+    for (int i = tid; i < GEN_TT * a.DK; i += 256) {
+      const int t = i / a.DK, k = i % a.DK;
+      sK[i] = t < nl ? src_at(a.K, b, t0 + t, h, g, k) : 0.f;
+      sQ[i] = t < nl ? src_at(a.Q, b, t0 + t, h, g, k) : 0.f;
+    }
+    if (tid < GEN_TT) {
+      const int t = t0 + tid;
+      float d = 0.f, w = 0.f, la = 0.f;
+      if (tid < nl) {
+        d = dtp[t];
+        const int ta = a.reverse ? t + 1 : t;                 // reverse scans decay with a_{t+1}
+        la = ta < a.L ? dtp[ta] * Ah : 0.f;
+        w = a.w_is_dt ? d : 1.f;
+      }
+      sdec[tid] = expf(la); sw[tid] = w; sdt[tid] = d;
+    }
+    block_sync();
+    for (int tt = 0; tt < nl; tt++) {
+      const int t = a.reverse ? nl - 1 - tt : tt;
+      const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < GEN_NPT; j++) {
+        const int k = k0 + j;
+        if (k < a.DK) {
+          s[j] = s[j] * dec + wu * sK[t * a.DK + k];
+          acc += s[j] * sQ[t * a.DK + k];
+        }
+      }
+      for (int m = TK >> 1; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
+      if (ks == 0) sO[t * RW + r] = acc;
+    }
+    block_sync();
+    // ---- epilogue over the tile
+    if (MODE == GS_Y || MODE == GS_DX) {
+      for (int i = tid; i < GEN_TT * RW; i += 256) {
+        const int t = i / RW, rr = i % RW, uu = ub * RW + rr;
+        if (t < nl && uu < a.DU) {
+          float v = sO[i];
+          const float Dv = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)uu * a.Dsp, a.D_dt) : 0.f;
+          if (MODE == GS_DX) v *= sdt[t];
+          v += Dv * sU[i];
+          const int64_t o = (int64_t)b * a.osb + (int64_t)(t0 + t) * a.osl + (int64_t)h * a.osh + uu;
+          if (MODE == GS_Y) {
+            if (a.outx) store_rt(a.outx, o, a.out_dt, v);
+            if (a.Z.p) v *= silu_f(sX[i]);
+          }
+          store_rt(a.out, o, a.out_dt, v);
+        }
+      }
+    } else {
+      for (int i = tid; i < GEN_TT * RW; i += 256) {
+        const int t = i / RW, rr = i % RW, uu = ub * RW + rr;
+        if (t < nl && uu < a.DU) {
+          float v = sO[i];
+          if (MODE == GS_DB) v *= sdt[t];
+          atomic_add_f32(a.acc32 + (((int64_t)b * a.L + (t0 + t)) * a.G + g) * a.DU + uu, v);
+        }
+      }
+      if (tid < nl) {   // token scalar: sum over this workgroup's rows of X4[t][u] * O[t][u]
+        float sc = 0.f;
+        for (int rr = 0; rr < RW; rr++) sc += sX[tid * RW + rr] * sO[tid * RW + rr];
+        atomic_add_f32(a.tokscal + ((int64_t)b * a.H + h) * a.L + t0 + tid, sc);
+      }
+      if (MODE == GS_DB && a.dD && ub == 0 && tid < a.DK) {
+        for (int t = 0; t < nl; t++) dDacc += sK[t * a.DK + tid] * sQ[t * a.DK + tid];
+      }
+    }
+    block_sync();
+  }
+  if (MODE == GS_DB && a.dD && ub == 0 && tid < a.DK) atomic_add_f32(a.dD + (int64_t)h * a.dDsh + (int64_t)tid * a.dDsp, dDacc);
+  if (a.fin && live) {
+    const float extra = a.fin_extra_decay ? expf(dtp[0] * Ah) : 1.f;
+#pragma unroll
+    for (int j = 0; j < GEN_NPT; j++) {
+      const int k = k0 + j;
+      if (k < a.DK) a.fin[(int64_t)b * a.fsb + (int64_t)h * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = s[j] * extra;
+    }
+  }
+}
+
+int ssd_generic_launch(const GScan& g, omk_stream stream) {
+  int TK = 1;
+  while (TK * GEN_NPT < g.DK) TK <<= 1;
+  if (TK > 64) return fail(OMK_EUNSUPPORTED, "ssd generic scan: inner dim %d too large", g.DK);
+  const int RW = 256 / TK;
+  const int ublocks = (g.DU + RW - 1) / RW;
+  dim3 grid((unsigned)((int64_t)g.B * g.H * ublocks)), block(256);
+  const size_t smem = (size_t)(GEN_TT * (3 * RW + 2 * g.DK) + 3 * GEN_TT) * 4;
+  switch (g.mode) {
+    case GS_Y: OMK_LAUNCH((ssd_generic_kernel<GS_Y>), grid, block, smem, stream, g, TK); break;
+    case GS_DC: OMK_LAUNCH((ssd_generic_kernel<GS_DC>), grid, block, smem, stream, g, TK); break;
+    case GS_DX: OMK_LAUNCH((ssd_generic_kernel<GS_DX>), grid, block, smem, stream, g, TK); break;
+    default: OMK_LAUNCH((ssd_generic_kernel<GS_DB>), grid, block, smem, stream, g, TK); break;
+  }
+  return OMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward finishing pass: one wave per (b, h), reverse inclusive prefix over tokens with wave shuffles
+// ---------------------------------------------------------------------------------------------------------
+struct FinishArgs {
+  const float* e; const float* wsum; const float* dtp; const float* dsoft; const float* A;
+  const float* dfin; int64_t dfsb, dfsh, dfsp, dfsn; const float* sfin;   // sfin: (B, H, N, P) contiguous f32 from the dC scan
+  void* ddt; int64_t dsb, dsl, dsh; int ddt_dt;
+  float* dA; float* ddtb;
+  int B, H, L, P, N;
+};
+__global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, lane = threadIdx.x;
+  const int64_t base = (int64_t)bh * a.L;
+  const float Ah = a.A[h];
+  float carry = 0.f;
+  if (a.dfin) {   // dl_L = <dfinal_states, S_final>
+    float acc = 0.f;
+    for (int i = lane; i < a.P * a.N; i += 64) {
+      const int n = i / a.P, p = i % a.P;
+      acc += a.sfin[(int64_t)bh * a.P * a.N + i] * a.dfin[(int64_t)b * a.dfsb + (int64_t)h * a.dfsh + (int64_t)p * a.dfsp + (int64_t)n * a.dfsn];
+    }
+    carry = wave_sum(acc);
+  }
+  float dAacc = 0.f, dbacc = 0.f;
+  const int nT = (a.L + 63) / 64;
+  for (int ti = nT - 1; ti >= 0; ti--) {
+    const int t = ti * 64 + lane;
+    const bool ok = t < a.L;
+    const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
+    float v = ok ? a.e[base + t] - d * w : 0.f;
+    // inclusive suffix sum within the wave: v_l = sum_{j >= l} v_j
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      float o = shfl_down(v, off);
+      if (lane + off < 64) v += o;
+    }
+    const float dl = v + carry;
+    carry = shfl(dl, 0);
+    if (ok) {
+      const float ddtp = w + Ah * dl;
+      const float draw = ddtp * a.dsoft[base + t];
+      dAacc += d * dl;
+      dbacc += draw;
+      store_rt(a.ddt, (int64_t)b * a.dsb + (int64_t)t * a.dsl + (int64_t)h * a.dsh, a.ddt_dt, draw);
+    }
+  }
+  dAacc = wave_sum(dAacc); dbacc = wave_sum(dbacc);
+  if (lane == 0) {
+    atomic_add_f32(a.dA + h, dAacc);
+    if (a.ddtb) atomic_add_f32(a.ddtb + h, dbacc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static Src make_src(const OmkTensor& t, bool per_group) {   // (B, L, H|G, dim) with unit stride on dim
+  Src s; s.p = t.data; s.sb = t.stride[0]; s.sl = t.stride[1]; s.sh = t.stride[2]; s.dt = t.dtype; s.per_group = per_group ? 1 : 0;
+  return s;
+}
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct SsdDims { int B, L, H, P, G, N; };
+static int ssd_check_common(const OmkTensor& x, const OmkTensor& dt, const OmkTensor& A, const OmkTensor& Bm, const OmkTensor& Cm,
+                            const OmkTensor& D, const OmkTensor& dtb, const OmkTensor& init, SsdDims* d, const char* who) {
+  OMK_REQUIRE(present(x) && present(dt) && present(A) && present(Bm) && present(Cm), "%s: x, dt, A, B, C required", who);
+  OMK_REQUIRE(x.ndim == 4 && dt.ndim == 3 && Bm.ndim == 4 && Cm.ndim == 4, "%s: x (B,L,H,P), dt (B,L,H), B/C (B,L,G,N)", who);
+  d->B = (int)x.shape[0]; d->L = (int)x.shape[1]; d->H = (int)x.shape[2]; d->P = (int)x.shape[3]; d->G = (int)Bm.shape[2]; d->N = (int)Bm.shape[3];
+  OMK_REQUIRE(d->G > 0 && d->H % d->G == 0, "%s: nheads must be a multiple of ngroups", who);
+  OMK_REQUIRE(dt.shape[0] == d->B && dt.shape[1] == d->L && dt.shape[2] == d->H, "%s: dt shape", who);
+  OMK_REQUIRE(Bm.shape[0] == d->B && Bm.shape[1] == d->L && Cm.shape[0] == d->B && Cm.shape[1] == d->L && Cm.shape[2] == d->G && Cm.shape[3] == d->N, "%s: B/C shape", who);
+  OMK_REQUIRE(x.stride[3] == 1 && Bm.stride[3] == 1 && Cm.stride[3] == 1, "%s: x, B, C need unit stride on the last dim", who);
+  OMK_REQUIRE(A.dtype == OMK_F32 && numel(A) == d->H && is_contig_last(A), "%s: A must be f32 (H)", who);
+  if (present(D)) OMK_REQUIRE((D.ndim == 1 && D.shape[0] == d->H) || (D.ndim == 2 && D.shape[0] == d->H && D.shape[1] == d->P), "%s: D must be (H) or (H, P)", who);
+  if (present(dtb)) OMK_REQUIRE(numel(dtb) == d->H && is_contig_last(dtb), "%s: dt_bias must be (H)", who);
+  if (present(init)) OMK_REQUIRE(init.ndim == 4 && init.shape[0] == d->B && init.shape[1] == d->H && init.shape[2] == d->P && init.shape[3] == d->N, "%s: initial_states must be (B,H,P,N)", who);
+  return OMK_OK;
+}
+
+static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdDims& d, float* dtp, float* dsoft, int softplus, float lo, float hi, omk_stream stream) {
+  DtPrepArgs a = {};
+  a.dt = dt.data; a.bias = dtb.data; a.dtp = dtp; a.dsoft = dsoft; a.sb = dt.stride[0]; a.sl = dt.stride[1]; a.sh = dt.stride[2];
+  a.B = d.B; a.L = d.L; a.H = d.H; a.dt_dt = dt.dtype; a.bias_dt = dtb.dtype; a.softplus = softplus; a.lo = lo;
+  a.hi = hi > 0.f ? hi : INFINITY;
+  int64_t n = (int64_t)d.B * d.L * d.H;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  OMK_LAUNCH(ssd_dt_prep_kernel, grid, block, 0, stream, a);
+}
+static void launch_zero(float* p, int64_t n, omk_stream stream) {
+  if (n <= 0) return;
+  int64_t blocks = (n + 255) / 256;
+  dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks)), block(256);
+  OMK_LAUNCH(zero_f32_kernel, grid, block, 0, stream, p, n);
+}
+static int run_scan(const GScan& g, int force_generic, omk_stream stream) {
+  if (!force_generic) {
+    int rc = ssd_mfma_launch(g, stream);
+    if (rc != OMK_EUNSUPPORTED) return rc;
+  }
+  return ssd_generic_launch(g, stream);
+}
+
+}  // namespace omk
+
+using namespace omk;
+
+extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
+  if (!p) return 0;
+  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4);
+}
+
+extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->out), "ssd_scan_fwd: out required");
+  SsdDims d;
+  int rc = ssd_check_common(p->x, p->dt, p->A, p->Bm, p->Cm, p->D, p->dt_bias, p->initial_states, &d, "ssd_scan_fwd");
+  if (rc) return rc;
+  OMK_REQUIRE(p->out.ndim == 4 && p->out.shape[0] == d.B && p->out.shape[1] == d.L && p->out.shape[2] == d.H && p->out.shape[3] == d.P && p->out.stride[3] == 1, "ssd_scan_fwd: out must be (B,L,H,P) with unit last stride");
+  OMK_REQUIRE(p->Bm.dtype == p->x.dtype && p->Cm.dtype == p->x.dtype && p->out.dtype == p->x.dtype, "ssd_scan_fwd: B, C, out must have x's dtype");
+  if (present(p->z)) OMK_REQUIRE(p->z.ndim == 4 && p->z.stride[3] == 1 && p->z.dtype == p->x.dtype, "ssd_scan_fwd: z must be (B,L,H,P) of x's dtype");
+  if (present(p->out_x)) OMK_REQUIRE(p->out_x.dtype == p->out.dtype && p->out_x.stride[0] == p->out.stride[0] && p->out_x.stride[1] == p->out.stride[1] && p->out_x.stride[2] == p->out.stride[2], "ssd_scan_fwd: out_x must match out's dtype and strides");
+  if (present(p->final_states)) OMK_REQUIRE(p->final_states.dtype == OMK_F32 && p->final_states.ndim == 4, "ssd_scan_fwd: final_states must be f32 (B,H,P,N)");
+  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p), "ssd_scan_fwd: workspace too small");
+  if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
+  float* dtp = (float*)p->workspace;
+  launch_dt_prep(p->dt, p->dt_bias, d, dtp, nullptr, p->dt_softplus, p->dt_min, p->dt_max, stream);
+  GScan g = {};
+  g.mode = GS_Y; g.U = make_src(p->x, false); g.K = make_src(p->Bm, true); g.Q = make_src(p->Cm, true);
+  if (present(p->z)) g.Z = make_src(p->z, false);
+  g.dtp = dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L; g.DU = d.P; g.DK = d.N; g.reverse = 0; g.w_is_dt = 1;
+  if (present(p->initial_states)) {
+    g.init = p->initial_states.data; g.init_dt = p->initial_states.dtype;
+    g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isu = p->initial_states.stride[2]; g.isk = p->initial_states.stride[3];
+  }
+  if (present(p->final_states)) {
+    g.fin = (float*)p->final_states.data;
+    g.fsb = p->final_states.stride[0]; g.fsh = p->final_states.stride[1]; g.fsu = p->final_states.stride[2]; g.fsk = p->final_states.stride[3];
+  }
+  g.out = p->out.data; g.osb = p->out.stride[0]; g.osl = p->out.stride[1]; g.osh = p->out.stride[2]; g.out_dt = p->out.dtype; g.outx = p->out_x.data;
+  if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
+  rc = run_scan(g, p->force_generic, stream);
+  if (rc) return rc;
+  return finish_launch("ssd_scan_fwd");
+}
+
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin; size_t total; };
+static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin) {
+  BwdWs w; size_t off = 0; char* c = (char*)base;
+  auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
+  const size_t bhl = (size_t)B * H * L * 4, blgn = (size_t)B * L * G * N * 4;
+  w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl); w.dB32 = take(blgn); w.dC32 = take(blgn);
+  w.sfin = need_sfin ? take((size_t)B * H * P * N * 4) : nullptr;
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p) {
+  if (!p) return 0;
+  return bwd_ws_layout(nullptr, (int)p->x.shape[0], (int)p->x.shape[1], (int)p->x.shape[2], (int)p->x.shape[3], (int)p->Bm.shape[2], (int)p->Bm.shape[3], present(p->dfinal_states)).total;
+}
+
+extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->dout) && present(p->dx) && present(p->ddt) && present(p->dA) && present(p->dB) && present(p->dC), "ssd_scan_bwd: dout, dx, ddt, dA, dB, dC required");
+  SsdDims d;
+  int rc = ssd_check_common(p->x, p->dt, p->A, p->Bm, p->Cm, p->D, p->dt_bias, p->initial_states, &d, "ssd_scan_bwd");
+  if (rc) return rc;
+  OMK_REQUIRE(p->dout.ndim == 4 && p->dout.stride[3] == 1 && p->dout.dtype == p->x.dtype, "ssd_scan_bwd: dout must be (B,L,H,P) of x's dtype, unit last stride");
+  OMK_REQUIRE(p->dx.ndim == 4 && p->dx.stride[3] == 1 && p->dx.dtype == p->x.dtype, "ssd_scan_bwd: dx must be (B,L,H,P) of x's dtype");
+  OMK_REQUIRE(p->Bm.dtype == p->x.dtype && p->Cm.dtype == p->x.dtype, "ssd_scan_bwd: B, C must have x's dtype");
+  OMK_REQUIRE(p->dB.ndim == 4 && p->dC.ndim == 4 && p->dB.stride[3] == 1 && p->dC.stride[3] == 1, "ssd_scan_bwd: dB/dC must be (B,L,G,N) with unit last stride");
+  OMK_REQUIRE(p->dA.dtype == OMK_F32 && is_contig_last(p->dA), "ssd_scan_bwd: dA must be f32 (H)");
+  OMK_REQUIRE(p->ddt.ndim == 3, "ssd_scan_bwd: ddt must be (B,L,H)");
+  if (present(p->dD)) OMK_REQUIRE(p->dD.dtype == OMK_F32 && present(p->D) && p->dD.ndim == p->D.ndim, "ssd_scan_bwd: dD must be f32 with D's shape");
+  if (present(p->ddt_bias)) OMK_REQUIRE(p->ddt_bias.dtype == OMK_F32, "ssd_scan_bwd: ddt_bias must be f32");
+  if (present(p->dinitial_states)) OMK_REQUIRE(p->dinitial_states.dtype == OMK_F32 && p->dinitial_states.ndim == 4, "ssd_scan_bwd: dinitial_states must be f32 (B,H,P,N)");
+  if (present(p->dfinal_states)) OMK_REQUIRE(p->dfinal_states.dtype == OMK_F32 && p->dfinal_states.ndim == 4, "ssd_scan_bwd: dfinal_states must be f32 (B,H,P,N)");
+  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_bwd_workspace_bytes(p), "ssd_scan_bwd: workspace too small");
+  if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
+  const bool has_dfin = present(p->dfinal_states);
+  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin);
+  const int64_t bhl = (int64_t)d.B * d.H * d.L, blgn = (int64_t)d.B * d.L * d.G * d.N;
+  launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream);
+  launch_zero((float*)p->dA.data, d.H, stream);
+  if (present(p->dD)) launch_zero((float*)p->dD.data, numel(p->dD), stream);
+  if (present(p->ddt_bias)) launch_zero((float*)p->ddt_bias.data, d.H, stream);
+  launch_dt_prep(p->dt, p->dt_bias, d, w.dtp, w.dsoft, p->dt_softplus, p->dt_min, p->dt_max, stream);
+  const float* A = (const float*)p->A.data;
+  auto base = [&](int mode) {
+    GScan g = {};
+    g.mode = mode; g.dtp = w.dtp; g.A = A; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L;
+    return g;
+  };
+  {  // dC: state [n][p], forward in time
+    GScan g = base(GS_DC);
+    g.U = make_src(p->Bm, true); g.K = make_src(p->x, false); g.Q = make_src(p->dout, false); g.X4 = make_src(p->Cm, true);
+    g.DU = d.N; g.DK = d.P; g.reverse = 0; g.w_is_dt = 1;
+    if (present(p->initial_states)) {
+      g.init = p->initial_states.data; g.init_dt = p->initial_states.dtype;
+      g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isk = p->initial_states.stride[2]; g.isu = p->initial_states.stride[3];
+    }
+    if (has_dfin) { g.fin = w.sfin; g.fsb = (int64_t)d.H * d.N * d.P; g.fsh = (int64_t)d.N * d.P; g.fsu = d.P; g.fsk = 1; }
+    g.acc32 = w.dC32; g.tokscal = w.e;
+    rc = run_scan(g, p->force_generic, stream);
+    if (rc) return rc;
+  }
+  {  // dx: state [p][n], reverse in time
+    GScan g = base(GS_DX);
+    g.U = make_src(p->dout, false); g.K = make_src(p->Cm, true); g.Q = make_src(p->Bm, true);
+    g.DU = d.P; g.DK = d.N; g.reverse = 1; g.w_is_dt = 0;
+    if (has_dfin) {
+      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
+      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isu = p->dfinal_states.stride[2]; g.isk = p->dfinal_states.stride[3];
+    }
+    if (present(p->dinitial_states)) {
+      g.fin = (float*)p->dinitial_states.data; g.fin_extra_decay = 1;
+      g.fsb = p->dinitial_states.stride[0]; g.fsh = p->dinitial_states.stride[1]; g.fsu = p->dinitial_states.stride[2]; g.fsk = p->dinitial_states.stride[3];
+    }
+    g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
+    if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
+    rc = run_scan(g, p->force_generic, stream);
+    if (rc) return rc;
+  }
+  {  // dB: state [n][p], reverse in time
+    GScan g = base(GS_DB);
+    g.U = make_src(p->Cm, true); g.K = make_src(p->dout, false); g.Q = make_src(p->x, false); g.X4 = make_src(p->Bm, true);
+    g.DU = d.N; g.DK = d.P; g.reverse = 1; g.w_is_dt = 0;
+    if (has_dfin) {
+      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
+      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isk = p->dfinal_states.stride[2]; g.isu = p->dfinal_states.stride[3];
+    }
+    g.acc32 = w.dB32; g.tokscal = w.wsum;
+    if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
+    rc = run_scan(g, p->force_generic, stream);
+    if (rc) return rc;
+  }
+  {
+    FinishArgs f = {};
+    f.e = w.e; f.wsum = w.wsum; f.dtp = w.dtp; f.dsoft = w.dsoft; f.A = A;
+    if (has_dfin) {
+      f.dfin = (const float*)p->dfinal_states.data; f.sfin = w.sfin;
+      f.dfsb = p->dfinal_states.stride[0]; f.dfsh = p->dfinal_states.stride[1]; f.dfsp = p->dfinal_states.stride[2]; f.dfsn = p->dfinal_states.stride[3];
+    }
+    f.ddt = p->ddt.data; f.dsb = p->ddt.stride[0]; f.dsl = p->ddt.stride[1]; f.dsh = p->ddt.stride[2]; f.ddt_dt = p->ddt.dtype;
+    f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
+    dim3 grid((unsigned)(d.B * d.H)), block(64);
+    OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);
+  }
+  {
+    int64_t blocks = (blgn + 255) / 256;
+    dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks)), block(256);
+    OMK_LAUNCH(cvt_f32_kernel, grid, block, 0, stream, (const float*)w.dB32, p->dB.data, p->dB.stride[0], p->dB.stride[1], p->dB.stride[2], d.B, d.L, d.G, d.N, (int)p->dB.dtype);
+    OMK_LAUNCH(cvt_f32_kernel, grid, block, 0, stream, (const float*)w.dC32, p->dC.data, p->dC.stride[0], p->dC.stride[1], p->dC.stride[2], d.B, d.L, d.G, d.N, (int)p->dC.dtype);
+  }
+  return finish_launch("ssd_scan_bwd");
+}

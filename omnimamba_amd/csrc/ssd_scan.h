@@ -1,0 +1,47 @@
+// ssd_scan.h -- the generalised linear-recurrence scan all Mamba-2 SSD passes are expressed with.
+//
+//   S_t = exp(a_t) * S_{t-1} + w_t * U_t (x) K_t        S in R^{DU x DK}
+//   O_t[u] = sum_k S_t[u][k] * Q_t[k]
+//
+// forward  y  : U = x  (head, P)   K = B (group, N)  Q = C (group, N)   a = dt'A   w = dt'   t ascending
+// backward dC : U = B  (group, N)  K = x (head, P)   Q = dy (head, P)   a = dt'A   w = dt'   t ascending
+//          dx : U = dy (head, P)   K = C (group, N)  Q = B (group, N)   a_t := dt'_{t+1} A, w = 1, t descending
+//          dB : U = C  (group, N)  K = dy (head, P)  Q = x (head, P)    a_t := dt'_{t+1} A, w = 1, t descending
+// (derivation checked against autograd in tests/test_bwd_derivation.py).  Two implementations consume this
+// descriptor: the shape-generic fp32 VALU kernel (ssd.hip) and the MFMA chunked kernel (ssd_mfma.hip).
+#pragma once
+#include "omk_common.h"
+
+namespace omk {
+
+enum { GS_Y = 0, GS_DC = 1, GS_DX = 2, GS_DB = 3 };
+
+struct Src {            // element (b, t, hh, i) at p[b*sb + t*sl + hh*sh + i]; hh = group index when per_group
+  const void* p;
+  int64_t sb, sl, sh;
+  int dt;
+  int per_group;
+};
+
+struct GScan {
+  int mode;
+  Src U, K, Q, X4, Z;   // X4: group vector of length DU for the token-scalar epilogue (C in dC, B in dB); Z: gate (Y)
+  const float* dtp;     // (B, H, L) processed dt' (bias + softplus + clamp applied)
+  const float* A;       // (H)
+  int B, H, G, L, DU, DK;
+  int reverse, w_is_dt;
+  const void* init; int64_t isb, ish, isu, isk; int init_dt;     // optional initial state, logical [u][k]
+  float* fin; int64_t fsb, fsh, fsu, fsk; int fin_extra_decay;   // optional final state (f32); extra exp(a_0) for dinit
+  void* out; int64_t osb, osl, osh; int out_dt;                  // Y: out, DX: dx   (b, t, h, u) with u contiguous
+  void* outx;                                                    // Y: optional pre-gate copy of out
+  const void* D; int64_t Dsh, Dsp; int D_dt;                     // Y, DX
+  float* acc32;                                                  // DC/DB: (B, L, G, DU) f32, atomically accumulated
+  float* tokscal;                                                // DC: e, DB: wsum  (B, H, L) f32, atomically accumulated
+  float* dD; int64_t dDsh, dDsp;                                 // DB: optional grad of D
+};
+
+int ssd_generic_launch(const GScan& g, omk_stream stream);
+// returns OMK_EUNSUPPORTED (without touching the error text) when the shape/dtype/layout is outside the MFMA kernel
+int ssd_mfma_launch(const GScan& g, omk_stream stream);
+
+}  // namespace omk

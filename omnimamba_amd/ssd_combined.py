@@ -1,0 +1,149 @@
+"""Mamba-2 SSD scan on the MI355X.
+
+Mirrors ``mamba_ssm.ops.triton.ssd_combined.{mamba_chunk_scan_combined, mamba_split_conv1d_scan_combined}``
+(the names HF wraps at transformers/models/mamba2/modeling_mamba2.py:166-187,253-268 and that the reference reaches
+through Mamba2.forward, /root/reference/models/stage2/block.py:117).  Arithmetic: omk_ssd_scan_fwd / _bwd
+(omnimamba_amd/csrc/ssd.hip, ssd_mfma.hip), omk_causal_conv1d_*, omk_norm_gated_*; the projection GEMMs stay on
+hipBLASLt through torch.  No PyTorch fallback for the scan.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _capi as K
+from ._lib import get_lib, require_device
+from .causal_conv1d import causal_conv1d_fn
+from .layernorm_gated import rmsnorm_fn
+
+_INF = float("inf")
+
+
+def _last_contig(t):
+    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+
+
+def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=None, dt_softplus=False,
+                 dt_limit=(0.0, _INF), return_final_states=False, want_out_x=False, chunk_size=256,
+                 force_generic=False):
+    """Raw (non-autograd) forward: returns (out, out_x | None, final_states | None)."""
+    lib = get_lib()
+    require_device(lib, x, dt, A, B, C, D, z, dt_bias, initial_states)
+    x, B, C, z = _last_contig(x), _last_contig(B), _last_contig(C), _last_contig(z)
+    if B.dtype != x.dtype:
+        B = B.to(x.dtype)
+    if C.dtype != x.dtype:
+        C = C.to(x.dtype)
+    if z is not None and z.dtype != x.dtype:
+        z = z.to(x.dtype)
+    A = A.float().contiguous()
+    Bsz, L, H, P = x.shape
+    N = B.shape[-1]
+    out = torch.empty(Bsz, L, H, P, dtype=x.dtype, device=x.device)
+    out_x = torch.empty_like(out) if (want_out_x and z is not None) else None
+    fin = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=x.device) if return_final_states else None
+    if x.numel() > 0:
+        p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), z=K.T(z), dt_bias=K.T(dt_bias),
+                     initial_states=K.T(initial_states), out=K.T(out), out_x=K.T(out_x), final_states=K.T(fin),
+                     dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]), dt_softplus=int(dt_softplus),
+                     chunk_size=int(chunk_size), force_generic=int(force_generic))
+        ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
+        K.run(lib, "omk_ssd_scan_fwd", p, x)
+    elif fin is not None:
+        fin.zero_() if initial_states is None else fin.copy_(initial_states)
+    return out, out_x, fin
+
+
+def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
+                 dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False):
+    """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states)."""
+    lib = get_lib()
+    x, B, C, dout = _last_contig(x), _last_contig(B), _last_contig(C), _last_contig(dout)
+    if B.dtype != x.dtype:
+        B = B.to(x.dtype)
+    if C.dtype != x.dtype:
+        C = C.to(x.dtype)
+    if dout.dtype != x.dtype:
+        dout = dout.to(x.dtype)
+    A = A.float().contiguous()
+    Bsz, L, H, P = x.shape
+    G, N = B.shape[2], B.shape[3]
+    dev = x.device
+    dx = torch.empty(Bsz, L, H, P, dtype=x.dtype, device=dev)
+    ddt = torch.empty(Bsz, L, H, dtype=torch.float32, device=dev)
+    dA = torch.empty(H, dtype=torch.float32, device=dev)
+    dB = torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
+    dC = torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
+    dD = None if D is None else torch.empty(D.shape, dtype=torch.float32, device=dev)
+    ddtb = None if dt_bias is None else torch.empty(H, dtype=torch.float32, device=dev)
+    dinit = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=dev) if need_dinit else None
+    if dfinal_states is not None:
+        dfinal_states = dfinal_states.float()
+    if x.numel() > 0:
+        p = K.SsdBwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), dt_bias=K.T(dt_bias),
+                     initial_states=K.T(initial_states), dout=K.T(dout), dfinal_states=K.T(dfinal_states), dx=K.T(dx),
+                     ddt=K.T(ddt), dA=K.T(dA), dB=K.T(dB), dC=K.T(dC), dD=K.T(dD), ddt_bias=K.T(ddtb),
+                     dinitial_states=K.T(dinit), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
+                     dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic))
+        ws = K.workspace(lib, "omk_ssd_scan_bwd_workspace_bytes", p, x)  # noqa: F841
+        K.run(lib, "omk_ssd_scan_bwd", p, x)
+    else:
+        for t in (dA, dD, ddtb):
+            if t is not None:
+                t.zero_()
+        if dinit is not None:
+            dinit.zero_() if dfinal_states is None else dinit.copy_(dfinal_states)
+    return dict(dx=dx, ddt=ddt, dA=dA, dB=dB, dC=dC, dD=dD, ddt_bias=ddtb, dinitial_states=dinit)
+
+
+def _silu_grad(z):
+    s = torch.sigmoid(z)
+    return s * (1 + z * (1 - s))
+
+
+class MambaChunkScanCombinedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, initial_states=None, seq_idx=None,
+                cu_seqlens=None, dt_softplus=False, dt_limit=(0.0, _INF), return_final_states=False,
+                return_varlen_states=False):
+        if seq_idx is not None or cu_seqlens is not None or return_varlen_states:
+            raise NotImplementedError("seq_idx / cu_seqlens / varlen states never reach the mixer in OmniMamba "
+                                      "(models/stage2/mixer_seq_simple.py:375,408-420)")
+        out, out_x, fin = ssd_scan_fwd(x, dt, A, B, C, D=D, z=z, dt_bias=dt_bias, initial_states=initial_states,
+                                       dt_softplus=dt_softplus, dt_limit=dt_limit,
+                                       return_final_states=return_final_states, want_out_x=True, chunk_size=chunk_size)
+        ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x)
+        ctx.dt_softplus, ctx.dt_limit, ctx.chunk_size = dt_softplus, dt_limit, chunk_size
+        ctx.return_final_states = return_final_states
+        return (out, fin) if return_final_states else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        x, dt, A, B, C, D, z, dt_bias, initial_states, out_x = ctx.saved_tensors
+        dfinal = args[0] if ctx.return_final_states and args else None
+        dz = None
+        if z is not None:
+            zf = z.float()
+            dz = (dout.float() * out_x.float() * _silu_grad(zf)).to(z.dtype)
+            dout = (dout.float() * F.silu(zf)).to(x.dtype)
+        g = ssd_scan_bwd(dout, x, dt, A, B, C, D=D, dt_bias=dt_bias, initial_states=initial_states,
+                         dfinal_states=dfinal, dt_softplus=ctx.dt_softplus, dt_limit=ctx.dt_limit,
+                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None)
+        dinit = g["dinitial_states"]
+        return (g["dx"], g["ddt"].to(dt.dtype), g["dA"].to(A.dtype), g["dB"].to(B.dtype), g["dC"].to(C.dtype), None,
+                None if D is None else g["dD"].to(D.dtype), dz,
+                None if dt_bias is None else g["ddt_bias"].to(dt_bias.dtype),
+                None if dinit is None else dinit.to(initial_states.dtype), None, None, None, None, None, None)
+
+
+def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, initial_states=None,
+                              seq_idx=None, cu_seqlens=None, dt_softplus=False, dt_limit=(0.0, _INF),
+                              return_final_states=False, return_varlen_states=False):
+    """x: (batch, seqlen, nheads, headdim); dt: (batch, seqlen, nheads); A: (nheads); B, C: (batch, seqlen, ngroups,
+    dstate); D: (nheads, headdim) or (nheads,); z: like x; dt_bias: (nheads,); initial_states: (batch, nheads,
+    headdim, dstate).  Returns out like x [, final_states (batch, nheads, headdim, dstate) fp32]."""
+    return MambaChunkScanCombinedFn.apply(x, dt, A, B, C, chunk_size, D, z, dt_bias, initial_states, seq_idx,
+                                          cu_seqlens, dt_softplus, dt_limit, return_final_states,
+                                          return_varlen_states)
