@@ -20,7 +20,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
         raise RuntimeError(
             f"omnimamba_amd: HIP extension not built ({path} missing). Run `python -m omnimamba_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for these ops.")
-    return _capi.bind(ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL))
+    return _capi.bind(ctypes.CDLL(path))
 
 
 def get_lib() -> ctypes.CDLL:

@@ -49,7 +49,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(lambda j: _compile(j[0], j[1], verbose), jobs))
     if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

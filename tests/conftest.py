@@ -20,3 +20,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def dev(request):
+    """Device the HIP sources run on: 'emu' = host build of the same kernels under the SIMT emulator (CPU tensors,
+    runs everywhere); 'gpu' = the real libomnimamba_hip.so on cuda:0 (only under `-m gpu` on the MI355X box)."""
+    import torch
+    if request.param == "emu":
+        from emu.loader import use_emulator
+        with use_emulator():
+            yield torch.device("cpu")
+    else:
+        yield torch.device("cuda:0")

@@ -36,7 +36,7 @@ def build(verbose=False, force=False):
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(cc, jobs))
     if jobs or not os.path.exists(LIB):
-        subprocess.run([CXX, "-shared", "-fPIC", *objs, "-o", LIB], check=True)
+        subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", LIB], check=True)
     return LIB
 
 

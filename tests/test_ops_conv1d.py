@@ -1,42 +1,41 @@
-"""causal_conv1d HIP kernels run through the SIMT emulator vs the oracle (forward, backward, update)."""
+"""causal_conv1d kernels (omk_causal_conv1d_{fwd,bwd,update}) vs the oracle: emulator on CPU, MI355X under -m gpu."""
 import pytest
 import torch
 
 import oracle as O
-from emu.loader import use_emulator
 
 
 def rel(a, b):
-    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    return ((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("W", [2, 3, 4])
 @pytest.mark.parametrize("layout,C,L", [("cl", 16, 37), ("cl", 24, 140), ("cf", 6, 19)])
-def test_conv1d_fwd_bwd_emulated(dtype, W, layout, C, L):
+def test_conv1d_fwd_bwd(dev, dtype, W, layout, C, L):
     from omnimamba_amd.causal_conv1d import causal_conv1d_fn
     torch.manual_seed(0)
     B = 2
     if layout == "cl":  # slice of a wider channel-last row, like xBC inside zxbcdt
         base = torch.randn(B, L, C + 8).to(dtype)
         x = base[:, :, 8:].transpose(1, 2)
+        xdev = base.to(dev)[:, :, 8:].transpose(1, 2)
     else:
         x = torch.randn(B, C, L).to(dtype)
+        xdev = x.to(dev)
     w, b = torch.randn(C, W), torch.randn(C)
     init = torch.randn(B, C, W - 1).to(dtype)
     for use_init in (False, True):
-        xr, wr, br = x.detach().clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
-        if layout == "cl":
-            xr = x.detach().requires_grad_()
-        ir = init.clone().requires_grad_() if use_init else None
-        with use_emulator():
-            out, fin = causal_conv1d_fn(xr, wr, br, initial_states=ir, return_final_states=True, activation="silu")
-            g = torch.randn(out.shape).to(dtype)
-            out.backward(g)
+        xr = xdev.detach().requires_grad_()
+        wr, br = w.clone().to(dev).requires_grad_(), b.clone().to(dev).requires_grad_()
+        ir = init.clone().to(dev).requires_grad_() if use_init else None
+        out, fin = causal_conv1d_fn(xr, wr, br, initial_states=ir, return_final_states=True, activation="silu")
+        g = torch.randn(out.shape).to(dtype)
+        out.backward(g.to(dev))
         o0, f0 = O.causal_conv1d_ref(x, w, b, initial_states=init if use_init else None, return_final_states=True, activation="silu")
         tol = 1e-5 if dtype == torch.float32 else 6e-3
-        assert rel(out, o0) < tol
-        assert torch.equal(fin.float(), f0.float())
+        assert rel(out.detach(), o0) < tol
+        assert torch.equal(fin.float().cpu(), f0.float())
         xd, wd, bd = x.double().detach().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
         idd = init.double().requires_grad_() if use_init else None
         od = O.causal_conv1d_ref(xd, wd, bd, initial_states=idd, activation="silu", compute_dtype=torch.float64)
@@ -48,23 +47,23 @@ def test_conv1d_fwd_bwd_emulated(dtype, W, layout, C, L):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv1d_update_emulated(dtype):
+def test_conv1d_update(dev, dtype):
     from omnimamba_amd.causal_conv1d import causal_conv1d_update
     torch.manual_seed(1)
     B, C, W = 2, 20, 4
     w, b = torch.randn(C, W), torch.randn(C)
     xs = torch.randn(B, C, 9).to(dtype)
-    st = torch.zeros(B, W, C, dtype=dtype).transpose(1, 2)   # channel-last state like Mamba2.allocate_inference_cache
+    st = torch.zeros(B, W, C, dtype=dtype, device=dev).transpose(1, 2)   # channel-last state like Mamba2.allocate_inference_cache
     st0 = torch.zeros(B, C, W, dtype=dtype)
-    with use_emulator():
-        for t in range(9):
-            o = causal_conv1d_update(xs[:, :, t], st, w, b, activation="silu")
-            o0 = O.causal_conv1d_update_ref(xs[:, :, t], st0, w, b, activation="silu")
-            assert rel(o, o0) < (1e-5 if dtype == torch.float32 else 6e-3)
-            assert torch.equal(st.float(), st0.float())
-        # multi-token update with state_len == W-1
-        st3, st30 = torch.randn(B, C, W - 1).to(dtype), None
-        st30 = st3.clone()
-        o = causal_conv1d_update(xs[:, :, :5], st3, w, b, activation=None)
-        o0 = O.causal_conv1d_update_ref(xs[:, :, :5], st30, w, b, activation=None)
-        assert rel(o, o0) < (1e-5 if dtype == torch.float32 else 6e-3) and torch.equal(st3.float(), st30.float())
+    wd, bd, xsd = w.to(dev), b.to(dev), xs.to(dev)
+    for t in range(9):
+        o = causal_conv1d_update(xsd[:, :, t], st, wd, bd, activation="silu")
+        o0 = O.causal_conv1d_update_ref(xs[:, :, t], st0, w, b, activation="silu")
+        assert rel(o, o0) < (1e-5 if dtype == torch.float32 else 6e-3)
+        assert torch.equal(st.float().cpu(), st0.float())
+    st3 = torch.randn(B, C, W - 1).to(dtype)
+    st30 = st3.clone()
+    st3 = st3.to(dev)
+    o = causal_conv1d_update(xsd[:, :, :5], st3, wd, bd, activation=None)
+    o0 = O.causal_conv1d_update_ref(xs[:, :, :5], st30, w, b, activation=None)
+    assert rel(o, o0) < (1e-5 if dtype == torch.float32 else 6e-3) and torch.equal(st3.float().cpu(), st30.float())

@@ -1,9 +1,8 @@
-"""HIP norm kernels executed on the CPU through the SIMT emulator (tests/emu) vs the oracle."""
+"""Norm kernels (omk_add_norm_*, omk_norm_gated_*) vs the oracle: under the SIMT emulator on CPU and, with -m gpu, on the MI355X."""
 import pytest
 import torch
 
 import oracle as O
-from emu.loader import use_emulator
 
 
 def rel(a, b):
@@ -13,20 +12,20 @@ def rel(a, b):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cols,has_res,res32,rms", [(64, True, True, True), (520, True, False, True), (48, False, True, True),
                                                     (100, True, True, False), (37, False, False, True)])
-def test_add_norm_fwd_bwd_emulated(dtype, cols, has_res, res32, rms):
+def test_add_norm_fwd_bwd(dev, dtype, cols, has_res, res32, rms):
     from omnimamba_amd.layer_norm import layer_norm_fn
     torch.manual_seed(0)
     x = torch.randn(3, 5, cols).to(dtype)
     res = (torch.randn(3, 5, cols).to(torch.float32 if res32 else dtype)) if has_res else None
     w = torch.randn(cols)
     b = None if rms else torch.randn(cols)
-    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
-    rr = None if res is None else res.clone().requires_grad_()
-    br = None if b is None else b.clone().requires_grad_()
-    with use_emulator():
-        y, ro = layer_norm_fn(xr, wr, br, residual=rr, eps=1e-5, prenorm=True, residual_in_fp32=res32, is_rms_norm=rms)
-        gy, gr = torch.randn_like(y), torch.randn_like(ro)
-        (y.float() * gy.float()).sum().backward(retain_graph=True) if False else torch.autograd.backward([y, ro], [gy, gr])
+    xr, wr = x.clone().to(dev).requires_grad_(), w.clone().to(dev).requires_grad_()
+    rr = None if res is None else res.clone().to(dev).requires_grad_()
+    br = None if b is None else b.clone().to(dev).requires_grad_()
+    y, ro = layer_norm_fn(xr, wr, br, residual=rr, eps=1e-5, prenorm=True, residual_in_fp32=res32, is_rms_norm=rms)
+    gy, gr = torch.randn(y.shape).to(y.dtype), torch.randn(ro.shape).to(ro.dtype)
+    torch.autograd.backward([y, ro], [gy.to(dev), gr.to(dev)])
+    y, ro = y.detach().cpu(), ro.detach().cpu()
     y0, ro0 = O.add_norm_ref(x, w, b, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=res32, is_rms_norm=rms)
     tol = 1e-5 if dtype == torch.float32 else 6e-3
     assert ro.dtype == ro0.dtype and rel(ro, ro0) < tol and rel(y, y0) < tol
@@ -42,27 +41,27 @@ def test_add_norm_fwd_bwd_emulated(dtype, cols, has_res, res32, rms):
         yd = (r - mu) * torch.rsqrt((r - mu).pow(2).mean(-1, keepdim=True) + 1e-5) * wd + bd
     torch.autograd.backward([yd, r], [gy.double(), gr.double()])
     gtol = 1e-4 if dtype == torch.float32 else 1.5e-2
-    assert rel(xr.grad, xd.grad) < gtol and rel(wr.grad, wd.grad) < gtol
+    assert rel(xr.grad.cpu(), xd.grad) < gtol and rel(wr.grad.cpu(), wd.grad) < gtol
     if rr is not None:
-        assert rr.grad.dtype == res.dtype and rel(rr.grad, rd.grad) < gtol
+        assert rr.grad.dtype == res.dtype and rel(rr.grad.cpu(), rd.grad) < gtol
     if br is not None:
-        assert rel(br.grad, bd.grad) < gtol
+        assert rel(br.grad.cpu(), bd.grad) < gtol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cols,gs,nbg,has_z", [(64, None, False, True), (128, 32, False, True), (96, 48, True, True), (40, None, False, False)])
-def test_norm_gated_emulated(dtype, cols, gs, nbg, has_z):
+def test_norm_gated(dev, dtype, cols, gs, nbg, has_z):
     from omnimamba_amd.layernorm_gated import rmsnorm_fn
     torch.manual_seed(1)
     x = torch.randn(7, cols).to(dtype)
     z = torch.randn(7, cols).to(dtype) if has_z else None
     w = torch.randn(cols)
-    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
-    zr = None if z is None else z.clone().requires_grad_()
-    with use_emulator():
-        y = rmsnorm_fn(xr, wr, None, z=zr, eps=1e-5, group_size=gs, norm_before_gate=nbg)
-        gy = torch.randn_like(y)
-        y.backward(gy)
+    xr, wr = x.clone().to(dev).requires_grad_(), w.clone().to(dev).requires_grad_()
+    zr = None if z is None else z.clone().to(dev).requires_grad_()
+    y = rmsnorm_fn(xr, wr, None, z=zr, eps=1e-5, group_size=gs, norm_before_gate=nbg)
+    gy = torch.randn(y.shape).to(y.dtype)
+    y.backward(gy.to(dev))
+    y = y.detach().cpu()
     y0 = O.rmsnorm_gated_ref(x, w, None, z=z, eps=1e-5, group_size=gs, norm_before_gate=nbg)
     tol = 1e-5 if dtype == torch.float32 else 6e-3
     assert rel(y, y0) < tol
@@ -71,6 +70,6 @@ def test_norm_gated_emulated(dtype, cols, gs, nbg, has_z):
     yd = O.rmsnorm_gated_ref(xd, wd, None, z=zd, eps=1e-5, group_size=gs, norm_before_gate=nbg, compute_dtype=torch.float64)
     yd.backward(gy.double())
     gtol = 1e-4 if dtype == torch.float32 else 1.5e-2
-    assert rel(xr.grad, xd.grad) < gtol and rel(wr.grad, wd.grad) < gtol
+    assert rel(xr.grad.cpu(), xd.grad) < gtol and rel(wr.grad.cpu(), wd.grad) < gtol
     if zr is not None:
-        assert rel(zr.grad, zd.grad) < gtol
+        assert rel(zr.grad.cpu(), zd.grad) < gtol

@@ -1,13 +1,13 @@
-"""SSD scan HIP kernels (generic + MFMA where the shape allows) through the emulator vs the oracle."""
+"""SSD scan kernels (omk_ssd_scan_fwd / _bwd: generic fp32 path and the MFMA path) vs the oracle: emulator on CPU,
+MI355X under -m gpu."""
 import pytest
 import torch
 
 import oracle as O
-from emu.loader import use_emulator
 
 
 def rel(a, b):
-    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    return ((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
 def make(Bsz, L, H, P, N, G, dtype, seed=0):
@@ -26,12 +26,13 @@ def make(Bsz, L, H, P, N, G, dtype, seed=0):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("L,H,P,N,G", [(37, 4, 8, 16, 2), (20, 2, 16, 24, 1), (70, 2, 64, 128, 1)])
-def test_ssd_generic_fwd_emulated(dtype, L, H, P, N, G):
+def test_ssd_generic_fwd(dev, dtype, L, H, P, N, G):
     from omnimamba_amd.ssd_combined import ssd_scan_fwd
     x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, dtype)
-    with use_emulator():
-        out, out_x, fin = ssd_scan_fwd(x, dt, A, Bm, Cm, D=D, z=z, dt_bias=dtb, initial_states=init, dt_softplus=True,
-                                       dt_limit=(0.0, 3.0), return_final_states=True, want_out_x=True, force_generic=True)
+    d = lambda t: t.to(dev)
+    out, out_x, fin = ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), D=d(D), z=d(z), dt_bias=d(dtb), initial_states=d(init),
+                                   dt_softplus=True, dt_limit=(0.0, 3.0), return_final_states=True, want_out_x=True,
+                                   force_generic=True)
     o0, f0 = O.ssd_ref_sequential(x, dt, A, Bm, Cm, D=D, z=z, dt_bias=dtb, initial_states=init, dt_softplus=True,
                                   dt_limit=(0.0, 3.0), return_final_states=True)
     ox0 = O.ssd_ref_sequential(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, initial_states=init, dt_softplus=True, dt_limit=(0.0, 3.0))
@@ -40,25 +41,21 @@ def test_ssd_generic_fwd_emulated(dtype, L, H, P, N, G):
 
 
 @pytest.mark.parametrize("L,H,P,N,G,dhp", [(29, 4, 8, 16, 2, False), (18, 2, 16, 8, 1, True)])
-def test_ssd_generic_bwd_emulated(L, H, P, N, G, dhp):
-    from omnimamba_amd.ssd_combined import mamba_chunk_scan_combined
-    dtype = torch.float32
-    x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, dtype, seed=3)
+def test_ssd_generic_bwd(dev, L, H, P, N, G, dhp, monkeypatch):
+    import omnimamba_amd.ssd_combined as S
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, torch.float32, seed=3)
     if dhp:
         D = torch.randn(H, P)
-    leaves = [t.clone().requires_grad_() for t in (x, dt, A, Bm, Cm, D, z, dtb, init)]
+    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, z, dtb, init)]
     xr, dtr, Ar, Br, Cr, Dr, zr, dtbr, ir = leaves
-    import omnimamba_amd.ssd_combined as S
-    with use_emulator():
-        y, fin = mamba_chunk_scan_combined(xr, dtr, Ar, Br, Cr, 64, D=Dr, z=zr, dt_bias=dtbr, initial_states=ir,
-                                           dt_softplus=True, return_final_states=True)
-        gy, gf = torch.randn_like(y), torch.randn_like(fin)
-        torch.autograd.backward([y, fin], [gy, gf])
+    y, fin = S.mamba_chunk_scan_combined(xr, dtr, Ar, Br, Cr, 64, D=Dr, z=zr, dt_bias=dtbr, initial_states=ir,
+                                         dt_softplus=True, return_final_states=True)
+    gy, gf = torch.randn(y.shape), torch.randn(fin.shape)
+    torch.autograd.backward([y, fin], [gy.to(dev), gf.to(dev)])
     dl = [t.double().clone().requires_grad_() for t in (x, dt, A, Bm, Cm, D, z, dtb, init)]
     y0, f0 = O.ssd_ref_sequential(dl[0], dl[1], dl[2], dl[3], dl[4], D=dl[5], z=dl[6], dt_bias=dl[7], initial_states=dl[8],
                                   dt_softplus=True, return_final_states=True, compute_dtype=torch.float64)
     torch.autograd.backward([y0, f0], [gy.double(), gf.double()])
-    assert rel(y, y0) < 3e-5 and rel(fin, f0) < 3e-5
-    names = ["x", "dt", "A", "B", "C", "D", "z", "dt_bias", "init"]
-    for n, a, b in zip(names, leaves, dl):
+    assert rel(y.detach(), y0.detach()) < 3e-5 and rel(fin.detach(), f0.detach()) < 3e-5
+    for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "z", "dt_bias", "init"], leaves, dl):
         assert rel(a.grad, b.grad) < 2e-4, n
