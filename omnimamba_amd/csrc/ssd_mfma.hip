@@ -1,5 +1,385 @@
-// ssd_mfma.hip -- MFMA chunked SSD scan (placeholder until the kernel lands: everything falls to the generic scan)
+// ssd_mfma.hip -- the MFMA chunked scan for the OmniMamba-1.3B block shape (headdim 64, d_state 128, bf16).
+//
+// One 512-thread workgroup (8 waves, 2 per SIMD) owns TWO heads of one batch element and walks the sequence in
+// chunks of 64 tokens, carrying both running states (64 x 128 fp32 each) in MFMA accumulator registers from the
+// first token to the last: states never touch HBM, so HBM traffic is the algorithmic minimum -- every x / dy row
+// read once, every y / dx row written once, B/C (shared by all 64 heads of a group) served from L2.
+//
+// Per chunk (local token l, s; a = log-decay, cs = inclusive prefix of a inside the chunk, w = input scale):
+//   G^T[s][l] = K_s . Q_l                                    16x16x32 MFMA, shared by both heads, via LDS (fp32)
+//   M[l][s]   = G[l][s] * exp(cs_l - cs_s) * w_s  (s <= l)    VALU, rounded to bf16 as the next A operand
+//   O_l       = sum_s M[l][s] U_s  +  exp(cs_l) * (Q_l . S_in)   2 x 32x32x16 MFMA chains (U via ds_read_tr16_b64)
+//   S_out     = exp(cs_63) S_in + sum_l (w_l exp(cs_63 - cs_l) U_l) (x) K_l   MFMA, both operands via transpose reads
+// The intra-chunk prefix cs is a 64-lane wave scan (__shfl_up); lanes = tokens.  S_in reaches the O chain as bf16
+// through LDS ([u][k], k contiguous = natural B-operand order).  Time-reversed scans (backward) only change the
+// global<->LDS row mapping and the decay index, the core is direction agnostic.
+//
+// Wave w: head hh = w >> 2, (wi, wj) = ((w >> 1) & 1, w & 1): owns O tile [32 wi .. +32][32 wj .. +32] and the two
+// state tiles S^T[64 wi + 32 kt .. +32][32 wj .. +32].
 #include "ssd_scan.h"
+
 namespace omk {
-int ssd_mfma_launch(const GScan&, omk_stream) { return OMK_EUNSUPPORTED; }
+
+constexpr int QC = 64;     // chunk length (tokens)
+constexpr int LDK = 136;   // row stride (bf16 elements) of 128-wide tiles: 272 B = 17 x 16 B -> conflict-free b128 rows
+constexpr int LDU = 72;    // row stride of 64-wide bf16 tiles
+constexpr int LDG = 68;    // row stride (floats) of 64-wide fp32 tiles
+
+struct SmemA {
+  uint16_t K[QC * LDK];
+  uint16_t Qm[QC * LDK];
+  uint16_t U[2][QC * LDU];
+  float G[QC * LDG];
+  uint16_t S[2][64 * LDK];   // [u][k] bf16 copy of S_in
+  float O[2][QC * LDG];
+  float cs[2][QC], ecs[2][QC], w[2][QC], ws[2][QC];
+  float dtl[2][2][QC];       // [chunk parity][head][row]: dt' of the token itself
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ s16x8 as_s16x8(u32x4 v) { return __builtin_bit_cast(s16x8, v); }
+__device__ __forceinline__ float bf_lo(uint32_t v) { return bf16_to_f32((uint16_t)(v & 0xffffu)); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return bf16_to_f32((uint16_t)(v >> 16)); }
+
+// B/A operand fragment (8 contraction values for this lane's column/row) out of a row-major [contraction][col] LDS
+// tile with two transpose reads: rows r0 + 8*h32 + 4*m + {0..3}, column c0 + (lane & 31).
+__device__ __forceinline__ s16x8 tr_frag(const uint16_t* tile, int ld, int r0, int c0, int lane) {
+  const int t16 = lane & 15, g16 = lane >> 4, h32 = lane >> 5;
+  const uint16_t* p = tile + (r0 + 8 * h32 + (t16 >> 2)) * ld + c0 + 16 * (g16 & 1) + 4 * (t16 & 3);
+  s16x4 a = lds_read_tr16_b64(p);
+  s16x4 b = lds_read_tr16_b64(p + 4 * ld);
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
 }
+
+// MODE: GS_Y (forward output) or GS_DX (reverse, dx + token scalars)
+template <int MODE>
+__global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
+  const void* Xe = a.XE.p; const int64_t xe_sb = a.XE.sb, xe_sl = a.XE.sl, xe_sh = a.XE.sh;
+  const void* Ye = a.YE.p; const int64_t ye_sb = a.YE.sb, ye_sl = a.YE.sl, ye_sh = a.YE.sh;
+  float* esum = a.esum; float* wsum = a.wsum;
+  OMK_DYN_SMEM(smem_raw);
+  SmemA& sm = *reinterpret_cast<SmemA*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int h32 = lane >> 5, l31 = lane & 31, g16 = lane >> 4, t16 = lane & 15;
+  const int pairs = a.H / 2;
+  const int b = blockIdx.x / pairs, hp = blockIdx.x % pairs;
+  const int h0 = hp * 2;
+  const int g = h0 / (a.H / a.G);
+  const int nC = (a.L + QC - 1) / QC;
+  const bool rev = a.reverse != 0;
+
+  auto tok = [&](int c, int row) -> int {   // token index of LDS row `row` in the c-th processed chunk
+    const int id = rev ? nC - 1 - c : c;
+    return rev ? id * QC + (QC - 1) - row : id * QC + row;
+  };
+
+  // ---- staging: K, Q (64 x 128) two 16-B segments per thread each; U (2 heads x 64 x 64) two per thread
+  u32x4 rk[2], rq[2], ru[2];
+  float rdt = 0.f;                                   // threads 0..127: dt' of (head tid>>6, row tid&63)
+  const uint16_t* Kg = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
+  const uint16_t* Qg = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
+  const uint16_t* Ug = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb;
+  const float* dtp0 = a.dtp + ((int64_t)b * a.H + h0) * a.L;
+  auto prefetch = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
+      const int t = tok(c, row);
+      const bool ok = c < nC && t < a.L;
+      rk[r] = ok ? ld16(Kg + (int64_t)t * a.K.sl + cs8) : u32x4{0, 0, 0, 0};
+      rq[r] = ok ? ld16(Qg + (int64_t)t * a.Q.sl + cs8) : u32x4{0, 0, 0, 0};
+      const int row_u = (tid >> 3), cu8 = (tid & 7) * 8;   // pass r = head r
+      const int tu = tok(c, row_u);
+      const bool oku = c < nC && tu < a.L;
+      ru[r] = oku ? ld16(Ug + (int64_t)tu * a.U.sl + (int64_t)(h0 + r) * a.U.sh + cu8) : u32x4{0, 0, 0, 0};
+    }
+    if (tid < 128) {
+      const int t = tok(c, tid & 63);
+      rdt = (c < nC && t < a.L) ? dtp0[(int64_t)(tid >> 6) * a.L + t] : 0.f;
+    }
+  };
+  auto commit = [&](int par) {   // registers -> LDS tiles (dt' goes to the parity buffer of the chunk it belongs to)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
+      st16(&sm.K[row * LDK + cs8], rk[r]);
+      st16(&sm.Qm[row * LDK + cs8], rq[r]);
+      st16(&sm.U[r][(tid >> 3) * LDU + (tid & 7) * 8], ru[r]);
+    }
+    if (tid < 128) sm.dtl[par][tid >> 6][tid & 63] = rdt;
+  };
+
+  // ---- running state: S^T tiles [k = 64 wi + 32 kt + row][u = 32 wj + l31], head h0 + hh
+  f32x16 accS[2];
+  const int hcur = h0 + hh;
+  const float Ah = a.A[hcur];
+#pragma unroll
+  for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = 0.f;
+      if (a.init) {
+        const int k = 64 * wi + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * wj + l31;
+        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)hcur * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+      accS[kt][r] = v;
+    }
+  auto publish_state = [&]() {   // bf16 copy of this wave's tiles into sm.S[hh][u][k]
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+      for (int rq4 = 0; rq4 < 4; rq4++) {
+        const int k = 64 * wi + 32 * kt + 8 * rq4 + 4 * h32;
+        u32x2 v;
+        v[0] = pack_bf16x2(accS[kt][4 * rq4 + 0], accS[kt][4 * rq4 + 1]);
+        v[1] = pack_bf16x2(accS[kt][4 * rq4 + 2], accS[kt][4 * rq4 + 3]);
+        *reinterpret_cast<u32x2*>(&sm.S[hh][(32 * wj + l31) * LDK + k]) = v;
+      }
+  };
+
+  prefetch(0);
+  commit(0);
+  publish_state();
+  block_sync();
+
+  float dDp[2][8] = {{0.f}};   // DX: per-thread partial of dD over its (head, 8 columns)
+  for (int c = 0; c < nC; c++) {
+    prefetch(c + 1);
+    // epilogue operands straight from HBM into registers: segment (head r, row tid>>3, cols (tid&7)*8 .. +8)
+    u32x4 ez[2], ex[2], ey[2];
+    {
+      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        ez[r] = ex[r] = ey[r] = u32x4{0, 0, 0, 0};
+        if (t < a.L) {
+          if (MODE == GS_Y && a.Z.p) ez[r] = ld16((const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)t * a.Z.sl + (int64_t)(h0 + r) * a.Z.sh + c8);
+          if (MODE == GS_DX && Xe) {
+            ex[r] = ld16((const uint16_t*)Xe + (int64_t)b * xe_sb + (int64_t)t * xe_sl + (int64_t)(h0 + r) * xe_sh + c8);
+            ey[r] = ld16((const uint16_t*)Ye + (int64_t)b * ye_sb + (int64_t)t * ye_sl + (int64_t)(h0 + r) * ye_sh + c8);
+          }
+        }
+      }
+    }
+    // ---- scalars: one wave per head, lanes = tokens
+    if ((wave & 3) == 0) {
+      const int t = tok(c, lane);
+      const bool ok = t < a.L;
+      const float d = sm.dtl[c & 1][hh][lane];
+      float la;
+      if (rev) la = (ok && t + 1 < a.L) ? a.dtp[((int64_t)b * a.H + hcur) * a.L + t + 1] * Ah : 0.f;
+      else la = ok ? d * Ah : 0.f;
+      float cs = la;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        float o = shfl_up(cs, off);
+        if (lane >= off) cs += o;
+      }
+      const float cs_end = shfl(cs, 63);
+      const float wv = ok ? (a.w_is_dt ? d : 1.f) : 0.f;
+      sm.cs[hh][lane] = cs;
+      sm.ecs[hh][lane] = expf(cs);
+      sm.w[hh][lane] = wv;
+      sm.ws[hh][lane] = wv * expf(cs_end - cs);
+    }
+    // ---- G^T = K Q^T, lower triangle of 16x16 tiles (s-tile ta <= l-tile tb), 4 MFMA each
+    for (int tile = wave; tile < 10; tile += 8) {
+      int ta, tb;   // enumerate (ta <= tb): tb = 0:(0) 1:(0,1) 2:(0,1,2) 3:(0..3)
+      if (tile < 1) { tb = 0; ta = tile; } else if (tile < 3) { tb = 1; ta = tile - 1; } else if (tile < 6) { tb = 2; ta = tile - 3; } else { tb = 3; ta = tile - 6; }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        s16x8 fa = as_s16x8(ld16(&sm.K[(16 * ta + t16) * LDK + 32 * kk + 8 * g16]));
+        s16x8 fb = as_s16x8(ld16(&sm.Qm[(16 * tb + t16) * LDK + 32 * kk + 8 * g16]));
+        acc = mfma16x16x32_bf16(fa, fb, acc);
+      }
+      // D[i = s][j = l]: lane holds column l = 16 tb + t16, rows s = 16 ta + 4 g16 + r
+      *reinterpret_cast<f32x4*>(&sm.G[(16 * tb + t16) * LDG + 16 * ta + 4 * g16]) = acc;
+    }
+    block_sync();   // B1: G and scalars visible
+
+    // ---- O_diag = M U
+    f32x16 accD, accO;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { accD[r] = 0.f; accO[r] = 0.f; }
+    {
+      const int l = 32 * wi + l31;
+      const float cs_l = sm.cs[hh][l];
+      const int nks = 2 * (wi + 1);
+      for (int ks = 0; ks < nks; ks++) {
+        const int s0 = 16 * ks + 8 * h32;
+        f32x4 g0 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0]);
+        f32x4 g1 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0 + 4]);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int s = s0 + e;
+          const float gv = e < 4 ? g0[e & 3] : g1[e & 3];
+          const float v = gv * expf(cs_l - sm.cs[hh][s]) * sm.w[hh][s];
+          m[e] = (s <= l) ? v : 0.f;
+        }
+        // M is the one rounding point that dominates the error of y (the state terms decay away at the module's
+        // dt/A init), so it is fed to the MFMA as hi + lo bf16 pairs: two MFMAs on the same B fragment.
+        u32x4 mp, ml;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const uint16_t h0b = f32_to_bf16(m[2 * e2]), h1b = f32_to_bf16(m[2 * e2 + 1]);
+          mp[e2] = (uint32_t)h0b | ((uint32_t)h1b << 16);
+          ml[e2] = pack_bf16x2(m[2 * e2] - bf16_to_f32(h0b), m[2 * e2 + 1] - bf16_to_f32(h1b));
+        }
+        s16x8 fb = tr_frag(sm.U[hh], LDU, 16 * ks, 32 * wj, lane);
+        accD = mfma32x32x16_bf16(as_s16x8(mp), fb, accD);
+        accD = mfma32x32x16_bf16(as_s16x8(ml), fb, accD);
+      }
+    }
+    // ---- O_off = Q S_in^T  (contraction over k = 0..127)
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      s16x8 fa = as_s16x8(ld16(&sm.Qm[(32 * wi + l31) * LDK + 16 * ks + 8 * h32]));
+      s16x8 fb = as_s16x8(ld16(&sm.S[hh][(32 * wj + l31) * LDK + 16 * ks + 8 * h32]));
+      accO = mfma32x32x16_bf16(fa, fb, accO);
+    }
+    // ---- state update: S^T[k][u] = exp(cs_end) S^T + sum_l K^T[k][l] (ws_l U[l][u])
+    {
+      const float dec = sm.ecs[hh][QC - 1];
+#pragma unroll
+      for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accS[kt][r] *= dec;
+#pragma unroll
+      for (int ls = 0; ls < 4; ls++) {
+        s16x8 fu = tr_frag(sm.U[hh], LDU, 16 * ls, 32 * wj, lane);
+        const int lb = 16 * ls + 8 * h32;
+        u32x4 up;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const float lo = bf16_to_f32((uint16_t)fu[2 * e2]) * sm.ws[hh][lb + 2 * e2];
+          const float hi = bf16_to_f32((uint16_t)fu[2 * e2 + 1]) * sm.ws[hh][lb + 2 * e2 + 1];
+          up[e2] = pack_bf16x2(lo, hi);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+          s16x8 fk = tr_frag(sm.K, LDK, 16 * ls, 64 * wi + 32 * kt, lane);
+          accS[kt] = mfma32x32x16_bf16(fk, as_s16x8(up), accS[kt]);
+        }
+      }
+    }
+    block_sync();   // B2: every wave is done reading S_in, G, K, Q, U of this chunk
+    publish_state();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+      sm.O[hh][l * LDG + 32 * wj + l31] = accD[r] + sm.ecs[hh][l] * accO[r];
+    }
+    block_sync();   // B3: O tile and the new bf16 state are complete
+    // ---- epilogue: thread = (head r, row tid>>3, 8 columns)
+    {
+      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int hd = h0 + r;
+        f32x4 o0 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8]);
+        f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8 + 4]);
+        u32x4 uv = ld16(&sm.U[r][row * LDU + c8]);
+        float o[8], uu[8], res[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          o[e] = e < 4 ? o0[e & 3] : o1[e & 3];
+          uu[e] = (e & 1) ? bf_hi(uv[e >> 1]) : bf_lo(uv[e >> 1]);
+        }
+        float Dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) Dv[e] = a.D ? load_rt(a.D, (int64_t)hd * a.Dsh + (int64_t)(c8 + e) * a.Dsp, a.D_dt) : 0.f;
+        const int64_t oaddr = (int64_t)b * a.osb + (int64_t)t * a.osl + (int64_t)hd * a.osh + c8;
+        if (MODE == GS_Y) {
+          u32x4 px, pz;
+#pragma unroll
+          for (int e = 0; e < 8; e++) res[e] = o[e] + Dv[e] * uu[e];
+          if (a.outx) {
+            px[0] = pack_bf16x2(res[0], res[1]); px[1] = pack_bf16x2(res[2], res[3]); px[2] = pack_bf16x2(res[4], res[5]); px[3] = pack_bf16x2(res[6], res[7]);
+            if (t < a.L) st16((uint16_t*)a.outx + oaddr, px);
+          }
+          if (a.Z.p) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) res[e] *= silu_f((e & 1) ? bf_hi(ez[r][e >> 1]) : bf_lo(ez[r][e >> 1]));
+          }
+          pz[0] = pack_bf16x2(res[0], res[1]); pz[1] = pack_bf16x2(res[2], res[3]); pz[2] = pack_bf16x2(res[4], res[5]); pz[3] = pack_bf16x2(res[6], res[7]);
+          if (t < a.L) st16((uint16_t*)a.out + oaddr, pz);
+        } else {
+          const float dtt = sm.dtl[c & 1][r][row];
+          u32x4 pz;
+#pragma unroll
+          for (int e = 0; e < 8; e++) res[e] = dtt * o[e] + Dv[e] * uu[e];
+          pz[0] = pack_bf16x2(res[0], res[1]); pz[1] = pack_bf16x2(res[2], res[3]); pz[2] = pack_bf16x2(res[4], res[5]); pz[3] = pack_bf16x2(res[6], res[7]);
+          if (t < a.L) st16((uint16_t*)a.out + oaddr, pz);
+          if (Xe) {   // token scalars: w_t = sum_p x O ; e_t = sum_p dy (y - D x) ; dD += dy x
+            float wp = 0.f, ep = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float xv = (e & 1) ? bf_hi(ex[r][e >> 1]) : bf_lo(ex[r][e >> 1]);
+              const float yv = (e & 1) ? bf_hi(ey[r][e >> 1]) : bf_lo(ey[r][e >> 1]);
+              wp += xv * o[e];
+              ep += uu[e] * (yv - Dv[e] * xv);
+              dDp[r][e] += uu[e] * xv;
+            }
+            wp += shfl_xor(wp, 1); wp += shfl_xor(wp, 2); wp += shfl_xor(wp, 4);
+            ep += shfl_xor(ep, 1); ep += shfl_xor(ep, 2); ep += shfl_xor(ep, 4);
+            if ((tid & 7) == 0 && t < a.L) {
+              wsum[((int64_t)b * a.H + hd) * a.L + t] = wp;
+              esum[((int64_t)b * a.H + hd) * a.L + t] = ep;
+            }
+          }
+        }
+      }
+    }
+    commit((c + 1) & 1);   // tiles of chunk c+1 (no reader of chunk c's tiles is left after B2; the epilogue read sm.U before this)
+    block_sync();   // B4
+  }
+  if (MODE == GS_DX && a.dD) {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)((tid & 7) * 8 + e) * a.dDsp, dDp[r][e]);
+  }
+  if (a.fin) {
+    const float extra = a.fin_extra_decay ? expf(a.dtp[((int64_t)b * a.H + hcur) * a.L] * Ah) : 1.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 64 * wi + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * wj + l31;
+        a.fin[(int64_t)b * a.fsb + (int64_t)hcur * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = accS[kt][r] * extra;
+      }
+  }
+}
+
+static bool src_ok16(const Src& s, bool need) {
+  if (!s.p) return !need;
+  return s.dt == OMK_BF16 && ((uintptr_t)s.p & 15) == 0 && s.sb % 8 == 0 && s.sl % 8 == 0 && s.sh % 8 == 0;
+}
+
+int ssd_mfma_launch(const GScan& g, omk_stream stream) {
+  if (g.mode != GS_Y && g.mode != GS_DX) return OMK_EUNSUPPORTED;
+  if (g.DU != 64 || g.DK != 128 || g.H % 2 != 0 || (g.H / g.G) % 2 != 0) return OMK_EUNSUPPORTED;
+  if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true) || !src_ok16(g.Z, false)) return OMK_EUNSUPPORTED;
+  if (g.out_dt != OMK_BF16 || ((uintptr_t)g.out & 15) || g.osb % 8 || g.osl % 8 || g.osh % 8) return OMK_EUNSUPPORTED;
+  if (g.outx && ((uintptr_t)g.outx & 15)) return OMK_EUNSUPPORTED;
+  if (g.mode == GS_DX && g.XE.p && (!src_ok16(g.XE, true) || !src_ok16(g.YE, true))) return OMK_EUNSUPPORTED;
+  if (g.mode == GS_DX && g.dD && !g.XE.p) return OMK_EUNSUPPORTED;
+  dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
+  const size_t smem = sizeof(SmemA);
+  if (g.mode == GS_Y) {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a_kernel<GS_Y>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_a_kernel<GS_Y>), grid, block, smem, stream, g);
+  } else {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a_kernel<GS_DX>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_a_kernel<GS_DX>), grid, block, smem, stream, g);
+  }
+  return OMK_OK;
+}
+
+}  // namespace omk

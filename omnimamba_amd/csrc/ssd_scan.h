@@ -37,7 +37,11 @@ struct GScan {
   const void* D; int64_t Dsh, Dsp; int D_dt;                     // Y, DX
   float* acc32;                                                  // DC/DB: (B, L, G, DU) f32, atomically accumulated
   float* tokscal;                                                // DC: e, DB: wsum  (B, H, L) f32, atomically accumulated
-  float* dD; int64_t dDsh, dDsp;                                 // DB: optional grad of D
+  float* dD; int64_t dDsh, dDsp;                                 // DB (or DX with XE): optional grad of D
+  // DX only, optional: x (XE) and the forward's pre-gate output y (YE) -> the scan also emits the two token
+  // scalars of the backward (wsum_t = sum_p x O, esum_t = sum_p dy (y - D x)) and dD, with plain stores
+  Src XE, YE;
+  float* esum; float* wsum;                                      // (B, H, L) f32
 };
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);
