@@ -142,6 +142,16 @@ template <class T> __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // ---- math ---------------------------------------------------------------------------------------------
+// hardware transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp) for the inner loops of the MFMA kernels
+#ifdef OMK_EMU
+__device__ __forceinline__ float exp2_fast(float x) { return exp2f(x); }
+__device__ __forceinline__ float rcp_fast(float x) { return 1.f / x; }
+#else
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float silu_fast(float x) { return x * rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }

@@ -338,20 +338,88 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   return finish_launch("ssd_scan_fwd");
 }
 
-struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin; size_t total; };
-static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin) {
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part; size_t total; };
+static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, bool need_part) {
   BwdWs w; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
   const size_t bhl = (size_t)B * H * L * 4, blgn = (size_t)B * L * G * N * 4;
   w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl); w.dB32 = take(blgn); w.dC32 = take(blgn);
   w.sfin = need_sfin ? take((size_t)B * H * P * N * 4) : nullptr;
+  w.part = need_part ? take((size_t)B * (H / 2) * L * 128 * 4) : nullptr;
   w.total = off;
   return w;
 }
 
+// the three backward scans as descriptors (pointers into the workspace filled in by the caller)
+static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool mfma, GScan* gdc, GScan* gdx, GScan* gdb) {
+  const bool has_dfin = present(p->dfinal_states);
+  auto base = [&](int mode) {
+    GScan g = {};
+    g.mode = mode; g.dtp = w.dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L;
+    return g;
+  };
+  {  // dC: state [n][p], forward in time
+    GScan g = base(GS_DC);
+    g.U = make_src(p->Bm, true); g.K = make_src(p->x, false); g.Q = make_src(p->dout, false); g.X4 = make_src(p->Cm, true);
+    g.DU = d.N; g.DK = d.P; g.reverse = 0; g.w_is_dt = 1;
+    if (present(p->initial_states)) {
+      g.init = p->initial_states.data; g.init_dt = p->initial_states.dtype;
+      g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isk = p->initial_states.stride[2]; g.isu = p->initial_states.stride[3];
+    }
+    if (has_dfin) { g.fin = w.sfin; g.fsb = (int64_t)d.H * d.N * d.P; g.fsh = (int64_t)d.N * d.P; g.fsu = d.P; g.fsk = 1; }
+    if (mfma) g.part = w.part; else { g.acc32 = w.dC32; g.tokscal = w.e; }
+    *gdc = g;
+  }
+  {  // dx: state [p][n], reverse in time
+    GScan g = base(GS_DX);
+    g.U = make_src(p->dout, false); g.K = make_src(p->Cm, true); g.Q = make_src(p->Bm, true);
+    g.DU = d.P; g.DK = d.N; g.reverse = 1; g.w_is_dt = 0;
+    if (has_dfin) {
+      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
+      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isu = p->dfinal_states.stride[2]; g.isk = p->dfinal_states.stride[3];
+    }
+    if (present(p->dinitial_states)) {
+      g.fin = (float*)p->dinitial_states.data; g.fin_extra_decay = 1;
+      g.fsb = p->dinitial_states.stride[0]; g.fsh = p->dinitial_states.stride[1]; g.fsu = p->dinitial_states.stride[2]; g.fsk = p->dinitial_states.stride[3];
+    }
+    g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
+    if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
+    if (mfma) {
+      g.XE = make_src(p->x, false); g.YE = make_src(p->y, false); g.esum = w.e; g.wsum = w.wsum;
+      if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
+    }
+    *gdx = g;
+  }
+  {  // dB: state [n][p], reverse in time
+    GScan g = base(GS_DB);
+    g.U = make_src(p->Cm, true); g.K = make_src(p->dout, false); g.Q = make_src(p->x, false); g.X4 = make_src(p->Bm, true);
+    g.DU = d.N; g.DK = d.P; g.reverse = 1; g.w_is_dt = 0;
+    if (has_dfin) {
+      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
+      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isk = p->dfinal_states.stride[2]; g.isu = p->dfinal_states.stride[3];
+    }
+    if (mfma) g.part = w.part;
+    else {
+      g.acc32 = w.dB32; g.tokscal = w.wsum;
+      if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
+    }
+    *gdb = g;
+  }
+}
+
+static bool bwd_mfma_applies(const OmkSsdBwd* p, const SsdDims& d) {
+  if (p->force_generic || !present(p->y) || p->y.dtype != p->x.dtype || p->y.ndim != 4 || p->y.stride[3] != 1) return false;
+  if (p->dB.dtype != OMK_BF16 && p->dB.dtype != OMK_F32 && p->dB.dtype != OMK_F16) return false;
+  BwdWs w = {};
+  GScan gdc, gdx, gdb;
+  bwd_scans(p, d, w, true, &gdc, &gdx, &gdb);
+  return ssd_mfma_launch(gdc, nullptr, 1) == OMK_OK && ssd_mfma_launch(gdx, nullptr, 1) == OMK_OK && ssd_mfma_launch(gdb, nullptr, 1) == OMK_OK;
+}
+
 extern "C" size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p) {
   if (!p) return 0;
-  return bwd_ws_layout(nullptr, (int)p->x.shape[0], (int)p->x.shape[1], (int)p->x.shape[2], (int)p->x.shape[3], (int)p->Bm.shape[2], (int)p->Bm.shape[3], present(p->dfinal_states)).total;
+  SsdDims d = {(int)p->x.shape[0], (int)p->x.shape[1], (int)p->x.shape[2], (int)p->x.shape[3], (int)p->Bm.shape[2], (int)p->Bm.shape[3]};
+  return bwd_ws_layout(nullptr, d.B, d.L, d.H, d.P, d.G, d.N, present(p->dfinal_states), bwd_mfma_applies(p, d)).total;
 }
 
 extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
@@ -372,61 +440,27 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_bwd_workspace_bytes(p), "ssd_scan_bwd: workspace too small");
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
   const bool has_dfin = present(p->dfinal_states);
-  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin);
+  const bool mfma = bwd_mfma_applies(p, d);
+  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, mfma);
   const int64_t bhl = (int64_t)d.B * d.H * d.L, blgn = (int64_t)d.B * d.L * d.G * d.N;
-  launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream);
+  if (!mfma) { launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream); }
   launch_zero((float*)p->dA.data, d.H, stream);
   if (present(p->dD)) launch_zero((float*)p->dD.data, numel(p->dD), stream);
   if (present(p->ddt_bias)) launch_zero((float*)p->ddt_bias.data, d.H, stream);
   launch_dt_prep(p->dt, p->dt_bias, d, w.dtp, w.dsoft, p->dt_softplus, p->dt_min, p->dt_max, stream);
   const float* A = (const float*)p->A.data;
-  auto base = [&](int mode) {
-    GScan g = {};
-    g.mode = mode; g.dtp = w.dtp; g.A = A; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L;
-    return g;
-  };
-  {  // dC: state [n][p], forward in time
-    GScan g = base(GS_DC);
-    g.U = make_src(p->Bm, true); g.K = make_src(p->x, false); g.Q = make_src(p->dout, false); g.X4 = make_src(p->Cm, true);
-    g.DU = d.N; g.DK = d.P; g.reverse = 0; g.w_is_dt = 1;
-    if (present(p->initial_states)) {
-      g.init = p->initial_states.data; g.init_dt = p->initial_states.dtype;
-      g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isk = p->initial_states.stride[2]; g.isu = p->initial_states.stride[3];
-    }
-    if (has_dfin) { g.fin = w.sfin; g.fsb = (int64_t)d.H * d.N * d.P; g.fsh = (int64_t)d.N * d.P; g.fsu = d.P; g.fsk = 1; }
-    g.acc32 = w.dC32; g.tokscal = w.e;
-    rc = run_scan(g, p->force_generic, stream);
-    if (rc) return rc;
-  }
-  {  // dx: state [p][n], reverse in time
-    GScan g = base(GS_DX);
-    g.U = make_src(p->dout, false); g.K = make_src(p->Cm, true); g.Q = make_src(p->Bm, true);
-    g.DU = d.P; g.DK = d.N; g.reverse = 1; g.w_is_dt = 0;
-    if (has_dfin) {
-      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
-      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isu = p->dfinal_states.stride[2]; g.isk = p->dfinal_states.stride[3];
-    }
-    if (present(p->dinitial_states)) {
-      g.fin = (float*)p->dinitial_states.data; g.fin_extra_decay = 1;
-      g.fsb = p->dinitial_states.stride[0]; g.fsh = p->dinitial_states.stride[1]; g.fsu = p->dinitial_states.stride[2]; g.fsk = p->dinitial_states.stride[3];
-    }
-    g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
-    if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
-    rc = run_scan(g, p->force_generic, stream);
-    if (rc) return rc;
-  }
-  {  // dB: state [n][p], reverse in time
-    GScan g = base(GS_DB);
-    g.U = make_src(p->Cm, true); g.K = make_src(p->dout, false); g.Q = make_src(p->x, false); g.X4 = make_src(p->Bm, true);
-    g.DU = d.N; g.DK = d.P; g.reverse = 1; g.w_is_dt = 0;
-    if (has_dfin) {
-      g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
-      g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isk = p->dfinal_states.stride[2]; g.isu = p->dfinal_states.stride[3];
-    }
-    g.acc32 = w.dB32; g.tokscal = w.wsum;
-    if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
-    rc = run_scan(g, p->force_generic, stream);
-    if (rc) return rc;
+  GScan gdc, gdx, gdb;
+  bwd_scans(p, d, w, mfma, &gdc, &gdx, &gdb);
+  if (mfma) {
+    if ((rc = ssd_mfma_launch(gdx, stream))) return rc;
+    if ((rc = ssd_mfma_launch(gdc, stream))) return rc;
+    ssd_reduce_partials(w.part, p->dC.data, p->dC.stride[0], p->dC.stride[1], p->dC.stride[2], p->dC.dtype, d.B, d.L, d.G, d.H, stream);
+    if ((rc = ssd_mfma_launch(gdb, stream))) return rc;
+    ssd_reduce_partials(w.part, p->dB.data, p->dB.stride[0], p->dB.stride[1], p->dB.stride[2], p->dB.dtype, d.B, d.L, d.G, d.H, stream);
+  } else {
+    if ((rc = ssd_generic_launch(gdc, stream))) return rc;
+    if ((rc = ssd_generic_launch(gdx, stream))) return rc;
+    if ((rc = ssd_generic_launch(gdb, stream))) return rc;
   }
   {
     FinishArgs f = {};
@@ -440,7 +474,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     dim3 grid((unsigned)(d.B * d.H)), block(64);
     OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);
   }
-  {
+  if (!mfma) {
     int64_t blocks = (blgn + 255) / 256;
     dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks)), block(256);
     OMK_LAUNCH(cvt_f32_kernel, grid, block, 0, stream, (const float*)w.dB32, p->dB.data, p->dB.stride[0], p->dB.stride[1], p->dB.stride[2], d.B, d.L, d.G, d.N, (int)p->dB.dtype);

@@ -34,6 +34,7 @@ struct SmemA {
   float O[2][QC * LDG];
   float cs[2][QC], ecs[2][QC], w[2][QC], ws[2][QC];
   float dtl[2][2][QC];       // [chunk parity][head][row]: dt' of the token itself
+  float Dv[2][64];           // D of the two heads, per column (broadcast when D is (H))
 };
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
   f32x16 accS[2];
   const int hcur = h0 + hh;
   const float Ah = a.A[hcur];
+  const float Ah2 = Ah * LOG2E;   // decays are carried in log2 units so every exp is a bare v_exp_f32
 #pragma unroll
   for (int kt = 0; kt < 2; kt++)
 #pragma unroll
@@ -144,35 +146,20 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
   prefetch(0);
   commit(0);
   publish_state();
+  if (tid < 128) sm.Dv[tid >> 6][tid & 63] = a.D ? load_rt(a.D, (int64_t)(h0 + (tid >> 6)) * a.Dsh + (int64_t)(tid & 63) * a.Dsp, a.D_dt) : 0.f;
   block_sync();
 
   float dDp[2][8] = {{0.f}};   // DX: per-thread partial of dD over its (head, 8 columns)
   for (int c = 0; c < nC; c++) {
     prefetch(c + 1);
-    // epilogue operands straight from HBM into registers: segment (head r, row tid>>3, cols (tid&7)*8 .. +8)
-    u32x4 ez[2], ex[2], ey[2];
-    {
-      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        ez[r] = ex[r] = ey[r] = u32x4{0, 0, 0, 0};
-        if (t < a.L) {
-          if (MODE == GS_Y && a.Z.p) ez[r] = ld16((const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)t * a.Z.sl + (int64_t)(h0 + r) * a.Z.sh + c8);
-          if (MODE == GS_DX && Xe) {
-            ex[r] = ld16((const uint16_t*)Xe + (int64_t)b * xe_sb + (int64_t)t * xe_sl + (int64_t)(h0 + r) * xe_sh + c8);
-            ey[r] = ld16((const uint16_t*)Ye + (int64_t)b * ye_sb + (int64_t)t * ye_sl + (int64_t)(h0 + r) * ye_sh + c8);
-          }
-        }
-      }
-    }
     // ---- scalars: one wave per head, lanes = tokens
     if ((wave & 3) == 0) {
       const int t = tok(c, lane);
       const bool ok = t < a.L;
       const float d = sm.dtl[c & 1][hh][lane];
       float la;
-      if (rev) la = (ok && t + 1 < a.L) ? a.dtp[((int64_t)b * a.H + hcur) * a.L + t + 1] * Ah : 0.f;
-      else la = ok ? d * Ah : 0.f;
+      if (rev) la = (ok && t + 1 < a.L) ? a.dtp[((int64_t)b * a.H + hcur) * a.L + t + 1] * Ah2 : 0.f;
+      else la = ok ? d * Ah2 : 0.f;
       float cs = la;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -181,10 +168,10 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
       }
       const float cs_end = shfl(cs, 63);
       const float wv = ok ? (a.w_is_dt ? d : 1.f) : 0.f;
-      sm.cs[hh][lane] = cs;
-      sm.ecs[hh][lane] = expf(cs);
+      sm.cs[hh][lane] = cs;              // log2 units (la was scaled by log2 e)
+      sm.ecs[hh][lane] = exp2_fast(cs);
       sm.w[hh][lane] = wv;
-      sm.ws[hh][lane] = wv * expf(cs_end - cs);
+      sm.ws[hh][lane] = wv * exp2_fast(cs_end - cs);
     }
     // ---- G^T = K Q^T, lower triangle of 16x16 tiles (s-tile ta <= l-tile tb), 4 MFMA each
     for (int tile = wave; tile < 10; tile += 8) {
@@ -219,7 +206,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
         for (int e = 0; e < 8; e++) {
           const int s = s0 + e;
           const float gv = e < 4 ? g0[e & 3] : g1[e & 3];
-          const float v = gv * expf(cs_l - sm.cs[hh][s]) * sm.w[hh][s];
+          const float v = gv * exp2_fast(cs_l - sm.cs[hh][s]) * sm.w[hh][s];
           m[e] = (s <= l) ? v : 0.f;
         }
         // M is the one rounding point that dominates the error of y (the state terms decay away at the module's
@@ -269,6 +256,22 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
       }
     }
     block_sync();   // B2: every wave is done reading S_in, G, K, Q, U of this chunk
+    // epilogue operands (issued here so they are not live across the MFMA section) straight from HBM into registers: segment (head r, row tid>>3, cols (tid&7)*8 .. +8)
+    u32x4 ez[2], ex[2], ey[2];
+    {
+      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        ez[r] = ex[r] = ey[r] = u32x4{0, 0, 0, 0};
+        if (t < a.L) {
+          if (MODE == GS_Y && a.Z.p) ez[r] = ld16((const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)t * a.Z.sl + (int64_t)(h0 + r) * a.Z.sh + c8);
+          if (MODE == GS_DX && Xe) {
+            ex[r] = ld16((const uint16_t*)Xe + (int64_t)b * xe_sb + (int64_t)t * xe_sl + (int64_t)(h0 + r) * xe_sh + c8);
+            ey[r] = ld16((const uint16_t*)Ye + (int64_t)b * ye_sb + (int64_t)t * ye_sl + (int64_t)(h0 + r) * ye_sh + c8);
+          }
+        }
+      }
+    }
     publish_state();
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -292,8 +295,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
           uu[e] = (e & 1) ? bf_hi(uv[e >> 1]) : bf_lo(uv[e >> 1]);
         }
         float Dv[8];
+        {
+          const f32x4 d0 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8]), d1 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8 + 4]);
 #pragma unroll
-        for (int e = 0; e < 8; e++) Dv[e] = a.D ? load_rt(a.D, (int64_t)hd * a.Dsh + (int64_t)(c8 + e) * a.Dsp, a.D_dt) : 0.f;
+          for (int e = 0; e < 8; e++) Dv[e] = e < 4 ? d0[e & 3] : d1[e & 3];
+        }
         const int64_t oaddr = (int64_t)b * a.osb + (int64_t)t * a.osl + (int64_t)hd * a.osh + c8;
         if (MODE == GS_Y) {
           u32x4 px, pz;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
           }
           if (a.Z.p) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) res[e] *= silu_f((e & 1) ? bf_hi(ez[r][e >> 1]) : bf_lo(ez[r][e >> 1]));
+            for (int e = 0; e < 8; e++) res[e] *= silu_fast((e & 1) ? bf_hi(ez[r][e >> 1]) : bf_lo(ez[r][e >> 1]));
           }
           pz[0] = pack_bf16x2(res[0], res[1]); pz[1] = pack_bf16x2(res[2], res[3]); pz[2] = pack_bf16x2(res[4], res[5]); pz[3] = pack_bf16x2(res[6], res[7]);
           if (t < a.L) st16((uint16_t*)a.out + oaddr, pz);
@@ -357,12 +363,305 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
   }
 }
 
+// =========================================================================================================
+// class B: U shared by the group and 128 wide (B or C), K / Q per head and 64 wide (x, dy): the dC and dB scans.
+// State tiles S^T[k = p][u = n]; output O_h[l][n] of both heads is scaled (dB: by dt'_l), summed through LDS and
+// written as one fp32 [64][128] tile per chunk to the per-head-pair partial buffer (reduced over head pairs by
+// ssd_reduce_partials_kernel -- 64-way fp32 atomics measured 330 G/s on MI355X, 4x slower than partial tiles).
+// Wave w: head hh = w >> 2, (wi, wj): O tiles [32 wi ..][64 wj + 32 ut ..], state tiles S^T[32 wi ..][64 wj + 32 ut ..].
+// =========================================================================================================
+struct SmemB {
+  uint16_t U[QC * LDK];
+  uint16_t K[2][QC * LDU];
+  uint16_t Qm[2][QC * LDU];
+  union {
+    float G[2][QC * LDG];       // per-head G (dead after the M fragments are built)
+    float O[QC * 132];          // summed output tile, written after barrier B2
+  };
+  uint16_t S[2][128 * LDU];     // [u][k] bf16 copy of S_in
+  float cs[2][QC], ecs[2][QC], w[2][QC], ws[2][QC];
+  float dtl[2][2][QC];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
+  OMK_DYN_SMEM(smem_raw);
+  SmemB& sm = *reinterpret_cast<SmemB*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int h32 = lane >> 5, l31 = lane & 31, g16 = lane >> 4, t16 = lane & 15;
+  const int pairs = a.H / 2;
+  const int b = blockIdx.x / pairs, hp = blockIdx.x % pairs;
+  const int h0 = hp * 2;
+  const int g = h0 / (a.H / a.G);
+  const int nC = (a.L + QC - 1) / QC;
+  const bool rev = a.reverse != 0;
+  auto tok = [&](int c, int row) -> int {
+    const int id = rev ? nC - 1 - c : c;
+    return rev ? id * QC + (QC - 1) - row : id * QC + row;
+  };
+  // staging: U (64 x 128) two segments per thread; K, Q (2 heads x 64 x 64) one segment per thread per head
+  u32x4 ruu[2], rk[2], rq[2];
+  float rdt = 0.f;
+  const uint16_t* Ug = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)g * a.U.sh;
+  const uint16_t* Kg = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb;
+  const uint16_t* Qg = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb;
+  const float* dtp0 = a.dtp + ((int64_t)b * a.H + h0) * a.L;
+  auto prefetch = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
+      const int t = tok(c, row);
+      const bool ok = c < nC && t < a.L;
+      ruu[r] = ok ? ld16(Ug + (int64_t)t * a.U.sl + cs8) : u32x4{0, 0, 0, 0};
+      const int tu = tok(c, tid >> 3), cu8 = (tid & 7) * 8;
+      const bool oku = c < nC && tu < a.L;
+      rk[r] = oku ? ld16(Kg + (int64_t)tu * a.K.sl + (int64_t)(h0 + r) * a.K.sh + cu8) : u32x4{0, 0, 0, 0};
+      rq[r] = oku ? ld16(Qg + (int64_t)tu * a.Q.sl + (int64_t)(h0 + r) * a.Q.sh + cu8) : u32x4{0, 0, 0, 0};
+    }
+    if (tid < 128) {
+      const int t = tok(c, tid & 63);
+      rdt = (c < nC && t < a.L) ? dtp0[(int64_t)(tid >> 6) * a.L + t] : 0.f;
+    }
+  };
+  auto commit = [&](int par) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
+      st16(&sm.U[row * LDK + cs8], ruu[r]);
+      st16(&sm.K[r][(tid >> 3) * LDU + (tid & 7) * 8], rk[r]);
+      st16(&sm.Qm[r][(tid >> 3) * LDU + (tid & 7) * 8], rq[r]);
+    }
+    if (tid < 128) sm.dtl[par][tid >> 6][tid & 63] = rdt;
+  };
+  f32x16 accS[2];
+  const int hcur = h0 + hh;
+  const float Ah = a.A[hcur];
+  const float Ah2 = Ah * LOG2E;   // decays are carried in log2 units so every exp is a bare v_exp_f32
+#pragma unroll
+  for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = 0.f;
+      if (a.init) {
+        const int k = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 64 * wj + 32 * ut + l31;
+        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)hcur * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+      accS[ut][r] = v;
+    }
+  auto publish_state = [&]() {   // sm.S[hh][u][k]
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int rq4 = 0; rq4 < 4; rq4++) {
+        const int k = 32 * wi + 8 * rq4 + 4 * h32;
+        u32x2 v;
+        v[0] = pack_bf16x2(accS[ut][4 * rq4 + 0], accS[ut][4 * rq4 + 1]);
+        v[1] = pack_bf16x2(accS[ut][4 * rq4 + 2], accS[ut][4 * rq4 + 3]);
+        *reinterpret_cast<u32x2*>(&sm.S[hh][(64 * wj + 32 * ut + l31) * LDU + k]) = v;
+      }
+  };
+  prefetch(0);
+  commit(0);
+  publish_state();
+  block_sync();
+  float* part = a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
+
+  for (int c = 0; c < nC; c++) {
+    prefetch(c + 1);
+    if ((wave & 3) == 0) {
+      const int t = tok(c, lane);
+      const bool ok = t < a.L;
+      const float d = sm.dtl[c & 1][hh][lane];
+      float la;
+      if (rev) la = (ok && t + 1 < a.L) ? a.dtp[((int64_t)b * a.H + hcur) * a.L + t + 1] * Ah2 : 0.f;
+      else la = ok ? d * Ah2 : 0.f;
+      float cs = la;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        float o = shfl_up(cs, off);
+        if (lane >= off) cs += o;
+      }
+      const float cs_end = shfl(cs, 63);
+      const float wv = ok ? (a.w_is_dt ? d : 1.f) : 0.f;
+      sm.cs[hh][lane] = cs;              // log2 units (la was scaled by log2 e)
+      sm.ecs[hh][lane] = exp2_fast(cs);
+      sm.w[hh][lane] = wv;
+      sm.ws[hh][lane] = wv * exp2_fast(cs_end - cs);
+    }
+    // per-head G^T = K Q^T (contraction 64): 10 lower tiles over the head's 4 waves
+    for (int tile = (wave & 3); tile < 10; tile += 4) {
+      int ta, tb;
+      if (tile < 1) { tb = 0; ta = tile; } else if (tile < 3) { tb = 1; ta = tile - 1; } else if (tile < 6) { tb = 2; ta = tile - 3; } else { tb = 3; ta = tile - 6; }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        s16x8 fa = as_s16x8(ld16(&sm.K[hh][(16 * ta + t16) * LDU + 32 * kk + 8 * g16]));
+        s16x8 fb = as_s16x8(ld16(&sm.Qm[hh][(16 * tb + t16) * LDU + 32 * kk + 8 * g16]));
+        acc = mfma16x16x32_bf16(fa, fb, acc);
+      }
+      *reinterpret_cast<f32x4*>(&sm.G[hh][(16 * tb + t16) * LDG + 16 * ta + 4 * g16]) = acc;
+    }
+    block_sync();   // B1
+    f32x16 accD[2], accO[2];
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { accD[ut][r] = 0.f; accO[ut][r] = 0.f; }
+    {
+      const int l = 32 * wi + l31;
+      const float cs_l = sm.cs[hh][l];
+      const int nks = 2 * (wi + 1);
+      for (int ks = 0; ks < nks; ks++) {
+        const int s0 = 16 * ks + 8 * h32;
+        f32x4 g0 = *reinterpret_cast<const f32x4*>(&sm.G[hh][l * LDG + s0]);
+        f32x4 g1 = *reinterpret_cast<const f32x4*>(&sm.G[hh][l * LDG + s0 + 4]);
+        u32x4 mp, ml;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          float m2[2];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int e = 2 * e2 + q, s = s0 + e;
+            const float gv = e < 4 ? g0[e & 3] : g1[e & 3];
+            const float v = gv * exp2_fast(cs_l - sm.cs[hh][s]) * sm.w[hh][s];
+            m2[q] = (s <= l) ? v : 0.f;
+          }
+          const uint16_t h0b = f32_to_bf16(m2[0]), h1b = f32_to_bf16(m2[1]);
+          mp[e2] = (uint32_t)h0b | ((uint32_t)h1b << 16);
+          ml[e2] = pack_bf16x2(m2[0] - bf16_to_f32(h0b), m2[1] - bf16_to_f32(h1b));
+        }
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+          s16x8 fb = tr_frag(sm.U, LDK, 16 * ks, 64 * wj + 32 * ut, lane);
+          accD[ut] = mfma32x32x16_bf16(as_s16x8(mp), fb, accD[ut]);
+          accD[ut] = mfma32x32x16_bf16(as_s16x8(ml), fb, accD[ut]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s16x8 fa = as_s16x8(ld16(&sm.Qm[hh][(32 * wi + l31) * LDU + 16 * ks + 8 * h32]));
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++) {
+        s16x8 fb = as_s16x8(ld16(&sm.S[hh][(64 * wj + 32 * ut + l31) * LDU + 16 * ks + 8 * h32]));
+        accO[ut] = mfma32x32x16_bf16(fa, fb, accO[ut]);
+      }
+    }
+    {
+      const float dec = sm.ecs[hh][QC - 1];
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accS[ut][r] *= dec;
+#pragma unroll
+      for (int ls = 0; ls < 4; ls++) {
+        s16x8 fk = tr_frag(sm.K[hh], LDU, 16 * ls, 32 * wi, lane);   // A operand K^T[k][l], scaled along l by ws
+        const int lb = 16 * ls + 8 * h32;
+        u32x4 kp;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const float lo = bf16_to_f32((uint16_t)fk[2 * e2]) * sm.ws[hh][lb + 2 * e2];
+          const float hi = bf16_to_f32((uint16_t)fk[2 * e2 + 1]) * sm.ws[hh][lb + 2 * e2 + 1];
+          kp[e2] = pack_bf16x2(lo, hi);
+        }
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+          s16x8 fu = tr_frag(sm.U, LDK, 16 * ls, 64 * wj + 32 * ut, lane);
+          accS[ut] = mfma32x32x16_bf16(as_s16x8(kp), fu, accS[ut]);
+        }
+      }
+    }
+    block_sync();   // B2: G, S_in and the tiles of this chunk are no longer read
+    publish_state();
+    // head 0 writes its scaled tile, head 1 adds
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      if (hh == pass) {
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+            float v = accD[ut][r] + sm.ecs[hh][l] * accO[ut][r];
+            if (MODE == GS_DB) v *= sm.dtl[c & 1][hh][l];
+            float* o = &sm.O[l * 132 + 64 * wj + 32 * ut + l31];
+            *o = pass == 0 ? v : *o + v;
+          }
+      }
+      block_sync();   // B3a / B3b
+    }
+    {   // [64][128] fp32 tile -> partial buffer, 4 x 16 B per thread
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int seg = tid + 512 * r, row = seg >> 5, c4 = (seg & 31) * 4;
+        const int t = tok(c, row);
+        if (t < a.L) *reinterpret_cast<f32x4*>(part + (int64_t)t * 128 + c4) = *reinterpret_cast<const f32x4*>(&sm.O[row * 132 + c4]);
+      }
+    }
+    commit((c + 1) & 1);
+    block_sync();   // B4
+  }
+  if (a.fin) {
+    const float extra = a.fin_extra_decay ? expf(a.dtp[((int64_t)b * a.H + hcur) * a.L] * Ah) : 1.f;
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 64 * wj + 32 * ut + l31;
+        a.fin[(int64_t)b * a.fsb + (int64_t)hcur * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = accS[ut][r] * extra;
+      }
+  }
+}
+
+// out[b][t][g][n] = sum over the head pairs of group g of part[b][pair][t][n]
+__global__ void ssd_reduce_partials_kernel(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt,
+                                           int B, int L, int G, int pairs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = 4 consecutive n
+  const int64_t total = (int64_t)B * L * G * 32;
+  if (i >= total) return;
+  const int n4 = (int)(i % 32) * 4, g = (int)((i / 32) % G), t = (int)((i / (32 * (int64_t)G)) % L), b = (int)(i / (32 * (int64_t)G * L));
+  const int ppg = pairs / G;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < ppg; p++) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + (((int64_t)b * pairs + g * ppg + p) * L + t) * 128 + n4);
+    acc += v;
+  }
+  const int64_t o = (int64_t)b * osb + (int64_t)t * osl + (int64_t)g * osg + n4;
+#pragma unroll
+  for (int e = 0; e < 4; e++) store_rt(out, o + e, out_dt, acc[e]);
+}
+
+int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream) {
+  const int64_t total = (int64_t)B * L * G * 32;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  OMK_LAUNCH(ssd_reduce_partials_kernel, grid, block, 0, stream, part, out, osb, osl, osg, out_dt, B, L, G, H / 2);
+  return OMK_OK;
+}
+
 static bool src_ok16(const Src& s, bool need) {
   if (!s.p) return !need;
   return s.dt == OMK_BF16 && ((uintptr_t)s.p & 15) == 0 && s.sb % 8 == 0 && s.sl % 8 == 0 && s.sh % 8 == 0;
 }
 
-int ssd_mfma_launch(const GScan& g, omk_stream stream) {
+static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
+  if (g.DU != 128 || g.DK != 64 || g.H % 2 != 0 || (g.H / g.G) % 2 != 0 || (!g.part && !dry)) return OMK_EUNSUPPORTED;
+  if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true)) return OMK_EUNSUPPORTED;
+  if (dry) return OMK_OK;
+  dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
+  const size_t smem = sizeof(SmemB);
+  if (g.mode == GS_DC) {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_b_kernel<GS_DC>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_b_kernel<GS_DC>), grid, block, smem, stream, g);
+  } else {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_b_kernel<GS_DB>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_b_kernel<GS_DB>), grid, block, smem, stream, g);
+  }
+  return OMK_OK;
+}
+
+int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
+  if (g.mode == GS_DC || g.mode == GS_DB) return ssd_mfma_launch_b(g, stream, dry);
   if (g.mode != GS_Y && g.mode != GS_DX) return OMK_EUNSUPPORTED;
   if (g.DU != 64 || g.DK != 128 || g.H % 2 != 0 || (g.H / g.G) % 2 != 0) return OMK_EUNSUPPORTED;
   if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true) || !src_ok16(g.Z, false)) return OMK_EUNSUPPORTED;
@@ -370,6 +669,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream) {
   if (g.outx && ((uintptr_t)g.outx & 15)) return OMK_EUNSUPPORTED;
   if (g.mode == GS_DX && g.XE.p && (!src_ok16(g.XE, true) || !src_ok16(g.YE, true))) return OMK_EUNSUPPORTED;
   if (g.mode == GS_DX && g.dD && !g.XE.p) return OMK_EUNSUPPORTED;
+  if (dry) return OMK_OK;
   dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
   const size_t smem = sizeof(SmemA);
   if (g.mode == GS_Y) {

@@ -42,10 +42,12 @@ struct GScan {
   // scalars of the backward (wsum_t = sum_p x O, esum_t = sum_p dy (y - D x)) and dD, with plain stores
   Src XE, YE;
   float* esum; float* wsum;                                      // (B, H, L) f32
+  float* part;                                                   // DC/DB (MFMA): (B, H/2, L, 128) f32 per-head-pair partial tiles
 };
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);
 // returns OMK_EUNSUPPORTED (without touching the error text) when the shape/dtype/layout is outside the MFMA kernel
-int ssd_mfma_launch(const GScan& g, omk_stream stream);
+int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 1: only answer whether it applies
+int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
 }  // namespace omk

@@ -57,10 +57,13 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
 
 
 def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
-                 dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False):
-    """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states)."""
+                 dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None):
+    """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states).  `y` = the forward's pre-gate
+    output (D*x included); with it the MFMA path applies."""
     lib = get_lib()
-    x, B, C, dout = _last_contig(x), _last_contig(B), _last_contig(C), _last_contig(dout)
+    x, B, C, dout, y = _last_contig(x), _last_contig(B), _last_contig(C), _last_contig(dout), _last_contig(y)
+    if y is not None and y.dtype != x.dtype:
+        y = y.to(x.dtype)
     if B.dtype != x.dtype:
         B = B.to(x.dtype)
     if C.dtype != x.dtype:
@@ -83,7 +86,7 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
         dfinal_states = dfinal_states.float()
     if x.numel() > 0:
         p = K.SsdBwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), dt_bias=K.T(dt_bias),
-                     initial_states=K.T(initial_states), dout=K.T(dout), dfinal_states=K.T(dfinal_states), dx=K.T(dx),
+                     initial_states=K.T(initial_states), y=K.T(y), dout=K.T(dout), dfinal_states=K.T(dfinal_states), dx=K.T(dx),
                      ddt=K.T(ddt), dA=K.T(dA), dB=K.T(dB), dC=K.T(dC), dD=K.T(dD), ddt_bias=K.T(ddtb),
                      dinitial_states=K.T(dinit), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
                      dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic))
@@ -114,7 +117,7 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
         out, out_x, fin = ssd_scan_fwd(x, dt, A, B, C, D=D, z=z, dt_bias=dt_bias, initial_states=initial_states,
                                        dt_softplus=dt_softplus, dt_limit=dt_limit,
                                        return_final_states=return_final_states, want_out_x=True, chunk_size=chunk_size)
-        ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x)
+        ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x if z is not None else out)
         ctx.dt_softplus, ctx.dt_limit, ctx.chunk_size = dt_softplus, dt_limit, chunk_size
         ctx.return_final_states = return_final_states
         return (out, fin) if return_final_states else out
@@ -130,7 +133,7 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
             dout = (dout.float() * F.silu(zf)).to(x.dtype)
         g = ssd_scan_bwd(dout, x, dt, A, B, C, D=D, dt_bias=dt_bias, initial_states=initial_states,
                          dfinal_states=dfinal, dt_softplus=ctx.dt_softplus, dt_limit=ctx.dt_limit,
-                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None)
+                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None, y=out_x)
         dinit = g["dinitial_states"]
         return (g["dx"], g["ddt"].to(dt.dtype), g["dA"].to(A.dtype), g["dB"].to(B.dtype), g["dC"].to(C.dtype), None,
                 None if D is None else g["dD"].to(D.dtype), dz,
