@@ -57,7 +57,8 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
 
 
 def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
-                 dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None):
+                 dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None,
+                 dx_out=None, dB_out=None, dC_out=None):
     """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states).  `y` = the forward's pre-gate
     output (D*x included); with it the MFMA path applies."""
     lib = get_lib()
@@ -74,11 +75,11 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
     Bsz, L, H, P = x.shape
     G, N = B.shape[2], B.shape[3]
     dev = x.device
-    dx = torch.empty(Bsz, L, H, P, dtype=x.dtype, device=dev)
+    dx = dx_out if dx_out is not None else torch.empty(Bsz, L, H, P, dtype=x.dtype, device=dev)
     ddt = torch.empty(Bsz, L, H, dtype=torch.float32, device=dev)
     dA = torch.empty(H, dtype=torch.float32, device=dev)
-    dB = torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
-    dC = torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
+    dB = dB_out if dB_out is not None else torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
+    dC = dC_out if dC_out is not None else torch.empty(Bsz, L, G, N, dtype=x.dtype, device=dev)
     dD = None if D is None else torch.empty(D.shape, dtype=torch.float32, device=dev)
     ddtb = None if dt_bias is None else torch.empty(H, dtype=torch.float32, device=dev)
     dinit = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=dev) if need_dinit else None
@@ -150,3 +151,134 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bia
     return MambaChunkScanCombinedFn.apply(x, dt, A, B, C, chunk_size, D, z, dt_bias, initial_states, seq_idx,
                                           cu_seqlens, dt_softplus, dt_limit, return_final_states,
                                           return_varlen_states)
+
+
+class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
+    """conv1d+SiLU -> SSD scan -> gated RMSNorm -> out_proj as ONE autograd node (upstream K2; SURVEY.md section 8
+    row a9).  Saves only zxbcdt, the pre-norm y and the parameters; the conv output is recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None, seq_idx=None,
+                dt_limit=(0.0, _INF), return_final_states=False, activation="silu", rmsnorm_weight=None,
+                rmsnorm_eps=1e-6, outproj_weight=None, outproj_bias=None, headdim=None, ngroups=1,
+                norm_before_gate=True):
+        if seq_idx is not None:
+            raise NotImplementedError("seq_idx never reaches the mixer in OmniMamba")
+        if activation not in ("silu", "swish"):
+            raise NotImplementedError("activation must be silu/swish")
+        if D.dim() == 1:
+            assert headdim is not None
+            H = D.shape[0]
+        else:
+            H, headdim = D.shape
+        Bsz, L, _ = zxbcdt.shape
+        P, G = headdim, ngroups
+        d_ssm = H * P
+        N = (conv1d_weight.shape[0] - d_ssm) // (2 * G)
+        if zxbcdt.shape[-1] != 2 * d_ssm + 2 * G * N + H:
+            raise NotImplementedError("d_mlp > 0 (d_ssm < d_inner) is handled by the un-fused path of Mamba2.forward")
+        if zxbcdt.stride(-1) != 1:
+            zxbcdt = zxbcdt.contiguous()
+        z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
+        xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv1d_weight, conv1d_bias, activation=activation).transpose(1, 2)
+        x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
+        use_norm = rmsnorm_weight is not None
+        zz = z.reshape(Bsz, L, H, P) if z.is_contiguous() else z.unflatten(-1, (H, P))
+        y, y_x, fin = ssd_scan_fwd(x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)), Cm.unflatten(-1, (G, N)), D=D,
+                                   z=None if use_norm else zz, dt_bias=dt_bias, initial_states=initial_states,
+                                   dt_softplus=True, dt_limit=dt_limit, return_final_states=return_final_states,
+                                   want_out_x=True, chunk_size=chunk_size)
+        y_pre = y if (use_norm or y_x is None) else y_x        # pre-gate / pre-norm scan output (D*x included)
+        if use_norm:
+            out_n = rmsnorm_fn(y.reshape(Bsz, L, d_ssm), rmsnorm_weight, None, z=z, eps=rmsnorm_eps,
+                               group_size=d_ssm // G, norm_before_gate=norm_before_gate)
+        else:
+            out_n = y.reshape(Bsz, L, d_ssm)
+        if outproj_weight is not None:
+            w = outproj_weight.to(out_n.dtype)
+            out = F.linear(out_n, w, None if outproj_bias is None else outproj_bias.to(out_n.dtype))
+        else:
+            out = out_n
+        ctx.save_for_backward(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, y_pre, rmsnorm_weight, outproj_weight,
+                              outproj_bias, initial_states)
+        ctx.cfg = (H, P, G, N, chunk_size, dt_limit, activation, rmsnorm_eps, norm_before_gate, return_final_states)
+        return (out, fin) if return_final_states else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        (zxbcdt, conv_w, conv_b, dt_bias, A, D, y_pre, norm_w, outproj_w, outproj_b, initial_states) = ctx.saved_tensors
+        H, P, G, N, chunk_size, dt_limit, activation, eps, nbg, ret_fin = ctx.cfg
+        dfinal = args[0] if ret_fin and args else None
+        Bsz, L, _ = zxbcdt.shape
+        d_ssm = H * P
+        dev, adt = zxbcdt.device, zxbcdt.dtype
+        use_norm = norm_w is not None
+        z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
+        dzxbcdt = torch.empty_like(zxbcdt)
+        dz, dxBC, ddt_v = torch.split(dzxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
+        # ---- out_proj (recompute the cheap norm output: it is the GEMM's other operand)
+        dout = dout.to(adt)
+        d_outproj_w = d_outproj_b = None
+        y2 = y_pre.reshape(Bsz, L, d_ssm)
+        if use_norm:
+            with torch.enable_grad():
+                yd, zd = y2.detach().requires_grad_(), z.detach().requires_grad_()
+                wd = norm_w.detach().requires_grad_()
+                out_n = rmsnorm_fn(yd, wd, None, z=zd, eps=eps, group_size=d_ssm // G, norm_before_gate=nbg)
+            on = out_n.detach()
+        else:
+            on = (y2.float() * F.silu(z.float())).to(adt)
+        if outproj_w is not None:
+            d_outn = dout @ outproj_w.to(adt)
+            d_outproj_w = (dout.reshape(-1, dout.shape[-1]).t() @ on.reshape(-1, d_ssm)).to(outproj_w.dtype)
+            if outproj_b is not None:
+                d_outproj_b = dout.reshape(-1, dout.shape[-1]).sum(0).to(outproj_b.dtype)
+        else:
+            d_outn = dout
+        # ---- gated norm (or plain gate) backward
+        d_norm_w = None
+        if use_norm:
+            gy, gz, gw = torch.autograd.grad(out_n, [yd, zd, wd], d_outn)
+            dy = gy
+            dz.copy_(gz)
+            d_norm_w = gw.to(norm_w.dtype)
+        else:
+            zf = z.float()
+            dz.copy_((d_outn.float() * y2.float() * _silu_grad(zf)).to(adt))
+            dy = (d_outn.float() * F.silu(zf)).to(adt)
+        # ---- recompute conv, SSD backward writes straight into the dxBC_conv buffer
+        xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv_w, conv_b, activation=activation).transpose(1, 2)
+        x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
+        dxBC_c = torch.empty_like(xBC_c)
+        dx_v, dB_v, dC_v = torch.split(dxBC_c, [d_ssm, G * N, G * N], dim=-1)
+        g = ssd_scan_bwd(dy.reshape(Bsz, L, H, P), x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)),
+                         Cm.unflatten(-1, (G, N)), D=D, dt_bias=dt_bias, initial_states=initial_states,
+                         dfinal_states=dfinal, dt_softplus=True, dt_limit=dt_limit, chunk_size=chunk_size,
+                         need_dinit=initial_states is not None, y=y_pre, dx_out=dx_v.unflatten(-1, (H, P)),
+                         dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)))
+        ddt_v.copy_(g["ddt"])
+        # ---- conv backward: dx lands in the xBC slice of dzxbcdt
+        lib = get_lib()
+        dw = torch.zeros(conv_w.shape, dtype=torch.float32, device=dev)
+        db = None if conv_b is None else torch.zeros(conv_b.shape, dtype=torch.float32, device=dev)
+        p = K.Conv1dBwd(x=K.T(xBC.transpose(1, 2)), weight=K.T(conv_w), bias=K.T(conv_b), initial_states=K.T(None),
+                        dout=K.T(dxBC_c.transpose(1, 2)), dx=K.T(dxBC.transpose(1, 2)), dweight=K.T(dw), dbias=K.T(db),
+                        dinitial_states=K.T(None), silu=1)
+        K.run(lib, "omk_causal_conv1d_bwd", p, zxbcdt)
+        dinit = g["dinitial_states"]
+        return (dzxbcdt, dw.to(conv_w.dtype), None if conv_b is None else db.to(conv_b.dtype),
+                g["ddt_bias"].to(dt_bias.dtype), g["dA"].to(A.dtype), g["dD"].to(D.dtype), None,
+                None if dinit is None else dinit.to(initial_states.dtype), None, None, None, None, d_norm_w, None,
+                d_outproj_w, d_outproj_b, None, None, None)
+
+
+def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None,
+                                     seq_idx=None, dt_limit=(0.0, _INF), return_final_states=False, activation="silu",
+                                     rmsnorm_weight=None, rmsnorm_eps=1e-6, outproj_weight=None, outproj_bias=None,
+                                     headdim=None, ngroups=1, norm_before_gate=True):
+    """zxbcdt: (batch, seqlen, 2 * dim + 2 * ngroups * dstate + nheads); conv1d_weight: (dim + 2 * ngroups * dstate,
+    width); dt_bias, A: (nheads); D: (nheads, headdim) or (nheads,).  Returns out (batch, seqlen, d_model | dim)."""
+    return MambaSplitConv1dScanCombinedFn.apply(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size,
+                                                initial_states, seq_idx, dt_limit, return_final_states, activation,
+                                                rmsnorm_weight, rmsnorm_eps, outproj_weight, outproj_bias, headdim,
+                                                ngroups, norm_before_gate)
