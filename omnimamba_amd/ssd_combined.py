@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _capi as K
+from . import _prof
 from ._lib import get_lib, require_device
 from .causal_conv1d import causal_conv1d_fn
 from .layernorm_gated import rmsnorm_fn
@@ -50,7 +51,8 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
                      dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]), dt_softplus=int(dt_softplus),
                      chunk_size=int(chunk_size), force_generic=int(force_generic))
         ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
-        K.run(lib, "omk_ssd_scan_fwd", p, x)
+        with _prof.range_("ssd_scan_fwd"):
+            K.run(lib, "omk_ssd_scan_fwd", p, x)
     elif fin is not None:
         fin.zero_() if initial_states is None else fin.copy_(initial_states)
     return out, out_x, fin
@@ -92,7 +94,8 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
                      dinitial_states=K.T(dinit), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
                      dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic))
         ws = K.workspace(lib, "omk_ssd_scan_bwd_workspace_bytes", p, x)  # noqa: F841
-        K.run(lib, "omk_ssd_scan_bwd", p, x)
+        with _prof.range_("ssd_scan_bwd"):
+            K.run(lib, "omk_ssd_scan_bwd", p, x)
     else:
         for t in (dA, dD, ddtb):
             if t is not None:
