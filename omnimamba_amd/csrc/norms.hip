@@ -1,8 +1,11 @@
 // norms.hip -- fused residual-add + RMSNorm/LayerNorm (layer_norm_fn) and gated RMSNorm (Mamba2.norm), fwd + bwd.
 //
-// Both are pure HBM streaming ops: one 64-lane wave owns one row (or one
-// (row, group) segment), keeps it in registers as NCHUNK x VEC floats per lane, reduces with wave shuffles
-// (no LDS, no block barrier) and touches every byte exactly once: 16-byte loads/stores per lane.
+// Pure HBM streaming ops.  A row (or one (row, group) segment) is owned by WPR
+// waves of a 256-thread block and lives in registers as NCHUNK x VEC floats per lane: WPR = 1 for rows up to 2048
+// elements (wave-shuffle reductions only, no barrier), WPR = 4 (the whole block, one LDS exchange per reduction) for
+// wider rows such as the 4096-lane gated norm of the 1.3B block -- so no array exceeds 32 floats per lane and nothing
+// spills.  Every byte is touched once with 16-byte loads/stores; weight-gradient partials go to a [nparts][cols]
+// workspace (nparts <= 1024) that a second tiny kernel folds.
 // Algorithmic bytes per row of `cols`: add+norm fwd = cols * (sx + sres_in + sx + sres_out); gated fwd = 3 * cols * sx.
 #include "omk_common.h"
 
@@ -10,6 +13,27 @@ namespace omk {
 
 constexpr int NORM_THREADS = 256;
 constexpr int NORM_WAVES = NORM_THREADS / 64;
+constexpr int NORM_MAX_BLOCKS = 1024;
+
+template <int WPR> __device__ __forceinline__ float row_sum(float v, float* red, int wave) {
+  v = wave_sum(v);
+  if constexpr (WPR == 1) {
+    return v;
+  } else {
+    block_sync();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    block_sync();
+    return red[0] + red[1] + red[2] + red[3];
+  }
+}
+// element chunk c of this lane covers columns NORM_COL(c) .. + VEC of its row
+#define NORM_ROWMAP()                                                         \
+  __shared__ float red[NORM_WAVES];                                           \
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                 \
+  constexpr int RPB = NORM_WAVES / WPR; /* rows per block */                  \
+  const int wsub = wave % WPR, wrow = wave / WPR;                             \
+  (void)red
+#define NORM_COL(c) ((((c) * WPR + wsub) * 64 + lane) * VEC)
 
 template <class T, int VEC>
 __device__ __forceinline__ void ld(const T* p, float (&o)[VEC]) { load_vec<T, VEC>(p, o); }
@@ -22,81 +46,6 @@ struct NormArgs {
   int64_t xs, rs, ys, ros, zs;      // row strides (elements)
   int64_t rows; int cols; int ngroups; int wdt, bdt; float eps; int rms; int norm_before_gate;
 };
-
-// ---------------------------------------------------------------------------------------------------------
-// forward: y = norm(x + residual) * w + b ; residual_out = x + residual
-// ---------------------------------------------------------------------------------------------------------
-template <class TX, class TR, class TRO, int VEC, int NCHUNK>
-__global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const TX* x = (const TX*)a.x;
-  const TR* res = (const TR*)a.res;
-  TX* y = (TX*)a.y;
-  TRO* ro = (TRO*)a.ro;
-  const float inv_n = 1.f / (float)a.cols;
-  for (int64_t row = (int64_t)blockIdx.x * NORM_WAVES + wave; row < a.rows; row += (int64_t)gridDim.x * NORM_WAVES) {
-    float v[NCHUNK][VEC];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
-      if (col < a.cols) {
-        ld<TX, VEC>(x + row * a.xs + col, v[c]);
-        if (res) {
-          float r[VEC];
-          ld<TR, VEC>(res + row * a.rs + col, r);
-#pragma unroll
-          for (int i = 0; i < VEC; i++) v[c][i] += r[i];
-        }
-        if (ro) st<TRO, VEC>(ro + row * a.ros + col, v[c]);
-#pragma unroll
-        for (int i = 0; i < VEC; i++) { s1 += v[c][i]; s2 += v[c][i] * v[c][i]; }
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; i++) v[c][i] = 0.f;
-      }
-    }
-    float mu = 0.f, var;
-    if (a.rms) {
-      var = wave_sum(s2) * inv_n;
-    } else {
-      mu = wave_sum(s1) * inv_n;
-      float d2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < NCHUNK; c++) {
-        int col = (c * 64 + lane) * VEC;
-        if (col < a.cols) {
-#pragma unroll
-          for (int i = 0; i < VEC; i++) { float d = v[c][i] - mu; d2 += d * d; }
-        }
-      }
-      var = wave_sum(d2) * inv_n;
-    }
-    float rstd = rsqrtf(var + a.eps);
-    if (lane == 0) {
-      if (a.rstd) a.rstd[row] = rstd;
-      if (a.mean) a.mean[row] = mu;
-    }
-#pragma unroll
-    for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
-      if (col < a.cols) {
-        float o[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; i++) {
-          float w = load_rt(a.w, col + i, a.wdt);
-          o[i] = (v[c][i] - mu) * rstd * w;
-          if (a.b) o[i] += load_rt(a.b, col + i, a.bdt);
-        }
-        st<TX, VEC>(y + row * a.ys + col, o);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// backward of the above.  dx = (wdy - xhat*c1 - c2) * rstd + dresidual_out ; dw += dy * xhat ; db += dy
-// ---------------------------------------------------------------------------------------------------------
 struct NormBwdArgs {
   const void* dy; const void* dro; const void* xsum; const void* w; const float* rstd; const float* mean;
   const void* x; const void* z;     // gated only
@@ -106,9 +55,85 @@ struct NormBwdArgs {
   int64_t rows; int cols; int ngroups; int wdt; int rms; float eps; int norm_before_gate;
 };
 
-template <class TX, class TS, class TRI, int VEC, int NCHUNK>
+// ---------------------------------------------------------------------------------------------------------
+// forward: y = norm(x + residual) * w + b ; residual_out = x + residual
+// ---------------------------------------------------------------------------------------------------------
+template <class TX, class TR, class TRO, int VEC, int NCHUNK, int WPR>
+__global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) {
+  NORM_ROWMAP();
+  const TX* x = (const TX*)a.x;
+  const TR* res = (const TR*)a.res;
+  TX* y = (TX*)a.y;
+  TRO* ro = (TRO*)a.ro;
+  const float inv_n = 1.f / (float)a.cols;
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    const int64_t row = rlive ? rraw : a.rows - 1;
+    float v[NCHUNK][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      const int col = NORM_COL(c);
+      if (col < a.cols) {
+        ld<TX, VEC>(x + row * a.xs + col, v[c]);
+        if (res) {
+          float r[VEC];
+          ld<TR, VEC>(res + row * a.rs + col, r);
+#pragma unroll
+          for (int i = 0; i < VEC; i++) v[c][i] += r[i];
+        }
+        if (ro && rlive) st<TRO, VEC>(ro + row * a.ros + col, v[c]);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { s1 += v[c][i]; s2 += v[c][i] * v[c][i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) v[c][i] = 0.f;
+      }
+    }
+    float mu = 0.f, var;
+    if (a.rms) {
+      var = row_sum<WPR>(s2, red, wave) * inv_n;
+    } else {
+      mu = row_sum<WPR>(s1, red, wave) * inv_n;
+      float d2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCHUNK; c++) {
+        if (NORM_COL(c) < a.cols) {
+#pragma unroll
+          for (int i = 0; i < VEC; i++) { float d = v[c][i] - mu; d2 += d * d; }
+        }
+      }
+      var = row_sum<WPR>(d2, red, wave) * inv_n;
+    }
+    const float rstd = rsqrtf(var + a.eps);
+    if (lane == 0 && wsub == 0 && rlive) {
+      if (a.rstd) a.rstd[row] = rstd;
+      if (a.mean) a.mean[row] = mu;
+    }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      const int col = NORM_COL(c);
+      if (col < a.cols && rlive) {
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          o[i] = (v[c][i] - mu) * rstd * load_rt(a.w, col + i, a.wdt);
+          if (a.b) o[i] += load_rt(a.b, col + i, a.bdt);
+        }
+        st<TX, VEC>(y + row * a.ys + col, o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward.  dx = (wdy - xhat*c1 - c2) * rstd + dresidual_out ; dw += dy * xhat ; db += dy
+// ---------------------------------------------------------------------------------------------------------
+template <class TX, class TS, class TRI, int VEC, int NCHUNK, int WPR>
 __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  NORM_ROWMAP();
   const TX* dy = (const TX*)a.dy;
   const TS* dro = (const TS*)a.dro;   // grad of residual_out has residual_out's dtype (= xsum's)
   const TS* xsum = (const TS*)a.xsum;
@@ -120,15 +145,19 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
   for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
     for (int i = 0; i < VEC; i++) { dwacc[c][i] = 0.f; dbacc[c][i] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * NORM_WAVES + wave; row < a.rows; row += (int64_t)gridDim.x * NORM_WAVES) {
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    const int64_t row = rlive ? rraw : a.rows - 1;
     float xh[NCHUNK][VEC], wdy[NCHUNK][VEC];
     const float rstd = a.rstd[row];
     const float mu = a.mean ? a.mean[row] : 0.f;
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
-      if (col < a.cols) {
+      const int col = NORM_COL(c);
+      if (col < a.cols && rlive) {
         float g[VEC];
         ld<TS, VEC>(xsum + row * a.xss + col, xh[c]);
         ld<TX, VEC>(dy + row * a.dys + col, g);
@@ -146,12 +175,12 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
         for (int i = 0; i < VEC; i++) { xh[c][i] = 0.f; wdy[c][i] = 0.f; }
       }
     }
-    c1 = wave_sum(c1) * inv_n;
-    c2 = a.rms ? 0.f : wave_sum(c2) * inv_n;
+    c1 = row_sum<WPR>(c1, red, wave) * inv_n;
+    c2 = a.rms ? 0.f : row_sum<WPR>(c2, red, wave) * inv_n;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
-      if (col < a.cols) {
+      const int col = NORM_COL(c);
+      if (col < a.cols && rlive) {
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; i++) o[i] = (wdy[c][i] - xh[c][i] * c1 - c2) * rstd;
@@ -166,10 +195,11 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
       }
     }
   }
-  const int64_t part = (int64_t)blockIdx.x * NORM_WAVES + wave;
+  // one partial row per (block, wrow): waves of the same row write disjoint columns
+  const int64_t part = (int64_t)blockIdx.x * RPB + wrow;
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++) {
-    int col = (c * 64 + lane) * VEC;
+    const int col = NORM_COL(c);
     if (col < a.cols) {
 #pragma unroll
       for (int i = 0; i < VEC; i++) {
@@ -180,35 +210,44 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
   }
 }
 
-__global__ void reduce_parts_kernel(const float* part, int nparts, int cols, float* out) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
+// out[col] = sum_p part[p][col]; block = 64 columns x 4 part-groups, folded through LDS
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int nparts, int cols, float* out) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; p++) s += part[(int64_t)p * cols + col];
-  out[col] = s;
+  if (col < cols)
+    for (int p = pg; p < nparts; p += 4) s += part[(int64_t)p * cols + col];
+  sh[pg][cl] = s;
+  block_sync();
+  if (pg == 0 && col < cols) out[col] = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // gated RMSNorm.  norm_before_gate = 0 (reference): y = rmsnorm(x * silu(z)) * w ; 1: y = rmsnorm(x) * w * silu(z)
-// one wave per (row, group) segment of group_size = cols / ngroups lanes
+// a segment = (row, group) of group_size = cols / ngroups lanes; blocks are striped so a block stays in one group
 // ---------------------------------------------------------------------------------------------------------
-template <class TX, int VEC, int NCHUNK>
+template <class TX, int VEC, int NCHUNK, int WPR>
 __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  NORM_ROWMAP();
   const TX* x = (const TX*)a.x;
   const TX* z = (const TX*)a.z;
   TX* y = (TX*)a.y;
   const int gs = a.cols / a.ngroups;
   const float inv_n = 1.f / (float)gs;
-  const int64_t nseg = a.rows * a.ngroups;
-  for (int64_t seg = (int64_t)blockIdx.x * NORM_WAVES + wave; seg < nseg; seg += (int64_t)gridDim.x * NORM_WAVES) {
-    const int64_t row = seg / a.ngroups;
-    const int g0 = (int)(seg % a.ngroups) * gs;
+  const int grp = blockIdx.x % a.ngroups;
+  const int g0 = grp * gs;
+  const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  for (int64_t it = bi; it < niter; it += nbg) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    const int64_t row = rlive ? rraw : a.rows - 1;
     float v[NCHUNK][VEC], sz[NCHUNK][VEC];
     float s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
+      const int col = NORM_COL(c);
       if (col < gs) {
         ld<TX, VEC>(x + row * a.xs + g0 + col, v[c]);
         if (z) {
@@ -226,12 +265,12 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
         for (int i = 0; i < VEC; i++) { v[c][i] = 0.f; sz[c][i] = 0.f; }
       }
     }
-    float rstd = rsqrtf(wave_sum(s2) * inv_n + a.eps);
-    if (lane == 0 && a.rstd) a.rstd[seg] = rstd;
+    const float rstd = rsqrtf(row_sum<WPR>(s2, red, wave) * inv_n + a.eps);
+    if (lane == 0 && wsub == 0 && a.rstd && rlive) a.rstd[row * a.ngroups + grp] = rstd;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      int col = (c * 64 + lane) * VEC;
-      if (col < gs) {
+      const int col = NORM_COL(c);
+      if (col < gs && rlive) {
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
@@ -245,9 +284,9 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
   }
 }
 
-template <class TX, int VEC, int NCHUNK>
+template <class TX, int VEC, int NCHUNK, int WPR>
 __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArgs a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  NORM_ROWMAP();
   const TX* x = (const TX*)a.x;
   const TX* z = (const TX*)a.z;
   const TX* dy = (const TX*)a.dy;
@@ -255,98 +294,94 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
   TX* dz = (TX*)a.dz;
   const int gs = a.cols / a.ngroups;
   const float inv_n = 1.f / (float)gs;
-  const int64_t nseg = a.rows * a.ngroups;
-  const int my_g = -1;
-  (void)my_g;
-  // a wave may visit segments of different groups, so dw partials are indexed by absolute column through a
-  // per-wave accumulation buffer in registers only when ngroups == 1; otherwise accumulate per visited segment.
+  const int grp = blockIdx.x % a.ngroups;
+  const int g0 = grp * gs;
+  const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
   float dwacc[NCHUNK][VEC];
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
     for (int i = 0; i < VEC; i++) dwacc[c][i] = 0.f;
-  const int64_t part = (int64_t)blockIdx.x * NORM_WAVES + wave;
-  // iterate so that every wave stays inside ONE group: segment index = row * ngroups + grp, waves are striped over rows
-  const int grp = (int)(part % a.ngroups);
-  const int64_t wave_in_grp = part / a.ngroups, waves_per_grp = ((int64_t)gridDim.x * NORM_WAVES) / a.ngroups;
-  const int g0 = grp * gs;
-  if (wave_in_grp < waves_per_grp) {
-    for (int64_t row = wave_in_grp; row < a.rows; row += waves_per_grp) {
-      float xv[NCHUNK][VEC], zv[NCHUNK][VEC], gv[NCHUNK][VEC], wdy[NCHUNK][VEC];
-      float s2 = 0.f;
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  for (int64_t it = bi; it < niter; it += nbg) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    const int64_t row = rlive ? rraw : a.rows - 1;
+    // gv: the normalised quantity (x or x*silu(z)); zv: z, later (norm_before_gate) the finished dz; wdy: dy then w*dy'
+    float xv[NCHUNK][VEC], zv[NCHUNK][VEC], gv[NCHUNK][VEC], wdy[NCHUNK][VEC];
+    float s2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < NCHUNK; c++) {
-        int col = (c * 64 + lane) * VEC;
-        if (col < gs) {
-          ld<TX, VEC>(x + row * a.xs + g0 + col, xv[c]);
-          ld<TX, VEC>(dy + row * a.dys + g0 + col, wdy[c]);
-          if (z) ld<TX, VEC>(z + row * a.zs + g0 + col, zv[c]);
+    for (int c = 0; c < NCHUNK; c++) {
+      const int col = NORM_COL(c);
+      if (col < gs && rlive) {
+        ld<TX, VEC>(x + row * a.xs + g0 + col, xv[c]);
+        ld<TX, VEC>(dy + row * a.dys + g0 + col, wdy[c]);
+        if (z) ld<TX, VEC>(z + row * a.zs + g0 + col, zv[c]);
 #pragma unroll
-          for (int i = 0; i < VEC; i++) {
-            float sg = z ? silu_f(zv[c][i]) : 1.f;
-            gv[c][i] = (z && !a.norm_before_gate) ? xv[c][i] * sg : xv[c][i];   // what gets normalised
-            s2 += gv[c][i] * gv[c][i];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < VEC; i++) { xv[c][i] = 0.f; zv[c][i] = 0.f; gv[c][i] = 0.f; wdy[c][i] = 0.f; }
+        for (int i = 0; i < VEC; i++) {
+          if (!z) zv[c][i] = 0.f;
+          gv[c][i] = (z && !a.norm_before_gate) ? xv[c][i] * silu_f(zv[c][i]) : xv[c][i];
+          s2 += gv[c][i] * gv[c][i];
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { xv[c][i] = 0.f; zv[c][i] = 0.f; gv[c][i] = 0.f; wdy[c][i] = 0.f; }
       }
-      const float rstd = rsqrtf(wave_sum(s2) * inv_n + a.eps);
-      float c1 = 0.f;
+    }
+    const float rstd = rsqrtf(row_sum<WPR>(s2, red, wave) * inv_n + a.eps);
+    float c1 = 0.f;
 #pragma unroll
-      for (int c = 0; c < NCHUNK; c++) {
-        int col = (c * 64 + lane) * VEC;
-        if (col < gs) {
+    for (int c = 0; c < NCHUNK; c++) {
+      const int col = NORM_COL(c);
+      if (col < gs && rlive) {
 #pragma unroll
-          for (int i = 0; i < VEC; i++) {
-            float w = load_rt(a.w, g0 + col + i, a.wdt);
-            float dyv = wdy[c][i];
-            float xhat = gv[c][i] * rstd;
-            float sg = z ? silu_f(zv[c][i]) : 1.f;
-            if (z && a.norm_before_gate) {
-              // y = xhat*w*silu(z): dz uses dy*xhat*w, the norm sees dy*silu(z)
-              float sig = sigmoid_f(zv[c][i]);
-              zv[c][i] = dyv * xhat * w * sig * (1.f + zv[c][i] * (1.f - sig));   // final dz
-              dyv *= sg;
-            }
-            dwacc[c][i] += dyv * xhat;
-            wdy[c][i] = dyv * w;
-            c1 += xhat * wdy[c][i];
-            gv[c][i] = xhat;
+        for (int i = 0; i < VEC; i++) {
+          const float w = load_rt(a.w, g0 + col + i, a.wdt);
+          float dyv = wdy[c][i];
+          const float xhat = gv[c][i] * rstd;
+          if (z && a.norm_before_gate) {   // y = xhat*w*silu(z): dz from dy*xhat*w, the norm sees dy*silu(z)
+            const float sig = sigmoid_f(zv[c][i]);
+            const float sg = zv[c][i] * sig;
+            zv[c][i] = dyv * xhat * w * sig * (1.f + zv[c][i] * (1.f - sig));   // finished dz
+            dyv *= sg;
           }
-        }
-      }
-      c1 = wave_sum(c1) * inv_n;
-#pragma unroll
-      for (int c = 0; c < NCHUNK; c++) {
-        int col = (c * 64 + lane) * VEC;
-        if (col < gs) {
-          float ox[VEC], oz[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; i++) {
-            float dg = (wdy[c][i] - gv[c][i] * c1) * rstd;   // grad wrt the normalised input
-            if (z && !a.norm_before_gate) {
-              float sig = sigmoid_f(zv[c][i]);
-              ox[i] = dg * zv[c][i] * sig;
-              oz[i] = dg * xv[c][i] * sig * (1.f + zv[c][i] * (1.f - sig));
-            } else {
-              ox[i] = dg;
-              oz[i] = zv[c][i];
-            }
-          }
-          st<TX, VEC>(dx + row * a.dxs + g0 + col, ox);
-          if (dz) st<TX, VEC>(dz + row * a.dzs + g0 + col, oz);
+          dwacc[c][i] += dyv * xhat;
+          wdy[c][i] = dyv * w;
+          c1 += xhat * wdy[c][i];
+          gv[c][i] = xhat;
         }
       }
     }
+    c1 = row_sum<WPR>(c1, red, wave) * inv_n;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      const int col = NORM_COL(c);
+      if (col < gs && rlive) {
+        float ox[VEC], oz[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          const float dg = (wdy[c][i] - gv[c][i] * c1) * rstd;   // grad wrt the normalised input
+          if (z && !a.norm_before_gate) {
+            const float sig = sigmoid_f(zv[c][i]);
+            ox[i] = dg * zv[c][i] * sig;
+            oz[i] = dg * xv[c][i] * sig * (1.f + zv[c][i] * (1.f - sig));
+          } else {
+            ox[i] = dg;
+            oz[i] = zv[c][i];
+          }
+        }
+        st<TX, VEC>(dx + row * a.dxs + g0 + col, ox);
+        if (dz) st<TX, VEC>(dz + row * a.dzs + g0 + col, oz);
+      }
+    }
   }
+  const int64_t part = bi * RPB + wrow;   // partial rows of this group
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++) {
-    int col = (c * 64 + lane) * VEC;
-    if (col < gs && wave_in_grp < waves_per_grp) {
+    const int col = NORM_COL(c);
+    if (col < gs) {
 #pragma unroll
-      for (int i = 0; i < VEC; i++) a.dw_part[wave_in_grp * a.cols + g0 + col + i] = dwacc[c][i];
+      for (int i = 0; i < VEC; i++) a.dw_part[part * a.cols + g0 + col + i] = dwacc[c][i];
     }
   }
 }
@@ -354,27 +389,39 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static int norm_grid(int64_t nseg) {
-  int64_t g = (nseg + NORM_WAVES - 1) / NORM_WAVES;
-  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
-}
-
-struct VecPlan { int vec, nchunk; };
-// VEC=8 needs 16-byte aligned rows; segment length must fit NCHUNK*64*VEC
+struct VecPlan { int vec, nchunk, wpr; };
+// VEC=8 needs 16-byte aligned rows; a segment must fit WPR * NCHUNK * 64 * VEC
 static bool plan_vec(int64_t seglen, bool can8, VecPlan* out) {
   if (can8 && seglen % 8 == 0) {
-    if (seglen <= 4 * 64 * 8) { *out = {8, 4}; return true; }
-    if (seglen <= 16 * 64 * 8) { *out = {8, 16}; return true; }
+    if (seglen <= 1 * 4 * 64 * 8) { *out = {8, 4, 1}; return true; }     // <= 2048
+    if (seglen <= 4 * 4 * 64 * 8) { *out = {8, 4, 4}; return true; }     // <= 8192
   }
-  if (seglen <= 32 * 64) { *out = {1, 32}; return true; }
+  if (seglen <= 4 * 32 * 64) { *out = {1, 32, 4}; return true; }         // <= 8192, any alignment
   return false;
+}
+static int norm_blocks(int64_t rows, int ngroups, const VecPlan& pl) {
+  const int rpb = NORM_WAVES / pl.wpr;
+  int64_t per_group = (rows + rpb - 1) / rpb;
+  int64_t cap = NORM_MAX_BLOCKS / ngroups;
+  if (cap < 1) cap = 1;
+  if (per_group > cap) per_group = cap;
+  if (per_group < 1) per_group = 1;
+  return (int)(per_group * ngroups);
+}
+static int norm_parts(int64_t rows, int ngroups, const VecPlan& pl) {   // partial dw rows per group
+  return (norm_blocks(rows, ngroups, pl) / ngroups) * (NORM_WAVES / pl.wpr);
 }
 static bool rows_ok8(const OmkTensor& t) { return !present(t) || (aligned16(t) && t.stride[1] == 1 && t.stride[0] % 8 == 0); }
 
-#define OMK_PLAN_SWITCH(plan, ...)                                                 \
-  if (plan.vec == 8 && plan.nchunk == 4) { constexpr int VEC = 8, NCHUNK = 4; __VA_ARGS__; }        \
-  else if (plan.vec == 8 && plan.nchunk == 16) { constexpr int VEC = 8, NCHUNK = 16; __VA_ARGS__; } \
-  else { constexpr int VEC = 1, NCHUNK = 32; __VA_ARGS__; }
+#define OMK_PLAN_SWITCH(plan, ...)                                                                                   \
+  if (plan.vec == 8 && plan.wpr == 1) { constexpr int VEC = 8, NCHUNK = 4, WPR = 1; __VA_ARGS__; }                   \
+  else if (plan.vec == 8) { constexpr int VEC = 8, NCHUNK = 4, WPR = 4; __VA_ARGS__; }                               \
+  else { constexpr int VEC = 1, NCHUNK = 32, WPR = 4; __VA_ARGS__; }
+
+static void launch_reduce(const float* part, int nparts, int64_t cols, float* out, omk_stream stream) {
+  dim3 rg((unsigned)((cols + 63) / 64)), rb(256);
+  OMK_LAUNCH(reduce_parts_kernel, rg, rb, 0, stream, part, nparts, (int)cols, out);
+}
 
 }  // namespace omk
 
@@ -404,8 +451,8 @@ extern "C" int omk_add_norm_fwd(const OmkAddNormFwd* p, omk_stream stream) {
   a.xs = p->x.stride[0]; a.rs = present(p->residual) ? p->residual.stride[0] : 0; a.ys = p->y.stride[0];
   a.ros = present(p->residual_out) ? p->residual_out.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = 1; a.wdt = p->weight.dtype; a.bdt = p->bias.dtype; a.eps = p->eps; a.rms = p->is_rms_norm;
-  dim3 grid(norm_grid(rows)), block(NORM_THREADS);
-#define LAUNCH_ADD(TX, TR, TRO) OMK_PLAN_SWITCH(plan, OMK_LAUNCH((add_norm_fwd_kernel<TX, TR, TRO, VEC, NCHUNK>), grid, block, 0, stream, a))
+  dim3 grid(norm_blocks(rows, 1, plan)), block(NORM_THREADS);
+#define LAUNCH_ADD(TX, TR, TRO) OMK_PLAN_SWITCH(plan, OMK_LAUNCH((add_norm_fwd_kernel<TX, TR, TRO, VEC, NCHUNK, WPR>), grid, block, 0, stream, a))
   OMK_DISPATCH_DTYPE(xdt, TX, {
     if (rdt == xdt && rodt == xdt) { LAUNCH_ADD(TX, TX, TX); }
     else if (rdt == xdt) { LAUNCH_ADD(TX, TX, float); }
@@ -416,11 +463,16 @@ extern "C" int omk_add_norm_fwd(const OmkAddNormFwd* p, omk_stream stream) {
   return finish_launch("add_norm_fwd");
 }
 
-static int add_norm_bwd_parts(int64_t rows) { return norm_grid(rows) * NORM_WAVES; }
+static bool add_bwd_plan(const OmkAddNormBwd* p, VecPlan* plan) {
+  bool can8 = rows_ok8(p->dy) && rows_ok8(p->xsum) && rows_ok8(p->dx) && rows_ok8(p->dresidual_out) && rows_ok8(p->dresidual_in);
+  return plan_vec(p->dy.shape[1], can8, plan);
+}
 
 extern "C" size_t omk_add_norm_bwd_workspace_bytes(const OmkAddNormBwd* p) {
   if (!p) return 0;
-  return (size_t)add_norm_bwd_parts(p->dy.shape[0]) * p->dy.shape[1] * 4 * 2;
+  VecPlan plan;
+  if (!add_bwd_plan(p, &plan)) return 0;
+  return (size_t)norm_parts(p->dy.shape[0], 1, plan) * p->dy.shape[1] * 4 * 2;
 }
 
 extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
@@ -430,13 +482,12 @@ extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
   OMK_REQUIRE(p->dx.dtype == p->dy.dtype, "add_norm_bwd: dx dtype must equal dy dtype");
   OMK_REQUIRE(!present(p->dresidual_out) || p->dresidual_out.dtype == p->xsum.dtype, "add_norm_bwd: dresidual_out dtype must equal xsum dtype");
   OMK_REQUIRE(p->xsum.dtype == p->dy.dtype || p->xsum.dtype == OMK_F32, "add_norm_bwd: xsum dtype");
-  OMK_REQUIRE(p->workspace_bytes >= omk_add_norm_bwd_workspace_bytes(p) && p->workspace, "add_norm_bwd: workspace too small");
   OMK_REQUIRE(p->dweight.dtype == OMK_F32, "add_norm_bwd: dweight must be f32");
   if (rows == 0) return OMK_OK;
   VecPlan plan;
-  bool can8 = rows_ok8(p->dy) && rows_ok8(p->xsum) && rows_ok8(p->dx) && rows_ok8(p->dresidual_out) && rows_ok8(p->dresidual_in);
-  if (!plan_vec(cols, can8, &plan)) return fail(OMK_EUNSUPPORTED, "add_norm_bwd: cols too large");
-  const int nparts = add_norm_bwd_parts(rows);
+  if (!add_bwd_plan(p, &plan)) return fail(OMK_EUNSUPPORTED, "add_norm_bwd: cols too large");
+  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_add_norm_bwd_workspace_bytes(p), "add_norm_bwd: workspace too small");
+  const int nparts = norm_parts(rows, 1, plan);
   NormBwdArgs a = {};
   a.dy = p->dy.data; a.dro = p->dresidual_out.data; a.xsum = p->xsum.data; a.w = p->weight.data;
   a.rstd = (const float*)p->rstd.data; a.mean = p->is_rms_norm ? nullptr : (const float*)p->mean.data;
@@ -448,8 +499,8 @@ extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
   const int xdt = p->dy.dtype, sdt = p->xsum.dtype;
   const int ridt = present(p->dresidual_in) ? p->dresidual_in.dtype : xdt;
   OMK_REQUIRE(ridt == xdt || ridt == OMK_F32, "add_norm_bwd: dresidual_in dtype");
-  dim3 grid(norm_grid(rows)), block(NORM_THREADS);
-#define LAUNCH_B(TX, TS, TRI) OMK_PLAN_SWITCH(plan, OMK_LAUNCH((add_norm_bwd_kernel<TX, TS, TRI, VEC, NCHUNK>), grid, block, 0, stream, a))
+  dim3 grid(norm_blocks(rows, 1, plan)), block(NORM_THREADS);
+#define LAUNCH_B(TX, TS, TRI) OMK_PLAN_SWITCH(plan, OMK_LAUNCH((add_norm_bwd_kernel<TX, TS, TRI, VEC, NCHUNK, WPR>), grid, block, 0, stream, a))
   OMK_DISPATCH_DTYPE(xdt, TX, {
     if (sdt == xdt && ridt == xdt) { LAUNCH_B(TX, TX, TX); }
     else if (sdt == xdt) { LAUNCH_B(TX, TX, float); }
@@ -457,10 +508,8 @@ extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
     else { LAUNCH_B(TX, float, float); }
   });
 #undef LAUNCH_B
-  dim3 rg((unsigned)((cols + 255) / 256)), rb(256);
-  OMK_LAUNCH(reduce_parts_kernel, rg, rb, 0, stream, (const float*)a.dw_part, nparts, (int)cols, (float*)p->dweight.data);
-  if (p->has_bias && present(p->dbias))
-    OMK_LAUNCH(reduce_parts_kernel, rg, rb, 0, stream, (const float*)a.db_part, nparts, (int)cols, (float*)p->dbias.data);
+  launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
+  if (p->has_bias && present(p->dbias)) launch_reduce(a.db_part, nparts, cols, (float*)p->dbias.data, stream);
   return finish_launch("add_norm_bwd");
 }
 
@@ -480,52 +529,46 @@ extern "C" int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream) {
   a.xs = p->x.stride[0]; a.zs = present(p->z) ? p->z.stride[0] : 0; a.ys = p->y.stride[0];
   a.rows = rows; a.cols = (int)cols; a.ngroups = (int)(cols / gs); a.wdt = p->weight.dtype; a.bdt = p->bias.dtype; a.eps = p->eps;
   a.rms = 1; a.norm_before_gate = p->norm_before_gate;
-  dim3 grid(norm_grid(rows * a.ngroups)), block(NORM_THREADS);
-  OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_fwd_kernel<TX, VEC, NCHUNK>), grid, block, 0, stream, a)));
+  dim3 grid(norm_blocks(rows, a.ngroups, plan)), block(NORM_THREADS);
+  OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_fwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
   return finish_launch("norm_gated_fwd");
 }
 
-static int gated_bwd_grid(int64_t rows, int ngroups) {
-  int g = norm_grid(rows * ngroups);
-  int waves = g * NORM_WAVES;
-  waves = ((waves + ngroups - 1) / ngroups) * ngroups;   // multiple of ngroups so every wave stays in one group
-  return (waves + NORM_WAVES - 1) / NORM_WAVES;
+static bool gated_bwd_plan(const OmkNormGatedBwd* p, VecPlan* plan, int* ng) {
+  const int64_t cols = p->x.shape[1];
+  const int64_t gs = p->group_size > 0 ? p->group_size : cols;
+  if (gs <= 0 || cols % gs) return false;
+  *ng = (int)(cols / gs);
+  bool can8 = rows_ok8(p->x) && rows_ok8(p->dy) && rows_ok8(p->z) && rows_ok8(p->dx) && rows_ok8(p->dz) && gs % 8 == 0;
+  return plan_vec(gs, can8, plan);
 }
 
 extern "C" size_t omk_norm_gated_bwd_workspace_bytes(const OmkNormGatedBwd* p) {
   if (!p) return 0;
-  const int64_t cols = p->x.shape[1];
-  const int64_t gs = p->group_size > 0 ? p->group_size : cols;
-  int ng = (int)(cols / gs);
-  int64_t waves = (int64_t)gated_bwd_grid(p->x.shape[0], ng) * NORM_WAVES;
-  return (size_t)(waves / ng + 1) * cols * 4;
+  VecPlan plan; int ng;
+  if (!gated_bwd_plan(p, &plan, &ng)) return 0;
+  return (size_t)norm_parts(p->x.shape[0], ng, plan) * p->x.shape[1] * 4;
 }
 
 extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
   OMK_REQUIRE(p && present(p->dy) && present(p->x) && present(p->weight) && present(p->dx) && present(p->dweight), "norm_gated_bwd: dy, x, weight, dx, dweight required");
   const int64_t rows = p->x.shape[0], cols = p->x.shape[1];
-  const int64_t gs = p->group_size > 0 ? p->group_size : cols;
-  OMK_REQUIRE(cols % gs == 0, "norm_gated_bwd: group_size must divide cols");
-  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_norm_gated_bwd_workspace_bytes(p), "norm_gated_bwd: workspace too small");
   OMK_REQUIRE(p->dweight.dtype == OMK_F32, "norm_gated_bwd: dweight must be f32");
   OMK_REQUIRE(p->dy.dtype == p->x.dtype && p->dx.dtype == p->x.dtype, "norm_gated_bwd: dtype mismatch");
   if (present(p->z)) OMK_REQUIRE(present(p->dz) && p->z.dtype == p->x.dtype && p->dz.dtype == p->x.dtype, "norm_gated_bwd: z/dz");
   if (rows == 0) return OMK_OK;
-  VecPlan plan;
-  bool can8 = rows_ok8(p->x) && rows_ok8(p->dy) && rows_ok8(p->z) && rows_ok8(p->dx) && rows_ok8(p->dz) && gs % 8 == 0;
-  if (!plan_vec(gs, can8, &plan)) return fail(OMK_EUNSUPPORTED, "norm_gated_bwd: group too large");
-  const int ng = (int)(cols / gs);
-  const int gridx = gated_bwd_grid(rows, ng);
-  const int nparts = gridx * NORM_WAVES / ng;
+  VecPlan plan; int ng;
+  if (!gated_bwd_plan(p, &plan, &ng)) return fail(OMK_EUNSUPPORTED, "norm_gated_bwd: unsupported group size");
+  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_norm_gated_bwd_workspace_bytes(p), "norm_gated_bwd: workspace too small");
+  const int nparts = norm_parts(rows, ng, plan);
   NormBwdArgs a = {};
   a.dy = p->dy.data; a.x = p->x.data; a.z = p->z.data; a.w = p->weight.data; a.dx = p->dx.data; a.dz = p->dz.data;
   a.dw_part = (float*)p->workspace;
   a.dys = p->dy.stride[0]; a.xs = p->x.stride[0]; a.zs = present(p->z) ? p->z.stride[0] : 0; a.dxs = p->dx.stride[0];
   a.dzs = present(p->dz) ? p->dz.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = ng; a.wdt = p->weight.dtype; a.rms = 1; a.eps = p->eps; a.norm_before_gate = p->norm_before_gate;
-  dim3 grid(gridx), block(NORM_THREADS);
-  OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_bwd_kernel<TX, VEC, NCHUNK>), grid, block, 0, stream, a)));
-  dim3 rg((unsigned)((cols + 255) / 256)), rb(256);
-  OMK_LAUNCH(reduce_parts_kernel, rg, rb, 0, stream, (const float*)a.dw_part, nparts, (int)cols, (float*)p->dweight.data);
+  dim3 grid(norm_blocks(rows, ng, plan)), block(NORM_THREADS);
+  OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_bwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
+  launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
   return finish_launch("norm_gated_bwd");
 }

@@ -346,10 +346,30 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
     block_sync();   // B4
   }
   if (MODE == GS_DX && a.dD) {
+    // fold the per-thread partials inside the workgroup first: same-address fp32 atomics from 512 threads x 256
+    // workgroups serialise at the memory side (measured: 12.6 ms of a 13.1 ms launch) -- one atomic per column instead
+    float* redw = sm.G;   // [8 waves][2 heads][64 cols]   (tiles are dead after the last chunk's B4)
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
-      for (int e = 0; e < 8; e++) atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)((tid & 7) * 8 + e) * a.dDsp, dDp[r][e]);
+      for (int e = 0; e < 8; e++) {
+        float v = dDp[r][e];
+        v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);   // lanes sharing (tid & 7) = same 8 columns
+        if (lane < 8) redw[(wave * 2 + r) * 64 + lane * 8 + e] = v;
+      }
+    block_sync();
+    if (tid < 128) {
+      const int r = tid >> 6, col = tid & 63;
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; w8++) v += redw[(w8 * 2 + r) * 64 + col];
+      if (a.dDsp == 0) {           // D is (H): one value per head
+        v = wave_sum(v);
+        if (col == 0) atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh, v);
+      } else {
+        atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)col * a.dDsp, v);
+      }
+    }
   }
   if (a.fin) {
     const float extra = a.fin_extra_decay ? expf(a.dtp[((int64_t)b * a.H + hcur) * a.L] * Ah) : 1.f;

@@ -10,7 +10,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cols,has_res,res32,rms", [(64, True, True, True), (520, True, False, True), (48, False, True, True),
+@pytest.mark.parametrize("cols,has_res,res32,rms", [(64, True, True, True), (520, True, False, True), (48, False, True, True), (2560, True, True, True),
                                                     (100, True, True, False), (37, False, False, True)])
 def test_add_norm_fwd_bwd(dev, dtype, cols, has_res, res32, rms):
     from omnimamba_amd.layer_norm import layer_norm_fn
@@ -49,7 +49,8 @@ def test_add_norm_fwd_bwd(dev, dtype, cols, has_res, res32, rms):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cols,gs,nbg,has_z", [(64, None, False, True), (128, 32, False, True), (96, 48, True, True), (40, None, False, False)])
+@pytest.mark.parametrize("cols,gs,nbg,has_z", [(64, None, False, True), (128, 32, False, True), (96, 48, True, True), (40, None, False, False),
+                                               (4096, None, False, True), (4608, 2304, False, True)])
 def test_norm_gated(dev, dtype, cols, gs, nbg, has_z):
     from omnimamba_amd.layernorm_gated import rmsnorm_fn
     torch.manual_seed(1)
