@@ -66,6 +66,15 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) 
   TX* y = (TX*)a.y;
   TRO* ro = (TRO*)a.ro;
   const float inv_n = 1.f / (float)a.cols;
+  float wreg[NCHUNK][VEC], breg[NCHUNK][VEC];   // this lane's columns never change: weights live in registers
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      const int col = NORM_COL(c) + i;
+      wreg[c][i] = col < a.cols ? load_rt(a.w, col, a.wdt) : 0.f;
+      breg[c][i] = (a.b && col < a.cols) ? load_rt(a.b, col, a.bdt) : 0.f;
+    }
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
     const int64_t rraw = it * RPB + wrow;
@@ -119,8 +128,7 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) 
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-          o[i] = (v[c][i] - mu) * rstd * load_rt(a.w, col + i, a.wdt);
-          if (a.b) o[i] += load_rt(a.b, col + i, a.bdt);
+          o[i] = (v[c][i] - mu) * rstd * wreg[c][i] + breg[c][i];
         }
         st<TX, VEC>(y + row * a.ys + col, o);
       }
@@ -140,6 +148,11 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
   TX* dx = (TX*)a.dx;
   TRI* dri = (TRI*)a.dri;
   const float inv_n = 1.f / (float)a.cols;
+  float wreg[NCHUNK][VEC];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { const int col = NORM_COL(c) + i; wreg[c][i] = col < a.cols ? load_rt(a.w, col, a.wdt) : 0.f; }
   float dwacc[NCHUNK][VEC], dbacc[NCHUNK][VEC];
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++)
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
           xh[c][i] = (xh[c][i] - mu) * rstd;
-          wdy[c][i] = g[i] * load_rt(a.w, col + i, a.wdt);
+          wdy[c][i] = g[i] * wreg[c][i];
           dwacc[c][i] += g[i] * xh[c][i];
           dbacc[c][i] += g[i];
           c1 += xh[c][i] * wdy[c][i];
@@ -238,6 +251,15 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
   const int grp = blockIdx.x % a.ngroups;
   const int g0 = grp * gs;
   const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
+  float wreg[NCHUNK][VEC], breg[NCHUNK][VEC];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      const int col = NORM_COL(c) + i;
+      wreg[c][i] = col < gs ? load_rt(a.w, g0 + col, a.wdt) : 0.f;
+      breg[c][i] = (a.b && col < gs) ? load_rt(a.b, g0 + col, a.bdt) : 0.f;
+    }
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   for (int64_t it = bi; it < niter; it += nbg) {
     const int64_t rraw = it * RPB + wrow;
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
           ld<TX, VEC>(z + row * a.zs + g0 + col, sz[c]);
 #pragma unroll
           for (int i = 0; i < VEC; i++) {
-            sz[c][i] = silu_f(sz[c][i]);
+            sz[c][i] = silu_fast(sz[c][i]);
             if (!a.norm_before_gate) v[c][i] *= sz[c][i];
           }
         }
@@ -274,8 +296,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-          o[i] = v[c][i] * rstd * load_rt(a.w, g0 + col + i, a.wdt);
-          if (a.b) o[i] += load_rt(a.b, g0 + col + i, a.bdt);
+          o[i] = v[c][i] * rstd * wreg[c][i] + breg[c][i];
           if (z && a.norm_before_gate) o[i] *= sz[c][i];
         }
         st<TX, VEC>(y + row * a.ys + g0 + col, o);
@@ -297,11 +318,15 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
   const int grp = blockIdx.x % a.ngroups;
   const int g0 = grp * gs;
   const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
-  float dwacc[NCHUNK][VEC];
+  float dwacc[NCHUNK][VEC], wreg[NCHUNK][VEC];
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
-    for (int i = 0; i < VEC; i++) dwacc[c][i] = 0.f;
+    for (int i = 0; i < VEC; i++) {
+      dwacc[c][i] = 0.f;
+      const int col = NORM_COL(c) + i;
+      wreg[c][i] = col < gs ? load_rt(a.w, g0 + col, a.wdt) : 0.f;
+    }
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   for (int64_t it = bi; it < niter; it += nbg) {
     const int64_t rraw = it * RPB + wrow;
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
       if (col < gs && rlive) {
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-          const float w = load_rt(a.w, g0 + col + i, a.wdt);
+          const float w = wreg[c][i];
           float dyv = wdy[c][i];
           const float xhat = gv[c][i] * rstd;
           if (z && a.norm_before_gate) {   // y = xhat*w*silu(z): dz from dy*xhat*w, the norm sees dy*silu(z)
