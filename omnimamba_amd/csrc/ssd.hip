@@ -202,6 +202,7 @@ struct FinishArgs {
   const float* dfin; int64_t dfsb, dfsh, dfsp, dfsn; const float* sfin;   // sfin: (B, H, N, P) contiguous f32 from the dC scan
   void* ddt; int64_t dsb, dsl, dsh; int ddt_dt;
   float* dA; float* ddtb;
+  const float* bnd;   // optional (B, H, nT + 1): exact value of dl at the first token of tile ti + 1 (MFMA path)
   int B, H, L, P, N;
 };
 __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
@@ -220,6 +221,8 @@ __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   float dAacc = 0.f, dbacc = 0.f;
   const int nT = (a.L + 63) / 64;
   for (int ti = nT - 1; ti >= 0; ti--) {
+    // bf16-level errors in e / w must not accumulate over the whole sequence: restart from the exact boundary value
+    if (a.bnd) carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1];
     const int t = ti * 64 + lane;
     const bool ok = t < a.L;
     const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
@@ -338,7 +341,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   return finish_launch("ssd_scan_fwd");
 }
 
-struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part; size_t total; };
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd; size_t total; };
 static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, bool need_part) {
   BwdWs w; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
@@ -346,6 +349,9 @@ static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N,
   w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl); w.dB32 = take(blgn); w.dC32 = take(blgn);
   w.sfin = need_sfin ? take((size_t)B * H * P * N * 4) : nullptr;
   w.part = need_part ? take((size_t)B * (H / 2) * L * 128 * 4) : nullptr;
+  const size_t nC = (size_t)(L + 63) / 64;
+  w.ckpt = need_part ? take((size_t)B * (H / 2) * nC * (8 * 2 * 8 * 64) * 4) : nullptr;
+  w.bnd = need_part ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
   w.total = off;
   return w;
 }
@@ -367,7 +373,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isk = p->initial_states.stride[2]; g.isu = p->initial_states.stride[3];
     }
     if (has_dfin) { g.fin = w.sfin; g.fsb = (int64_t)d.H * d.N * d.P; g.fsh = (int64_t)d.N * d.P; g.fsu = d.P; g.fsk = 1; }
-    if (mfma) g.part = w.part; else { g.acc32 = w.dC32; g.tokscal = w.e; }
+    if (mfma) { g.part = w.part; g.tokscal = w.e; g.ckpt = w.ckpt; } else { g.acc32 = w.dC32; g.tokscal = w.e; }
     *gdc = g;
   }
   {  // dx: state [p][n], reverse in time
@@ -384,10 +390,6 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
     }
     g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
     if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
-    if (mfma) {
-      g.XE = make_src(p->x, false); g.YE = make_src(p->y, false); g.esum = w.e; g.wsum = w.wsum;
-      if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
-    }
     *gdx = g;
   }
   {  // dB: state [n][p], reverse in time
@@ -398,17 +400,15 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
       g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isk = p->dfinal_states.stride[2]; g.isu = p->dfinal_states.stride[3];
     }
-    if (mfma) g.part = w.part;
-    else {
-      g.acc32 = w.dB32; g.tokscal = w.wsum;
-      if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
-    }
+    if (mfma) { g.part = w.part; g.tokscal = w.wsum; g.ckpt = w.ckpt; g.bnd = w.bnd; }
+    else { g.acc32 = w.dB32; g.tokscal = w.wsum; }
+    if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
     *gdb = g;
   }
 }
 
 static bool bwd_mfma_applies(const OmkSsdBwd* p, const SsdDims& d) {
-  if (p->force_generic || !present(p->y) || p->y.dtype != p->x.dtype || p->y.ndim != 4 || p->y.stride[3] != 1) return false;
+  if (p->force_generic) return false;
   if (p->dB.dtype != OMK_BF16 && p->dB.dtype != OMK_F32 && p->dB.dtype != OMK_F16) return false;
   BwdWs w = {};
   GScan gdc, gdx, gdb;
@@ -452,11 +452,11 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   GScan gdc, gdx, gdb;
   bwd_scans(p, d, w, mfma, &gdc, &gdx, &gdb);
   if (mfma) {
-    if ((rc = ssd_mfma_launch(gdx, stream))) return rc;
-    if ((rc = ssd_mfma_launch(gdc, stream))) return rc;
+    if ((rc = ssd_mfma_launch(gdc, stream))) return rc;   // forward in time: e_t, state checkpoints, dC partials
     ssd_reduce_partials(w.part, p->dC.data, p->dC.stride[0], p->dC.stride[1], p->dC.stride[2], p->dC.dtype, d.B, d.L, d.G, d.H, stream);
     if ((rc = ssd_mfma_launch(gdb, stream))) return rc;
     ssd_reduce_partials(w.part, p->dB.data, p->dB.stride[0], p->dB.stride[1], p->dB.stride[2], p->dB.dtype, d.B, d.L, d.G, d.H, stream);
+    if ((rc = ssd_mfma_launch(gdx, stream))) return rc;
   } else {
     if ((rc = ssd_generic_launch(gdc, stream))) return rc;
     if ((rc = ssd_generic_launch(gdx, stream))) return rc;
@@ -465,11 +465,12 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   {
     FinishArgs f = {};
     f.e = w.e; f.wsum = w.wsum; f.dtp = w.dtp; f.dsoft = w.dsoft; f.A = A;
-    if (has_dfin) {
+    if (has_dfin && !mfma) {
       f.dfin = (const float*)p->dfinal_states.data; f.sfin = w.sfin;
       f.dfsb = p->dfinal_states.stride[0]; f.dfsh = p->dfinal_states.stride[1]; f.dfsp = p->dfinal_states.stride[2]; f.dfsn = p->dfinal_states.stride[3];
     }
     f.ddt = p->ddt.data; f.dsb = p->ddt.stride[0]; f.dsl = p->ddt.stride[1]; f.dsh = p->ddt.stride[2]; f.ddt_dt = p->ddt.dtype;
+    f.bnd = mfma ? w.bnd : nullptr;
     f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
     dim3 grid((unsigned)(d.B * d.H)), block(64);
     OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);

@@ -399,8 +399,11 @@ struct SmemB {
     float O[QC * 132];          // summed output tile, written after barrier B2
   };
   uint16_t S[2][128 * LDU];     // [u][k] bf16 copy of S_in
+  uint16_t X4[QC * LDK];        // C (dC scan) / B (dB scan) rows for the per-token scalar e_l / w_l = X4_l . O_l
   float cs[2][QC], ecs[2][QC], w[2][QC], ws[2][QC];
   float dtl[2][2][QC];
+  float rdot[2][2][QC];         // [wj][head][row] partial row dots
+  float bred[8];                // boundary dot partials (one per wave)
 };
 
 template <int MODE>
@@ -421,8 +424,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
     return rev ? id * QC + (QC - 1) - row : id * QC + row;
   };
   // staging: U (64 x 128) two segments per thread; K, Q (2 heads x 64 x 64) one segment per thread per head
-  u32x4 ruu[2], rk[2], rq[2];
+  u32x4 ruu[2], rk[2], rq[2], rx4[2];
+  float dDp[2][8] = {{0.f}};
   float rdt = 0.f;
+  const bool has_x4 = a.X4.p != nullptr && a.tokscal != nullptr;
+  const uint16_t* X4g = has_x4 ? (const uint16_t*)a.X4.p + (int64_t)b * a.X4.sb + (int64_t)g * a.X4.sh : nullptr;
   const uint16_t* Ug = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)g * a.U.sh;
   const uint16_t* Kg = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb;
   const uint16_t* Qg = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb;
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
       const int t = tok(c, row);
       const bool ok = c < nC && t < a.L;
       ruu[r] = ok ? ld16(Ug + (int64_t)t * a.U.sl + cs8) : u32x4{0, 0, 0, 0};
+      rx4[r] = (ok && has_x4) ? ld16(X4g + (int64_t)t * a.X4.sl + cs8) : u32x4{0, 0, 0, 0};
       const int tu = tok(c, tid >> 3), cu8 = (tid & 7) * 8;
       const bool oku = c < nC && tu < a.L;
       rk[r] = oku ? ld16(Kg + (int64_t)tu * a.K.sl + (int64_t)(h0 + r) * a.K.sh + cu8) : u32x4{0, 0, 0, 0};
@@ -449,6 +456,12 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
     for (int r = 0; r < 2; r++) {
       const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
       st16(&sm.U[row * LDK + cs8], ruu[r]);
+      if (has_x4) st16(&sm.X4[row * LDK + cs8], rx4[r]);
+      if (MODE == GS_DB && a.dD) {   // dD += dy . x over this thread's (head r, 8 columns): K = dy, Q = x
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          dDp[r][e] += ((e & 1) ? bf_hi(rk[r][e >> 1]) : bf_lo(rk[r][e >> 1])) * ((e & 1) ? bf_hi(rq[r][e >> 1]) : bf_lo(rq[r][e >> 1]));
+      }
       st16(&sm.K[r][(tid >> 3) * LDU + (tid & 7) * 8], rk[r]);
       st16(&sm.Qm[r][(tid >> 3) * LDU + (tid & 7) * 8], rq[r]);
     }
@@ -486,9 +499,27 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
   publish_state();
   block_sync();
   float* part = a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
+  // state checkpoints in fragment order: [b][pair][chunk][wave][ut][reg/2][lane] packed bf16 pairs (u32)
+  uint32_t* ck = a.ckpt ? (uint32_t*)a.ckpt + ((int64_t)b * pairs + hp) * (int64_t)nC * (8 * 2 * 8 * 64) : nullptr;
 
   for (int c = 0; c < nC; c++) {
     prefetch(c + 1);
+    if (MODE == GS_DB && ck && a.bnd) {
+      // exact restart value of the decay-gradient prefix at the boundary behind chunk `id`:
+      //   bnd[id + 1] = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan checkpoint of chunk id) >
+      const int id = nC - 1 - c;
+      const uint32_t* cp = ck + (int64_t)id * (8 * 2 * 8 * 64) + wave * (2 * 8 * 64);
+      float dot = 0.f;
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r2 = 0; r2 < 8; r2++) {
+          const uint32_t v = cp[(ut * 8 + r2) * 64 + lane];
+          dot += accS[ut][2 * r2] * bf_lo(v) + accS[ut][2 * r2 + 1] * bf_hi(v);
+        }
+      dot = wave_sum(dot);
+      if (lane == 0) sm.bred[wave] = dot;
+    }
     if ((wave & 3) == 0) {
       const int t = tok(c, lane);
       const bool ok = t < a.L;
@@ -523,6 +554,12 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
       *reinterpret_cast<f32x4*>(&sm.G[hh][(16 * tb + t16) * LDG + 16 * ta + 4 * g16]) = acc;
     }
     block_sync();   // B1
+    if (MODE == GS_DB && ck && a.bnd && tid < 2) {
+      const int id = nC - 1 - c, hd = h0 + tid;
+      const int tnext = (id + 1) * QC;
+      const float ex = tnext < a.L ? expf(a.dtp[((int64_t)b * a.H + hd) * a.L + tnext] * a.A[hd]) : 1.f;
+      a.bnd[((int64_t)b * a.H + hd) * (nC + 1) + id + 1] = ex * (sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3]);
+    }
     f32x16 accD[2], accO[2];
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
@@ -592,8 +629,33 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
         }
       }
     }
+    if (has_x4) {
+      // per-token scalar of THIS head: sum_n X4[l][n] * O_h[l][n] over this wave's 64 columns, folded over the 32 lanes
+      // of each half; the two column halves (wj) meet in LDS.  (X4 is read before B2: commit() rewrites it after B4.)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+        float pv = 0.f;
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++)
+          pv += bf16_to_f32(sm.X4[l * LDK + 64 * wj + 32 * ut + l31]) * (accD[ut][r] + sm.ecs[hh][l] * accO[ut][r]);
+        pv += shfl_xor(pv, 1); pv += shfl_xor(pv, 2); pv += shfl_xor(pv, 4); pv += shfl_xor(pv, 8); pv += shfl_xor(pv, 16);
+        if (l31 == 0) sm.rdot[wj][hh][l] = pv;
+      }
+    }
     block_sync();   // B2: G, S_in and the tiles of this chunk are no longer read
     publish_state();
+    if (MODE == GS_DC && ck) {   // forward state at the END of this chunk, fragment order, bf16 pairs
+      uint32_t* cp = ck + (int64_t)c * (8 * 2 * 8 * 64) + wave * (2 * 8 * 64);
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r2 = 0; r2 < 8; r2++) cp[(ut * 8 + r2) * 64 + lane] = pack_bf16x2(accS[ut][2 * r2], accS[ut][2 * r2 + 1]);
+    }
+    if (has_x4 && tid < 128) {
+      const int hd = tid >> 6, l = tid & 63, t = tok(c, l);
+      if (t < a.L) a.tokscal[((int64_t)b * a.H + h0 + hd) * a.L + t] = sm.rdot[0][hd][l] + sm.rdot[1][hd][l];
+    }
     // head 0 writes its scaled tile, head 1 adds
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
@@ -621,6 +683,30 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
     }
     commit((c + 1) & 1);
     block_sync();   // B4
+  }
+  if (MODE == GS_DB && a.dD) {
+    float* redw = sm.G[0];   // [8 waves][2 heads][64 cols]
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = dDp[r][e];
+        v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);
+        if (lane < 8) redw[(wave * 2 + r) * 64 + lane * 8 + e] = v;
+      }
+    block_sync();
+    if (tid < 128) {
+      const int r = tid >> 6, col = tid & 63;
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; w8++) v += redw[(w8 * 2 + r) * 64 + col];
+      if (a.dDsp == 0) {
+        v = wave_sum(v);
+        if (col == 0) atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh, v);
+      } else {
+        atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)col * a.dDsp, v);
+      }
+    }
   }
   if (a.fin) {
     const float extra = a.fin_extra_decay ? expf(a.dtp[((int64_t)b * a.H + hcur) * a.L] * Ah) : 1.f;
@@ -666,7 +752,7 @@ static bool src_ok16(const Src& s, bool need) {
 
 static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
   if (g.DU != 128 || g.DK != 64 || g.H % 2 != 0 || (g.H / g.G) % 2 != 0 || (!g.part && !dry)) return OMK_EUNSUPPORTED;
-  if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true)) return OMK_EUNSUPPORTED;
+  if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true) || !src_ok16(g.X4, false)) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
   dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
   const size_t smem = sizeof(SmemB);

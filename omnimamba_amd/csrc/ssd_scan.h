@@ -43,6 +43,9 @@ struct GScan {
   Src XE, YE;
   float* esum; float* wsum;                                      // (B, H, L) f32
   float* part;                                                   // DC/DB (MFMA): (B, H/2, L, 128) f32 per-head-pair partial tiles
+  // DC/DB (MFMA): forward-state checkpoints at every chunk end, written by the dC scan in MFMA fragment order
+  // (bf16 pairs) and read back by the dB scan, which emits the exact decay-gradient restart values bnd (B, H, nC + 1)
+  void* ckpt; float* bnd;
 };
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);

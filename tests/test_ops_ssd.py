@@ -125,10 +125,11 @@ def test_ssd_mfma_bwd(dev, L, H, G, with_z, with_init):
                                   dt_softplus=True, return_final_states=True, compute_dtype=torch.float64)
     torch.autograd.backward([y0, f0], [gy.double(), gf.double()])
     # bf16 outputs (dx, dB, dC, dz) carry one output rounding (1.65e-3) on top of the arithmetic error; fp32 outputs do not
-    # KNOWN LIMITATION (DESIGN.md "open items"): d(dt), dA, d(dt_bias) of the bf16 MFMA path come from a reverse prefix
-    # over ALL tokens of two per-token scalars that carry bf16-level (1e-3) errors, so their error grows ~sqrt(L);
-    # bounded here at L <= 130.  The fp32 generic path (test_ssd_generic_bwd) is exact to 2e-4.
-    tol = {"x": 5e-3, "dt": 1e-1, "A": 1e9, "B": 5e-3, "C": 5e-3, "D": 5e-3, "z": 5e-3, "dt_bias": 1e9, "init": 5e-3}
+    # bf16 outputs (dx, dB, dC, dz) carry one output rounding (1.65e-3) on top of the arithmetic error.  d(dt) is
+    # accurate per token (~2e-3); dA and d(dt_bias) are signed SUMS of it over every token, so at this tiny size
+    # (130 tokens, 1 sequence) cancellation amplifies the same bf16-level noise: 8e-2 of the vector norm here, shrinking
+    # ~1/sqrt(tokens) at training sizes.  The fp32 generic path (test_ssd_generic_bwd) is exact to 2e-4.
+    tol = {"x": 5e-3, "dt": 6e-3, "A": 8e-2, "B": 5e-3, "C": 5e-3, "D": 5e-3, "z": 5e-3, "dt_bias": 8e-2, "init": 5e-3}
     for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "z", "dt_bias", "init"], leaves, dl):
         if a is not None:
             e = rel(a.grad, b.grad)
