@@ -1,0 +1,159 @@
+"""Autoregressive decode around Mamba2.step (reference
+/root/reference/models/stage2/generation.py:19-36 InferenceParams, :87-121 sample, :125-266 decode,
+:308-434 graph cache).  Integer state -- seqlen_offset, position_ids, lengths_per_sample, the stop rule, greedy argmax
+-- is reproduced exactly; the 1-token step is captured once in a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed,
+which the omk_* kernels allow because they never allocate, synchronise or read host scalars.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class InferenceParams:
+    max_seqlen: int
+    max_batch_size: int
+    seqlen_offset: int = 0
+    batch_size_offset: int = 0
+    key_value_memory_dict: dict = field(default_factory=dict)
+    lengths_per_sample: Optional[torch.Tensor] = None
+
+    def reset(self, max_seqlen, max_batch_size):
+        self.max_seqlen = max_seqlen
+        self.max_batch_size = max_batch_size
+        self.seqlen_offset = 0
+        if self.lengths_per_sample is not None:
+            self.lengths_per_sample.zero_()
+
+
+def _top_p_filter_(logits, top_p):
+    if top_p <= 0.0 or top_p >= 1.0:
+        return
+    sorted_logits, sorted_idx = torch.sort(logits, descending=False)
+    remove = sorted_logits.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+    logits.masked_fill_(remove.scatter(1, sorted_idx, remove), float("-inf"))
+
+
+def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
+    """(batch, vocab) -> (batch,) token ids.  top_k == 1 is greedy argmax (what the inference scripts use)."""
+    if top_k == 1:
+        return logits.argmax(dim=-1)
+    if top_k > 0:
+        top_k = min(top_k, logits.size(-1))
+        vals, idx = torch.topk(logits, top_k, dim=-1)
+        if temperature != 1.0:
+            vals = vals / temperature
+        _top_p_filter_(vals, top_p)
+        pick = torch.multinomial(torch.softmax(vals, dim=-1), num_samples=1).squeeze(-1)
+        return idx[torch.arange(idx.shape[0], device=idx.device), pick]
+    work = logits / temperature if temperature != 1.0 else logits.clone()
+    if min_p > 0.0:
+        probs = torch.softmax(work, dim=-1)
+        work.masked_fill_(probs < probs.max(dim=-1, keepdim=True)[0] * min_p, float("-inf"))
+    else:
+        _top_p_filter_(work, top_p)
+    return torch.multinomial(torch.softmax(work, dim=-1), num_samples=1).squeeze(-1)
+
+
+class StepGraph:
+    """The captured 1-token model step: static input buffers refreshed by copy_, states updated in place."""
+
+    def __init__(self, model, inference_params, batch_size, max_seqlen, task, n_warmups=2):
+        dev = next(iter(model.parameters())).device
+        self.ip = inference_params
+        self.input_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
+        self.position_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
+        off = inference_params.seqlen_offset
+        # warm-ups run the STEP branch (offset > 0); they scribble on the caches, which prefill fully overwrites later
+        inference_params.seqlen_offset = max_seqlen - 1
+        inference_params.lengths_per_sample[:] = inference_params.seqlen_offset
+
+        def fwd():
+            out = model(self.input_ids, None, position_ids=self.position_ids, task=task, inference_params=inference_params,
+                        num_last_tokens=1)
+            return (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(n_warmups):
+                fwd()
+            s.synchronize()
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.barrier()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = fwd()
+        inference_params.seqlen_offset = off
+
+    def run(self, new_ids, new_pos, seqlen):
+        self.ip.lengths_per_sample[:] = seqlen
+        self.input_ids.copy_(new_ids)
+        self.position_ids.copy_(new_pos)
+        self.graph.replay()
+        return self.logits.clone()
+
+
+@torch.inference_mode()
+def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0,
+           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None):
+    """Prefill with ``input_embeddings`` (batch, seqlen_og, d), then sample until ``seqlen_offset >= max_length - 1`` (or
+    EOS).  Returns the token matrix (batch, seqlen_og + n_sampled): prompt ids followed by the sampled ids.
+    ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact."""
+    batch_size, seqlen_og = input_ids.shape
+    dev = input_embeddings.device
+    graph = None
+    if cg:
+        cache = getattr(model, "_decoding_cache", None)
+        key = (batch_size, max_length, task)
+        if cache is None or cache.get("key") != key:
+            dtype = next(iter(model.parameters())).dtype
+            ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
+                                 key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
+                                 lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
+            cache = {"key": key, "ip": ip, "graph": StepGraph(model, ip, batch_size, max_length, task)}
+            model._decoding_cache = cache
+        inference_params, graph = cache["ip"], cache["graph"]
+        inference_params.reset(max_length, batch_size)
+    else:
+        inference_params = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size)
+
+    def logits_of(out):
+        lg = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+        return lg[..., :vocab_size] if vocab_size is not None else lg
+
+    def get_logits(tokens, embeddings):
+        decoding = inference_params.seqlen_offset > 0
+        pos = torch.full((batch_size, 1), inference_params.seqlen_offset, dtype=torch.long, device=dev) if decoding else None
+        if trace is not None:
+            trace.append((inference_params.seqlen_offset, None if pos is None else int(pos[0, 0])))
+        if graph is not None and decoding:
+            lg = graph.run(tokens, pos, inference_params.seqlen_offset)
+            return lg[..., :vocab_size] if vocab_size is not None else lg
+        return logits_of(model(tokens, embeddings, position_ids=pos, task=task, inference_params=inference_params,
+                               num_last_tokens=1))
+
+    def should_stop(cur):
+        if inference_params.seqlen_offset == 0:
+            return False
+        if eos_token_id is not None and bool((cur == eos_token_id).all()):
+            return True
+        return inference_params.seqlen_offset >= max_length - 1
+
+    seqs = input_ids
+    last, first, n_in = None, True, seqlen_og
+    while not should_stop(last):
+        lg = get_logits(None, input_embeddings) if first else get_logits(last, None)
+        inference_params.seqlen_offset += n_in
+        first, n_in = False, 1
+        if teacher_outputs is not None and teacher_outputs.shape[1] > inference_params.seqlen_offset:
+            tok = teacher_outputs[:, inference_params.seqlen_offset]
+        else:
+            tok = sample(lg, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temperature)
+        last = tok.unsqueeze(1)
+        seqs = torch.cat([seqs, last], dim=1)
+    return seqs

@@ -1,0 +1,201 @@
+"""The sequence model around the hot path, restated for synthetic benchmarks and tests (SURVEY.md section 8 rows
+a1, a3; reference: /root/reference/models/stage2/{block.py, lora.py, mixer_seq_simple.py}, models/mamba_vlm.py:115-116).
+
+Not a port of OmniMamba: only what drives the Mamba-2 path -- token / image-token embeddings, N x [fused add+RMSNorm ->
+Mamba2 (in_proj wrapped by the task-switched LoRA)], final fused norm, the two tied heads.  Vision towers, VQ-VAE,
+tokenizer and captions are inputs of the path and are replaced by synthetic tensors.
+State-dict keys of the mixer/norm parts match the reference (`backbone.layers.{i}.mixer.*`, `backbone.layers.{i}.norm.weight`,
+`backbone.norm_f.weight`) so real checkpoints can replace the random init later (section 8f-4).
+"""
+from __future__ import annotations
+
+import math
+from collections import namedtuple
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layer_norm import RMSNorm, layer_norm_fn
+from .mamba2 import Mamba2
+
+CausalLMOutput = namedtuple("CausalLMOutput", ["t2i_logits", "mmu_logits"])
+
+
+@dataclass
+class StackConfig:
+    d_model: int = 2048
+    n_layer: int = 48
+    vocab_size: int = 50277
+    pad_vocab_size_multiple: int = 16
+    vqvae_vocab_size: int = 16384
+    num_tokens: int = 256                  # image tokens of a T2I sample
+    t2i_positions: int = 256 + 73          # reference: num_tokens + 73 (mixer_seq_simple.py:298-299)
+    mmu_positions: int = 1500              # reference cap (mixer_seq_simple.py:302-303); raise for L > 1500 (documented deviation)
+    ssm_cfg: dict = field(default_factory=dict)
+    norm_epsilon: float = 1e-5
+    residual_in_fp32: bool = True
+    lora_r: int = 8
+    lora_alpha: int = 32
+    lora_dropout: float = 0.05
+    t2i_task: bool = True
+    mmu_task: bool = True
+
+    @staticmethod
+    def omnimamba_1_3b(**kw):
+        return StackConfig(d_model=2048, n_layer=48, **kw)
+
+    @property
+    def padded_vocab(self):
+        m = self.pad_vocab_size_multiple
+        return self.vocab_size + (-self.vocab_size) % m
+
+
+class TaskLoRALinear(nn.Linear):
+    """Task-switched LoRA on a dense layer (reference models/stage2/lora.py:185-279 with lora_nums = 1):
+    y = x W^T (+b) + scaling * B_task(A_task(dropout(x))),  task in {'t2i', 'mmu'} chosen by ``self.task_types``.
+    Parameter names match the reference (`{task}_lora_A0.weight`, `{task}_lora_B0.weight`)."""
+
+    def __init__(self, in_features, out_features, r=8, lora_alpha=32, lora_dropout=0.05, bias=False, device=None, dtype=None):
+        super().__init__(in_features, out_features, bias=bias, device=device, dtype=dtype)
+        self.r, self.lora_alpha = r, lora_alpha
+        self.scaling = lora_alpha / r
+        self.lora_dropout = nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else nn.Identity()
+        self.task_types = "t2i"
+        self.disable_adapters = False
+        for task in ("mmu", "t2i"):
+            setattr(self, f"{task}_lora_A0", nn.Linear(in_features, r, bias=False, device=device, dtype=dtype))
+            setattr(self, f"{task}_lora_B0", nn.Linear(r, out_features, bias=False, device=device, dtype=dtype))
+        self.weight.requires_grad = False
+        for task in ("mmu", "t2i"):
+            nn.init.kaiming_uniform_(getattr(self, f"{task}_lora_A0").weight, a=math.sqrt(5))
+            nn.init.zeros_(getattr(self, f"{task}_lora_B0").weight)
+
+    def forward(self, x):
+        result = F.linear(x, self.weight, self.bias)
+        if self.disable_adapters or self.task_types not in ("t2i", "mmu"):
+            return result
+        A = getattr(self, f"{self.task_types}_lora_A0")
+        B = getattr(self, f"{self.task_types}_lora_B0")
+        return result + B(A(self.lora_dropout(x))) * self.scaling
+
+
+class ResidualBlock(nn.Module):
+    """Add -> RMSNorm -> Mixer with the residual stream kept in fp32 (reference block.py:71-117, fused_add_norm path)."""
+
+    def __init__(self, d_model, layer_idx, cfg: StackConfig, device=None, dtype=None):
+        super().__init__()
+        self.residual_in_fp32 = cfg.residual_in_fp32
+        self.norm = RMSNorm(d_model, eps=cfg.norm_epsilon, device=device, dtype=dtype)
+        self.mixer = Mamba2(d_model, layer_idx=layer_idx, device=device, dtype=dtype, **cfg.ssm_cfg)
+        self.layer_idx = layer_idx
+
+    def forward(self, hidden_states, residual=None, inference_params=None):
+        hidden_states, residual = layer_norm_fn(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
+                                                prenorm=True, residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps,
+                                                is_rms_norm=True)
+        return self.mixer(hidden_states, inference_params=inference_params), residual
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
+
+
+class MixerStack(nn.Module):
+    def __init__(self, cfg: StackConfig, device=None, dtype=None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.cfg = cfg
+        d = cfg.d_model
+        self.embedding = nn.Embedding(cfg.padded_vocab, d, **fk)
+        if cfg.t2i_task:
+            self.img_embeddings = nn.Embedding(cfg.vqvae_vocab_size, d, **fk)
+            self.pos_embed = nn.Parameter(nn.init.trunc_normal_(torch.zeros(1, cfg.t2i_positions, d, **fk), 0.0, 0.02))
+        if cfg.mmu_task:
+            self.mmu_pos_embed = nn.Parameter(nn.init.trunc_normal_(torch.zeros(1, cfg.mmu_positions, d, **fk), 0.0, 0.02))
+        self.layers = nn.ModuleList([ResidualBlock(d, i, cfg, **fk) for i in range(cfg.n_layer)])
+        self.norm_f = RMSNorm(d, eps=cfg.norm_epsilon, **fk)
+        # reference _init_weights (mixer_seq_simple.py:233-262): embeddings N(0, 0.02), out_proj / sqrt(n_layer)
+        nn.init.normal_(self.embedding.weight, std=0.02)
+        if cfg.t2i_task:
+            nn.init.normal_(self.img_embeddings.weight, std=0.02)
+        for blk in self.layers:
+            nn.init.kaiming_uniform_(blk.mixer.out_proj.weight, a=math.sqrt(5))
+            with torch.no_grad():
+                blk.mixer.out_proj.weight /= math.sqrt(cfg.n_layer)
+        # reference _find_and_replace (lora.py:78-112): every mixer.in_proj becomes the task-switched LoRA Linear that
+        # shares the base weight tensor
+        for blk in self.layers:
+            old = blk.mixer.in_proj
+            new = TaskLoRALinear(old.in_features, old.out_features, r=cfg.lora_r, lora_alpha=cfg.lora_alpha,
+                                 lora_dropout=cfg.lora_dropout, bias=old.bias is not None, device=old.weight.device,
+                                 dtype=old.weight.dtype)
+            new.weight = old.weight
+            new.weight.requires_grad = False
+            blk.mixer.in_proj = new
+
+    def set_lora_mode(self, task):
+        for blk in self.layers:
+            blk.mixer.in_proj.task_types = task
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return {i: blk.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs) for i, blk in enumerate(self.layers)}
+
+    def forward(self, input_ids, input_embeddings, position_ids=None, task="t2i", inference_params=None):
+        """Training / prefill: ``input_embeddings`` (B, L, d) given.  Decode: ``input_ids`` (B, 1) + ``position_ids``
+        (reference MixerModel.forward, mixer_seq_simple.py:375-440, minus the dead adaLN branches)."""
+        self.set_lora_mode(task)
+        if input_embeddings is not None:
+            h = input_embeddings     # the reference adds the position table in OmniMamba.forward (omnimamba.py:264 / mixer_seq_simple.py:386)
+            h = h + (self.mmu_pos_embed if task == "mmu" else self.pos_embed)[:, : h.shape[1]]
+        else:
+            if task == "t2i":
+                h = self.img_embeddings(input_ids)
+                pe = self.pos_embed.expand(h.shape[0], -1, -1)
+            else:
+                h = self.embedding(input_ids)
+                pe = self.mmu_pos_embed.expand(h.shape[0], -1, -1)
+            h = h + pe.gather(1, position_ids.unsqueeze(-1).expand(-1, -1, pe.size(-1)))
+        residual = None
+        for blk in self.layers:
+            h, residual = blk(h, residual, inference_params=inference_params)
+        return layer_norm_fn(h, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual, prenorm=False,
+                             residual_in_fp32=self.cfg.residual_in_fp32, is_rms_norm=True)
+
+
+class OmniMambaLM(nn.Module):
+    """backbone + tied heads (reference MambaLMHeadModel, mixer_seq_simple.py:443-524)."""
+
+    def __init__(self, cfg: StackConfig, device=None, dtype=None):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = MixerStack(cfg, device=device, dtype=dtype)
+        self.lm_head = nn.Linear(cfg.d_model, cfg.padded_vocab, bias=False, device=device, dtype=dtype)
+        self.lm_head.weight = self.backbone.embedding.weight
+        if cfg.t2i_task:
+            self.img_head = nn.Linear(cfg.d_model, cfg.vqvae_vocab_size, bias=False, device=device, dtype=dtype)
+            self.img_head.weight = self.backbone.img_embeddings.weight
+        self._decoding_cache = None
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return self.backbone.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
+
+    def forward(self, input_ids, input_embeddings, position_ids=None, cond=None, task=None, inference_params=None,
+                num_last_tokens=0):
+        h = self.backbone(input_ids, input_embeddings, position_ids, task, inference_params=inference_params)
+        if num_last_tokens > 0:
+            h = h[:, -num_last_tokens:]
+        return CausalLMOutput(t2i_logits=self.img_head(h) if task == "t2i" else None,
+                              mmu_logits=self.lm_head(h) if task == "mmu" else None)
+
+    def set_stage(self, stage: str):
+        """Which parameters train (reference omnimamba.py:119-188): 'align' = LoRA adapters (+ embeddings of the new
+        modality), 'finetune' = everything in the Mamba stack."""
+        if stage == "finetune":
+            for p in self.parameters():
+                p.requires_grad_(True)
+        elif stage == "align":
+            for n, p in self.named_parameters():
+                p.requires_grad_("lora" in n or "img_embeddings" in n or "pos_embed" in n)
+        else:
+            raise ValueError(stage)
