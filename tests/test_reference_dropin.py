@@ -32,5 +32,6 @@ def test_reference_block_runs_on_our_operators():
         y1, r1 = blk(h, res)
         y2, r2 = ours(h, res)
         assert r1.dtype == torch.float32 and torch.equal(r1, r2) and torch.allclose(y1, y2, atol=1e-6)
-        y1, r1 = blk(h.bfloat16(), None)                    # first block: residual=None, bf16 activations, fp32 residual out
+        with torch.autocast("cpu", dtype=torch.bfloat16):   # training runs under bf16 AMP (train_stage2.py:21,37)
+            y1, r1 = blk(h.bfloat16(), None)                # first block: residual=None, bf16 activations, fp32 residual out
         assert r1.dtype == torch.float32 and y1.dtype == torch.bfloat16
