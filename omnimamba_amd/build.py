@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomnimamba_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast"] + (["-DOMK_PHASE_PROF"] if os.environ.get("OMK_PHASE_PROF") else [])
 
 
 def sources():

@@ -37,6 +37,7 @@ typedef void* hipStream_t;
 
 namespace omk {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -115,6 +116,7 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
   return r;
 }
 __device__ __forceinline__ float atomic_add_f32(float* p, float v) { float o = *p; *p = o + v; return o; }
+__device__ __forceinline__ void lds_add_f32(float* p, float v) { *p += v; }
 #else
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 template <class T> __device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src, 64); }
@@ -133,6 +135,8 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 __device__ __forceinline__ float atomic_add_f32(float* p, float v) { return unsafeAtomicAdd(p, v); }
+// fire-and-forget LDS float add (ds_add_f32): result unused so no return value is requested
+__device__ __forceinline__ void lds_add_f32(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
 template <class T> __device__ __forceinline__ T wave_sum(T v) {
@@ -149,6 +153,11 @@ __device__ __forceinline__ float rcp_fast(float x) { return 1.f / x; }
 #else
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+#ifdef OMK_EMU
+__device__ __forceinline__ uint64_t clock64_() { return 0; }
+#else
+__device__ __forceinline__ uint64_t clock64_() { return __builtin_readcyclecounter(); }
 #endif
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float silu_fast(float x) { return x * rcp_fast(1.f + exp2_fast(-x * LOG2E)); }

@@ -6,6 +6,8 @@
 //   e_t = dy_t . y~_t            (from GS_DC:  sum_n C_t[n] O_t[n])
 //   w_t = <g_t, x_t (x) B_t>     (from GS_DB:  sum_n B_t[n] O_t[n])
 //   dl_t = e_t - dt'_t w_t + dl_{t+1} ;  d(dt')_t = w_t + A_h dl_t ;  dA_h = sum_t dt'_t dl_t
+#include <cstdlib>
+
 #include "ssd_scan.h"
 
 namespace omk {
@@ -305,7 +307,7 @@ using namespace omk;
 
 extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
   if (!p) return 0;
-  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4);
+  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024;   // + developer profiling slots
 }
 
 extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
@@ -336,6 +338,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   }
   g.out = p->out.data; g.osb = p->out.stride[0]; g.osl = p->out.stride[1]; g.osh = p->out.stride[2]; g.out_dt = p->out.dtype; g.outx = p->out_x.data;
   if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
+  if (getenv("OMK_PROF") && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p)) g.prof = (unsigned long long*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4));
   rc = run_scan(g, p->force_generic, stream);
   if (rc) return rc;
   return finish_launch("ssd_scan_fwd");

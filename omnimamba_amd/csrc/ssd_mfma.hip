@@ -55,16 +55,20 @@ __device__ __forceinline__ s16x8 tr_frag(const uint16_t* tile, int ld, int r0, i
   return r;
 }
 
-// MODE: GS_Y (forward output) or GS_DX (reverse, dx + token scalars)
+// MODE: GS_Y (forward output y) or GS_DX (time-reversed, dx)
+//
+// Wave roles inside a head (4 waves): wave (wi, wj) always owns the two state tiles S^T[64 wi + 32 kt ..][32 wj ..];
+// for the output it is either a "D" wave -- builds the decay-masked M fragments of l-tile wi ONCE and runs the
+// M.U chain for both u-tiles -- or an "S" wave -- runs the Q.S_in chain of l-tile wi for both u-tiles.  The two
+// partial outputs meet in LDS (S wave stores exp2(cs) * acc, D wave ds_add's).  Heads use opposite role maps so the two
+// waves sharing a SIMD (w, w + 4) are one VALU-heavy D wave and one MFMA-heavy S wave.
 template <int MODE>
 __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
-  const void* Xe = a.XE.p; const int64_t xe_sb = a.XE.sb, xe_sl = a.XE.sl, xe_sh = a.XE.sh;
-  const void* Ye = a.YE.p; const int64_t ye_sb = a.YE.sb, ye_sl = a.YE.sl, ye_sh = a.YE.sh;
-  float* esum = a.esum; float* wsum = a.wsum;
   OMK_DYN_SMEM(smem_raw);
   SmemA& sm = *reinterpret_cast<SmemA*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const bool roleD = ((wj ^ hh) & 1) == 0;
   const int h32 = lane >> 5, l31 = lane & 31, g16 = lane >> 4, t16 = lane & 15;
   const int pairs = a.H / 2;
   const int b = blockIdx.x / pairs, hp = blockIdx.x % pairs;
@@ -72,36 +76,38 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
   const int g = h0 / (a.H / a.G);
   const int nC = (a.L + QC - 1) / QC;
   const bool rev = a.reverse != 0;
+  const int tstep = rev ? -QC : QC;
 
-  auto tok = [&](int c, int row) -> int {   // token index of LDS row `row` in the c-th processed chunk
-    const int id = rev ? nC - 1 - c : c;
-    return rev ? id * QC + (QC - 1) - row : id * QC + row;
-  };
-
-  // ---- staging: K, Q (64 x 128) two 16-B segments per thread each; U (2 heads x 64 x 64) two per thread
+  // ---- staging with pointer-increment addressing: token of (chunk 0, row) once, then +-64 tokens per chunk
+  auto tok0 = [&](int row) -> int { return rev ? (nC - 1) * QC + (QC - 1) - row : row; };
   u32x4 rk[2], rq[2], ru[2];
-  float rdt = 0.f;                                   // threads 0..127: dt' of (head tid>>6, row tid&63)
-  const uint16_t* Kg = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
-  const uint16_t* Qg = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
-  const uint16_t* Ug = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb;
-  const float* dtp0 = a.dtp + ((int64_t)b * a.H + h0) * a.L;
-  auto prefetch = [&](int c) {
+  float rdt = 0.f;
+  int tk[2], tu = tok0(tid >> 3), tdt = tok0(tid & 63);
+  const uint16_t *pk[2], *pq[2], *pu[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
+    tk[r] = tok0(row);
+    pk[r] = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh + (int64_t)tk[r] * a.K.sl + cs8;
+    pq[r] = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh + (int64_t)tk[r] * a.Q.sl + cs8;
+    pu[r] = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)(h0 + r) * a.U.sh + (int64_t)tu * a.U.sl + (tid & 7) * 8;
+  }
+  const float* pdt = a.dtp + ((int64_t)b * a.H + h0 + ((tid >> 6) & 1)) * a.L + tdt;
+  const int64_t dK = (int64_t)tstep * a.K.sl, dQ = (int64_t)tstep * a.Q.sl, dU = (int64_t)tstep * a.U.sl;
+  int cload = 0;   // chunk the staging registers currently point at
+  auto prefetch = [&]() {
+    const bool in = cload < nC;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
-      const int t = tok(c, row);
-      const bool ok = c < nC && t < a.L;
-      rk[r] = ok ? ld16(Kg + (int64_t)t * a.K.sl + cs8) : u32x4{0, 0, 0, 0};
-      rq[r] = ok ? ld16(Qg + (int64_t)t * a.Q.sl + cs8) : u32x4{0, 0, 0, 0};
-      const int row_u = (tid >> 3), cu8 = (tid & 7) * 8;   // pass r = head r
-      const int tu = tok(c, row_u);
-      const bool oku = c < nC && tu < a.L;
-      ru[r] = oku ? ld16(Ug + (int64_t)tu * a.U.sl + (int64_t)(h0 + r) * a.U.sh + cu8) : u32x4{0, 0, 0, 0};
+      const bool ok = in && tk[r] < a.L;
+      rk[r] = ok ? ld16(pk[r]) : u32x4{0, 0, 0, 0};
+      rq[r] = ok ? ld16(pq[r]) : u32x4{0, 0, 0, 0};
+      ru[r] = (in && tu < a.L) ? ld16(pu[r]) : u32x4{0, 0, 0, 0};
+      pk[r] += dK; pq[r] += dQ; pu[r] += dU; tk[r] += tstep;
     }
-    if (tid < 128) {
-      const int t = tok(c, tid & 63);
-      rdt = (c < nC && t < a.L) ? dtp0[(int64_t)(tid >> 6) * a.L + t] : 0.f;
-    }
+    if (tid < 128) rdt = (in && tdt < a.L) ? *pdt : 0.f;
+    pdt += tstep; tdt += tstep; tu += tstep;
+    cload++;
   };
   auto commit = [&](int par) {   // registers -> LDS tiles (dt' goes to the parity buffer of the chunk it belongs to)
 #pragma unroll
@@ -143,18 +149,38 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
       }
   };
 
-  prefetch(0);
+  prefetch();
   commit(0);
   publish_state();
   if (tid < 128) sm.Dv[tid >> 6][tid & 63] = a.D ? load_rt(a.D, (int64_t)(h0 + (tid >> 6)) * a.Dsh + (int64_t)(tid & 63) * a.Dsp, a.D_dt) : 0.f;
   block_sync();
 
-  float dDp[2][8] = {{0.f}};   // DX: per-thread partial of dD over its (head, 8 columns)
+  // epilogue mapping: thread = (head r, row tid>>3, 8 columns); token of the row advances by +-64 per chunk
+  int tep = tok0(tid >> 3);
+  const uint16_t* pz[2] = {nullptr, nullptr};
+  int64_t po[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    po[r] = (int64_t)b * a.osb + (int64_t)tep * a.osl + (int64_t)(h0 + r) * a.osh + (tid & 7) * 8;
+    if (MODE == GS_Y && a.Z.p) pz[r] = (const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)tep * a.Z.sl + (int64_t)(h0 + r) * a.Z.sh + (tid & 7) * 8;
+  }
+  const int64_t dO = (int64_t)tstep * a.osl, dZ = (int64_t)tstep * a.Z.sl;
+
+#ifdef OMK_PHASE_PROF   // developer build (tools/phase_prof.py): s_memtime deltas per phase, workgroup 0
+  uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+#define PT(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+  uint64_t tprev = prof ? clock64_() : 0;
+#else
+#define PT(i) do { } while (0)
+#endif
   for (int c = 0; c < nC; c++) {
-    prefetch(c + 1);
+    prefetch();
+    PT(0);
     // ---- scalars: one wave per head, lanes = tokens
     if ((wave & 3) == 0) {
-      const int t = tok(c, lane);
+      const int id = rev ? nC - 1 - c : c;
+      const int t = rev ? id * QC + (QC - 1) - lane : id * QC + lane;
       const bool ok = t < a.L;
       const float d = sm.dtl[c & 1][hh][lane];
       float la;
@@ -168,14 +194,14 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
       }
       const float cs_end = shfl(cs, 63);
       const float wv = ok ? (a.w_is_dt ? d : 1.f) : 0.f;
-      sm.cs[hh][lane] = cs;              // log2 units (la was scaled by log2 e)
+      sm.cs[hh][lane] = cs;              // log2 units
       sm.ecs[hh][lane] = exp2_fast(cs);
       sm.w[hh][lane] = wv;
       sm.ws[hh][lane] = wv * exp2_fast(cs_end - cs);
     }
     // ---- G^T = K Q^T, lower triangle of 16x16 tiles (s-tile ta <= l-tile tb), 4 MFMA each
     for (int tile = wave; tile < 10; tile += 8) {
-      int ta, tb;   // enumerate (ta <= tb): tb = 0:(0) 1:(0,1) 2:(0,1,2) 3:(0..3)
+      int ta, tb;
       if (tile < 1) { tb = 0; ta = tile; } else if (tile < 3) { tb = 1; ta = tile - 1; } else if (tile < 6) { tb = 2; ta = tile - 3; } else { tb = 3; ta = tile - 6; }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -184,69 +210,90 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
         s16x8 fb = as_s16x8(ld16(&sm.Qm[(16 * tb + t16) * LDK + 32 * kk + 8 * g16]));
         acc = mfma16x16x32_bf16(fa, fb, acc);
       }
-      // D[i = s][j = l]: lane holds column l = 16 tb + t16, rows s = 16 ta + 4 g16 + r
       *reinterpret_cast<f32x4*>(&sm.G[(16 * tb + t16) * LDG + 16 * ta + 4 * g16]) = acc;
     }
+    PT(1);
     block_sync();   // B1: G and scalars visible
+    PT(2);
 
-    // ---- O_diag = M U
-    f32x16 accD, accO;
+    f32x16 accX[2];   // D wave: M.U for u-tiles 0/1 ; S wave: Q.S_in for u-tiles 0/1   (l-tile wi)
 #pragma unroll
-    for (int r = 0; r < 16; r++) { accD[r] = 0.f; accO[r] = 0.f; }
-    {
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) accX[ut][r] = 0.f;
+    if (roleD) {
       const int l = 32 * wi + l31;
       const float cs_l = sm.cs[hh][l];
       const int nks = 2 * (wi + 1);
       for (int ks = 0; ks < nks; ks++) {
         const int s0 = 16 * ks + 8 * h32;
-        f32x4 g0 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0]);
-        f32x4 g1 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0 + 4]);
-        float m[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int s = s0 + e;
-          const float gv = e < 4 ? g0[e & 3] : g1[e & 3];
-          const float v = gv * exp2_fast(cs_l - sm.cs[hh][s]) * sm.w[hh][s];
-          m[e] = (s <= l) ? v : 0.f;
-        }
-        // M is the one rounding point that dominates the error of y (the state terms decay away at the module's
-        // dt/A init), so it is fed to the MFMA as hi + lo bf16 pairs: two MFMAs on the same B fragment.
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(&sm.G[l * LDG + s0 + 4]);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sm.cs[hh][s0]);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sm.cs[hh][s0 + 4]);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(&sm.w[hh][s0]);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(&sm.w[hh][s0 + 4]);
+        // M is the one rounding point that dominates the error of y, so it is fed as hi + lo bf16 pairs (2 MFMAs)
         u32x4 mp, ml;
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) {
-          const uint16_t h0b = f32_to_bf16(m[2 * e2]), h1b = f32_to_bf16(m[2 * e2 + 1]);
-          mp[e2] = (uint32_t)h0b | ((uint32_t)h1b << 16);
-          ml[e2] = pack_bf16x2(m[2 * e2] - bf16_to_f32(h0b), m[2 * e2 + 1] - bf16_to_f32(h1b));
+          const f32x2 gv = e2 < 2 ? f32x2{g0[2 * e2], g0[2 * e2 + 1]} : f32x2{g1[2 * e2 - 4], g1[2 * e2 - 3]};
+          const f32x2 cv = e2 < 2 ? f32x2{c0[2 * e2], c0[2 * e2 + 1]} : f32x2{c1[2 * e2 - 4], c1[2 * e2 - 3]};
+          const f32x2 wv = e2 < 2 ? f32x2{w0[2 * e2], w0[2 * e2 + 1]} : f32x2{w1[2 * e2 - 4], w1[2 * e2 - 3]};
+          const f32x2 dd = f32x2{cs_l, cs_l} - cv;
+          f32x2 v = gv * wv * f32x2{exp2_fast(dd[0]), exp2_fast(dd[1])};
+          const int s = s0 + 2 * e2;
+          v[0] = (s <= l) ? v[0] : 0.f;
+          v[1] = (s + 1 <= l) ? v[1] : 0.f;
+          const uint32_t hi = pack_bf16x2(v[0], v[1]);
+          mp[e2] = hi;
+          ml[e2] = pack_bf16x2(v[0] - bf_lo(hi), v[1] - bf_hi(hi));
         }
-        s16x8 fb = tr_frag(sm.U[hh], LDU, 16 * ks, 32 * wj, lane);
-        accD = mfma32x32x16_bf16(as_s16x8(mp), fb, accD);
-        accD = mfma32x32x16_bf16(as_s16x8(ml), fb, accD);
-      }
-    }
-    // ---- O_off = Q S_in^T  (contraction over k = 0..127)
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      s16x8 fa = as_s16x8(ld16(&sm.Qm[(32 * wi + l31) * LDK + 16 * ks + 8 * h32]));
-      s16x8 fb = as_s16x8(ld16(&sm.S[hh][(32 * wj + l31) * LDK + 16 * ks + 8 * h32]));
-      accO = mfma32x32x16_bf16(fa, fb, accO);
+        for (int ut = 0; ut < 2; ut++) {
+          s16x8 fb = tr_frag(sm.U[hh], LDU, 16 * ks, 32 * ut, lane);
+          accX[ut] = mfma32x32x16_bf16(as_s16x8(mp), fb, accX[ut]);
+          accX[ut] = mfma32x32x16_bf16(as_s16x8(ml), fb, accX[ut]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        s16x8 fa = as_s16x8(ld16(&sm.Qm[(32 * wi + l31) * LDK + 16 * ks + 8 * h32]));
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+          s16x8 fb = as_s16x8(ld16(&sm.S[hh][(32 * ut + l31) * LDK + 16 * ks + 8 * h32]));
+          accX[ut] = mfma32x32x16_bf16(fa, fb, accX[ut]);
+        }
+      }
+      // S wave lands first: exp2(cs_l) * (Q . S_in) as plain stores (O of the previous chunk was consumed before B4)
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+          sm.O[hh][l * LDG + 32 * ut + l31] = sm.ecs[hh][l] * accX[ut][r];
+        }
     }
+    PT(3);
     // ---- state update: S^T[k][u] = exp(cs_end) S^T + sum_l K^T[k][l] (ws_l U[l][u])
     {
       const float dec = sm.ecs[hh][QC - 1];
 #pragma unroll
-      for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) accS[kt][r] *= dec;
+      for (int kt = 0; kt < 2; kt++) accS[kt] *= dec;
 #pragma unroll
       for (int ls = 0; ls < 4; ls++) {
         s16x8 fu = tr_frag(sm.U[hh], LDU, 16 * ls, 32 * wj, lane);
         const int lb = 16 * ls + 8 * h32;
+        const f32x4 s0v = *reinterpret_cast<const f32x4*>(&sm.ws[hh][lb]);
+        const f32x4 s1v = *reinterpret_cast<const f32x4*>(&sm.ws[hh][lb + 4]);
         u32x4 up;
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) {
-          const float lo = bf16_to_f32((uint16_t)fu[2 * e2]) * sm.ws[hh][lb + 2 * e2];
-          const float hi = bf16_to_f32((uint16_t)fu[2 * e2 + 1]) * sm.ws[hh][lb + 2 * e2 + 1];
-          up[e2] = pack_bf16x2(lo, hi);
+          const f32x2 uv = {bf16_to_f32((uint16_t)fu[2 * e2]), bf16_to_f32((uint16_t)fu[2 * e2 + 1])};
+          const f32x2 sv = e2 < 2 ? f32x2{s0v[2 * e2], s0v[2 * e2 + 1]} : f32x2{s1v[2 * e2 - 4], s1v[2 * e2 - 3]};
+          const f32x2 pr = uv * sv;
+          up[e2] = pack_bf16x2(pr[0], pr[1]);
         }
 #pragma unroll
         for (int kt = 0; kt < 2; kt++) {
@@ -255,122 +302,73 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
         }
       }
     }
-    block_sync();   // B2: every wave is done reading S_in, G, K, Q, U of this chunk
-    // epilogue operands (issued here so they are not live across the MFMA section) straight from HBM into registers: segment (head r, row tid>>3, cols (tid&7)*8 .. +8)
-    u32x4 ez[2], ex[2], ey[2];
-    {
-      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
+    PT(4);
+    block_sync();   // B2: every wave is done reading S_in, G, K, Q, U tiles; the S waves' part of O is in LDS
+    PT(5);
+    // epilogue operands (issued here so they are not live across the MFMA section) straight from HBM into registers
+    u32x4 ez[2];
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        ez[r] = ex[r] = ey[r] = u32x4{0, 0, 0, 0};
-        if (t < a.L) {
-          if (MODE == GS_Y && a.Z.p) ez[r] = ld16((const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)t * a.Z.sl + (int64_t)(h0 + r) * a.Z.sh + c8);
-          if (MODE == GS_DX && Xe) {
-            ex[r] = ld16((const uint16_t*)Xe + (int64_t)b * xe_sb + (int64_t)t * xe_sl + (int64_t)(h0 + r) * xe_sh + c8);
-            ey[r] = ld16((const uint16_t*)Ye + (int64_t)b * ye_sb + (int64_t)t * ye_sl + (int64_t)(h0 + r) * ye_sh + c8);
-          }
-        }
-      }
-    }
+    for (int r = 0; r < 2; r++) ez[r] = (MODE == GS_Y && pz[r] && tep < a.L) ? ld16(pz[r]) : u32x4{0, 0, 0, 0};
     publish_state();
+    if (roleD) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
-      sm.O[hh][l * LDG + 32 * wj + l31] = accD[r] + sm.ecs[hh][l] * accO[r];
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+          sm.O[hh][l * LDG + 32 * ut + l31] += accX[ut][r];   // plain read-modify-write: this lane is the only writer after B2
+                                                               // (an LDS float atomic here compiled to a CAS loop: 21K of 34K cycles/chunk)
+        }
     }
+    PT(6);
     block_sync();   // B3: O tile and the new bf16 state are complete
+    PT(7);
     // ---- epilogue: thread = (head r, row tid>>3, 8 columns)
     {
-      const int row = tid >> 3, c8 = (tid & 7) * 8, t = tok(c, row);
+      const int row = tid >> 3, c8 = (tid & 7) * 8;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        const int hd = h0 + r;
-        f32x4 o0 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8]);
-        f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8 + 4]);
-        u32x4 uv = ld16(&sm.U[r][row * LDU + c8]);
-        float o[8], uu[8], res[8];
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8]);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[r][row * LDG + c8 + 4]);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8]), d1 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8 + 4]);
+        const u32x4 uv = ld16(&sm.U[r][row * LDU + c8]);
+        const float sc = MODE == GS_DX ? sm.dtl[c & 1][r][row] : 1.f;
+        float res[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          o[e] = e < 4 ? o0[e & 3] : o1[e & 3];
-          uu[e] = (e & 1) ? bf_hi(uv[e >> 1]) : bf_lo(uv[e >> 1]);
+          const float o = e < 4 ? o0[e & 3] : o1[e & 3];
+          const float dv = e < 4 ? d0[e & 3] : d1[e & 3];
+          const float uu = (e & 1) ? bf_hi(uv[e >> 1]) : bf_lo(uv[e >> 1]);
+          res[e] = sc * o + dv * uu;
         }
-        float Dv[8];
-        {
-          const f32x4 d0 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8]), d1 = *reinterpret_cast<const f32x4*>(&sm.Dv[r][c8 + 4]);
-#pragma unroll
-          for (int e = 0; e < 8; e++) Dv[e] = e < 4 ? d0[e & 3] : d1[e & 3];
-        }
-        const int64_t oaddr = (int64_t)b * a.osb + (int64_t)t * a.osl + (int64_t)hd * a.osh + c8;
         if (MODE == GS_Y) {
-          u32x4 px, pz;
-#pragma unroll
-          for (int e = 0; e < 8; e++) res[e] = o[e] + Dv[e] * uu[e];
-          if (a.outx) {
+          if (a.outx && tep < a.L) {
+            u32x4 px;
             px[0] = pack_bf16x2(res[0], res[1]); px[1] = pack_bf16x2(res[2], res[3]); px[2] = pack_bf16x2(res[4], res[5]); px[3] = pack_bf16x2(res[6], res[7]);
-            if (t < a.L) st16((uint16_t*)a.outx + oaddr, px);
+            st16((uint16_t*)a.outx + po[r], px);
           }
           if (a.Z.p) {
 #pragma unroll
             for (int e = 0; e < 8; e++) res[e] *= silu_fast((e & 1) ? bf_hi(ez[r][e >> 1]) : bf_lo(ez[r][e >> 1]));
           }
-          pz[0] = pack_bf16x2(res[0], res[1]); pz[1] = pack_bf16x2(res[2], res[3]); pz[2] = pack_bf16x2(res[4], res[5]); pz[3] = pack_bf16x2(res[6], res[7]);
-          if (t < a.L) st16((uint16_t*)a.out + oaddr, pz);
-        } else {
-          const float dtt = sm.dtl[c & 1][r][row];
-          u32x4 pz;
-#pragma unroll
-          for (int e = 0; e < 8; e++) res[e] = dtt * o[e] + Dv[e] * uu[e];
-          pz[0] = pack_bf16x2(res[0], res[1]); pz[1] = pack_bf16x2(res[2], res[3]); pz[2] = pack_bf16x2(res[4], res[5]); pz[3] = pack_bf16x2(res[6], res[7]);
-          if (t < a.L) st16((uint16_t*)a.out + oaddr, pz);
-          if (Xe) {   // token scalars: w_t = sum_p x O ; e_t = sum_p dy (y - D x) ; dD += dy x
-            float wp = 0.f, ep = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              const float xv = (e & 1) ? bf_hi(ex[r][e >> 1]) : bf_lo(ex[r][e >> 1]);
-              const float yv = (e & 1) ? bf_hi(ey[r][e >> 1]) : bf_lo(ey[r][e >> 1]);
-              wp += xv * o[e];
-              ep += uu[e] * (yv - Dv[e] * xv);
-              dDp[r][e] += uu[e] * xv;
-            }
-            wp += shfl_xor(wp, 1); wp += shfl_xor(wp, 2); wp += shfl_xor(wp, 4);
-            ep += shfl_xor(ep, 1); ep += shfl_xor(ep, 2); ep += shfl_xor(ep, 4);
-            if ((tid & 7) == 0 && t < a.L) {
-              wsum[((int64_t)b * a.H + hd) * a.L + t] = wp;
-              esum[((int64_t)b * a.H + hd) * a.L + t] = ep;
-            }
-          }
         }
+        u32x4 pzv;
+        pzv[0] = pack_bf16x2(res[0], res[1]); pzv[1] = pack_bf16x2(res[2], res[3]); pzv[2] = pack_bf16x2(res[4], res[5]); pzv[3] = pack_bf16x2(res[6], res[7]);
+        if (tep < a.L) st16((uint16_t*)a.out + po[r], pzv);
+        po[r] += dO;
+        if (pz[r]) pz[r] += dZ;
       }
+      tep += tstep;
     }
-    commit((c + 1) & 1);   // tiles of chunk c+1 (no reader of chunk c's tiles is left after B2; the epilogue read sm.U before this)
+    commit((c + 1) & 1);   // tiles of chunk c+1 (no reader of chunk c's tiles is left after B2; the epilogue read its own sm.U segment before this)
+    PT(8);
     block_sync();   // B4
+    PT(9);
   }
-  if (MODE == GS_DX && a.dD) {
-    // fold the per-thread partials inside the workgroup first: same-address fp32 atomics from 512 threads x 256
-    // workgroups serialise at the memory side (measured: 12.6 ms of a 13.1 ms launch) -- one atomic per column instead
-    float* redw = sm.G;   // [8 waves][2 heads][64 cols]   (tiles are dead after the last chunk's B4)
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float v = dDp[r][e];
-        v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);   // lanes sharing (tid & 7) = same 8 columns
-        if (lane < 8) redw[(wave * 2 + r) * 64 + lane * 8 + e] = v;
-      }
-    block_sync();
-    if (tid < 128) {
-      const int r = tid >> 6, col = tid & 63;
-      float v = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; w8++) v += redw[(w8 * 2 + r) * 64 + col];
-      if (a.dDsp == 0) {           // D is (H): one value per head
-        v = wave_sum(v);
-        if (col == 0) atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh, v);
-      } else {
-        atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)col * a.dDsp, v);
-      }
-    }
-  }
+#ifdef OMK_PHASE_PROF
+  if (prof && lane == 0)
+    for (int i = 0; i < 10; i++) a.prof[wave * 10 + i] = pt[i];
+#endif
   if (a.fin) {
     const float extra = a.fin_extra_decay ? expf(a.dtp[((int64_t)b * a.H + hcur) * a.L] * Ah) : 1.f;
 #pragma unroll
@@ -773,8 +771,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true) || !src_ok16(g.Z, false)) return OMK_EUNSUPPORTED;
   if (g.out_dt != OMK_BF16 || ((uintptr_t)g.out & 15) || g.osb % 8 || g.osl % 8 || g.osh % 8) return OMK_EUNSUPPORTED;
   if (g.outx && ((uintptr_t)g.outx & 15)) return OMK_EUNSUPPORTED;
-  if (g.mode == GS_DX && g.XE.p && (!src_ok16(g.XE, true) || !src_ok16(g.YE, true))) return OMK_EUNSUPPORTED;
-  if (g.mode == GS_DX && g.dD && !g.XE.p) return OMK_EUNSUPPORTED;
+  if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (dry) return OMK_OK;
   dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
   const size_t smem = sizeof(SmemA);

@@ -46,6 +46,7 @@ struct GScan {
   // DC/DB (MFMA): forward-state checkpoints at every chunk end, written by the dC scan in MFMA fragment order
   // (bf16 pairs) and read back by the dB scan, which emits the exact decay-gradient restart values bnd (B, H, nC + 1)
   void* ckpt; float* bnd;
+  unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
 };
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);
