@@ -21,7 +21,7 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float silu_grad(float pre) {
-  float s = sigmoid_f(pre);
+  float s = sigmoid_fast(pre);
   return s * (1.f + pre * (1.f - s));
 }
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
       float acc = bias[i];
 #pragma unroll
       for (int k = 0; k < W; k++) acc += w[k][i] * win[k][i];
-      o[i] = a.silu ? silu_f(acc) : acc;
+      o[i] = a.silu ? silu_fast(acc) : acc;
     }
     store_vec<T, VEC>(out + (int64_t)l * a.osl, o);
   }
@@ -129,13 +129,17 @@ __global__ void conv1d_final_states_kernel(ConvArgs a) {
 //   dw[k] = sum_{b,l} dpre[l] xpad[l+k] ; db = sum dpre ; dinit[j] = sum_k w[k] dpre[j - k] (j-k >= 0, < L)
 // channel-last vectorised: thread = (b, tile of TL tokens, 8 channels); dw/db reduced with one atomic per thread.
 // ---------------------------------------------------------------------------------------------------------
+// block = 64 channel vectors (one wave row of 1 KB per token) x 4 token strips of TL tokens; the four strips fold
+// their dw / db partials through LDS so each (channel, tap) costs one global atomic per block.
 template <class T, int VEC, int TL, int W>
 __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
-  const int CV = a.C / VEC, NT = (a.L + TL - 1) / TL;
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (int64_t)a.B * NT * CV) return;
-  const int cv = (int)(g % CV), tile = (int)((g / CV) % NT), b = (int)(g / ((int64_t)CV * NT));
-  const int c0 = cv * VEC, l0 = tile * TL;
+  __shared__ float sred[4][64][VEC * (W + 1)];
+  const int CV = a.C / VEC, NT4 = (a.L + 4 * TL - 1) / (4 * TL), CVB = (CV + 63) / 64;
+  const int cvb = blockIdx.x % CVB, t4 = (blockIdx.x / CVB) % NT4, b = blockIdx.x / (CVB * NT4);
+  const int cvl = threadIdx.x & 63, strip = threadIdx.x >> 6;
+  const int cv = cvb * 64 + cvl;
+  const bool cvok = cv < CV;
+  const int c0 = (cvok ? cv : 0) * VEC, l0 = (t4 * 4 + strip) * TL;
   const T* x = (const T*)a.x;
   const T* dout = (const T*)a.dout + (int64_t)b * a.dosb + c0;
   T* dx = (T*)a.dx + (int64_t)b * a.dxsb + c0;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
       dwacc[k][i] = 0.f;
     }
   }
-  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
+  const int lend = !cvok ? l0 : ((l0 + TL < a.L) ? l0 + TL : a.L);   // idle lanes (cv out of range) do zero tokens
   // walking p = l0 .. lend+W-2: xw[k] = xpad at position p-(W-1)+k, dp[k] = dpre[p-(W-1)+k];
   // at step p dpre[p] becomes known and dx[p-(W-1)] = sum_k w[k] dpre[p-k] = sum_k w[k] dp[W-1-k] is complete.
   float xw[W][VEC], dp[W][VEC];
@@ -209,9 +213,22 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
-    if (a.db) atomic_add_f32(a.db + c0 + i, dbacc[i]);
+    sred[strip][cvl][i * (W + 1) + W] = dbacc[i];
 #pragma unroll
-    for (int k = 0; k < W; k++) atomic_add_f32(a.dw + (int64_t)(c0 + i) * W + k, dwacc[k][i]);
+    for (int k = 0; k < W; k++) sred[strip][cvl][i * (W + 1) + k] = dwacc[k][i];
+  }
+  block_sync();
+  if (strip == 0 && cvok) {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+#pragma unroll
+      for (int k = 0; k <= W; k++) {
+        const int j = i * (W + 1) + k;
+        const float v = sred[0][cvl][j] + sred[1][cvl][j] + sred[2][cvl][j] + sred[3][cvl][j];
+        if (k < W) atomic_add_f32(a.dw + (int64_t)(c0 + i) * W + k, v);
+        else if (a.db) atomic_add_f32(a.db + c0 + i, v);
+      }
+    }
   }
 }
 
@@ -391,9 +408,9 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
   const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->dout, a.C) && cl_fast_ok(p->dx, a.C);
   dim3 block(256);
   if (fast) {
-    constexpr int TL = 128;
-    int64_t n = (int64_t)a.B * ((a.L + TL - 1) / TL) * (a.C / 8);
-    dim3 grid((unsigned)((n + 255) / 256));
+    constexpr int TL = 32;
+    const int CVB = (a.C / 8 + 63) / 64, NT4 = (a.L + 4 * TL - 1) / (4 * TL);
+    dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB));
 #define CONV_BWD_W(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 4>), grid, block, 0, stream, a); \
       else if (a.W == 3) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 3>), grid, block, 0, stream, a); \
       else OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, 8, TL, 2>), grid, block, 0, stream, a); } while (0)

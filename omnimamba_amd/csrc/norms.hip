@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
           if (!z) zv[c][i] = 0.f;
-          gv[c][i] = (z && !a.norm_before_gate) ? xv[c][i] * silu_f(zv[c][i]) : xv[c][i];
+          gv[c][i] = (z && !a.norm_before_gate) ? xv[c][i] * silu_fast(zv[c][i]) : xv[c][i];
           s2 += gv[c][i] * gv[c][i];
         }
       } else {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
           float dyv = wdy[c][i];
           const float xhat = gv[c][i] * rstd;
           if (z && a.norm_before_gate) {   // y = xhat*w*silu(z): dz from dy*xhat*w, the norm sees dy*silu(z)
-            const float sig = sigmoid_f(zv[c][i]);
+            const float sig = sigmoid_fast(zv[c][i]);
             const float sg = zv[c][i] * sig;
             zv[c][i] = dyv * xhat * w * sig * (1.f + zv[c][i] * (1.f - sig));   // finished dz
             dyv *= sg;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
         for (int i = 0; i < VEC; i++) {
           const float dg = (wdy[c][i] - gv[c][i] * c1) * rstd;   // grad wrt the normalised input
           if (z && !a.norm_before_gate) {
-            const float sig = sigmoid_f(zv[c][i]);
+            const float sig = sigmoid_fast(zv[c][i]);
             ox[i] = dg * zv[c][i] * sig;
             oz[i] = dg * xv[c][i] * sig * (1.f + zv[c][i] * (1.f - sig));
           } else {

@@ -160,7 +160,8 @@ __device__ __forceinline__ uint64_t clock64_() { return 0; }
 __device__ __forceinline__ uint64_t clock64_() { return __builtin_readcyclecounter(); }
 #endif
 constexpr float LOG2E = 1.4426950408889634f;
-__device__ __forceinline__ float silu_fast(float x) { return x * rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
+__device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }

@@ -34,6 +34,7 @@ struct SmemA {
   float O[2][QC * LDG];
   float cs[2][QC], ecs[2][QC], w[2][QC], ws[2][QC];
   float dtl[2][2][QC];       // [chunk parity][head][row]: dt' of the token itself
+  float dta[2][2][QC];       // dt' driving the row's decay (the next token's in reverse scans)
   float Dv[2][64];           // D of the two heads, per column (broadcast when D is (H))
 };
 
@@ -92,32 +93,47 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
     pq[r] = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh + (int64_t)tk[r] * a.Q.sl + cs8;
     pu[r] = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)(h0 + r) * a.U.sh + (int64_t)tu * a.U.sl + (tid & 7) * 8;
   }
-  const float* pdt = a.dtp + ((int64_t)b * a.H + h0 + ((tid >> 6) & 1)) * a.L + tdt;
   const int64_t dK = (int64_t)tstep * a.K.sl, dQ = (int64_t)tstep * a.Q.sl, dU = (int64_t)tstep * a.U.sl;
+  // Loads are UNCONDITIONAL (a runtime-predicated load makes hipcc branch around it and wait vmcnt(0) at the join,
+  // which serialised every chunk behind a full HBM round trip): out-of-range rows read a clamped in-range address and
+  // are zeroed when the registers are committed to LDS.
+  const uint16_t* safeK = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
+  const uint16_t* safeQ = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
+  const uint16_t* safeU = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h0 * a.U.sh;
+  const float* dtrow = a.dtp + ((int64_t)b * a.H + h0 + ((tid >> 6) & 1)) * a.L;
   int cload = 0;   // chunk the staging registers currently point at
+  bool okk[2] = {false, false}, oku = false;
+  float rda = 0.f;   // dt' that drives the decay of the row (reverse scans: the NEXT token's)
   auto prefetch = [&]() {
     const bool in = cload < nC;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const bool ok = in && tk[r] < a.L;
-      rk[r] = ok ? ld16(pk[r]) : u32x4{0, 0, 0, 0};
-      rq[r] = ok ? ld16(pq[r]) : u32x4{0, 0, 0, 0};
-      ru[r] = (in && tu < a.L) ? ld16(pu[r]) : u32x4{0, 0, 0, 0};
+      okk[r] = in && tk[r] < a.L;
+      rk[r] = ld16(okk[r] ? pk[r] : safeK);
+      rq[r] = ld16(okk[r] ? pq[r] : safeQ);
+      oku = in && tu < a.L;
+      ru[r] = ld16(oku ? pu[r] : safeU);
       pk[r] += dK; pq[r] += dQ; pu[r] += dU; tk[r] += tstep;
     }
-    if (tid < 128) rdt = (in && tdt < a.L) ? *pdt : 0.f;
-    pdt += tstep; tdt += tstep; tu += tstep;
+    const bool okd = in && tdt < a.L;
+    const int ta = rev ? tdt + 1 : tdt;
+    rdt = dtrow[okd ? tdt : 0];
+    rda = dtrow[(okd && ta < a.L) ? ta : 0];
+    if (!okd) rdt = 0.f;
+    if (!(okd && ta < a.L)) rda = 0.f;
+    tdt += tstep; tu += tstep;
     cload++;
   };
   auto commit = [&](int par) {   // registers -> LDS tiles (dt' goes to the parity buffer of the chunk it belongs to)
+    const u32x4 zero4 = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int seg = tid + 512 * r, row = seg >> 4, cs8 = (seg & 15) * 8;
-      st16(&sm.K[row * LDK + cs8], rk[r]);
-      st16(&sm.Qm[row * LDK + cs8], rq[r]);
-      st16(&sm.U[r][(tid >> 3) * LDU + (tid & 7) * 8], ru[r]);
+      st16(&sm.K[row * LDK + cs8], okk[r] ? rk[r] : zero4);
+      st16(&sm.Qm[row * LDK + cs8], okk[r] ? rq[r] : zero4);
+      st16(&sm.U[r][(tid >> 3) * LDU + (tid & 7) * 8], oku ? ru[r] : zero4);
     }
-    if (tid < 128) sm.dtl[par][tid >> 6][tid & 63] = rdt;
+    if (tid < 128) { sm.dtl[par][tid >> 6][tid & 63] = rdt; sm.dta[par][tid >> 6][tid & 63] = rda; }
   };
 
   // ---- running state: S^T tiles [k = 64 wi + 32 kt + row][u = 32 wj + l31], head h0 + hh
@@ -183,10 +199,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
       const int t = rev ? id * QC + (QC - 1) - lane : id * QC + lane;
       const bool ok = t < a.L;
       const float d = sm.dtl[c & 1][hh][lane];
-      float la;
-      if (rev) la = (ok && t + 1 < a.L) ? a.dtp[((int64_t)b * a.H + hcur) * a.L + t + 1] * Ah2 : 0.f;
-      else la = ok ? d * Ah2 : 0.f;
-      float cs = la;
+      float cs = sm.dta[c & 1][hh][lane] * Ah2;   // zero for rows past the end
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         float o = shfl_up(cs, off);
@@ -308,7 +321,10 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
     // epilogue operands (issued here so they are not live across the MFMA section) straight from HBM into registers
     u32x4 ez[2];
 #pragma unroll
-    for (int r = 0; r < 2; r++) ez[r] = (MODE == GS_Y && pz[r] && tep < a.L) ? ld16(pz[r]) : u32x4{0, 0, 0, 0};
+    for (int r = 0; r < 2; r++) {
+      ez[r] = u32x4{0, 0, 0, 0};
+      if (MODE == GS_Y && a.Z.p) ez[r] = ld16(tep < a.L ? pz[r] : (const uint16_t*)a.Z.p);   // wave-uniform branch, unconditional load
+    }
     publish_state();
     if (roleD) {
 #pragma unroll
@@ -630,15 +646,29 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
     if (has_x4) {
       // per-token scalar of THIS head: sum_n X4[l][n] * O_h[l][n] over this wave's 64 columns, folded over the 32 lanes
       // of each half; the two column halves (wj) meet in LDS.  (X4 is read before B2: commit() rewrites it after B4.)
+      float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
-        float pv = 0.f;
+        pv[r] = 0.f;
 #pragma unroll
         for (int ut = 0; ut < 2; ut++)
-          pv += bf16_to_f32(sm.X4[l * LDK + 64 * wj + 32 * ut + l31]) * (accD[ut][r] + sm.ecs[hh][l] * accO[ut][r]);
-        pv += shfl_xor(pv, 1); pv += shfl_xor(pv, 2); pv += shfl_xor(pv, 4); pv += shfl_xor(pv, 8); pv += shfl_xor(pv, 16);
-        if (l31 == 0) sm.rdot[wj][hh][l] = pv;
+          pv[r] += bf16_to_f32(sm.X4[l * LDK + 64 * wj + 32 * ut + l31]) * (accD[ut][r] + sm.ecs[hh][l] * accO[ut][r]);
+      }
+      // 16 row sums over the 32 lanes of each half as a halving butterfly: 8 + 4 + 2 + 1 + 1 = 16 shuffles instead of 80
+      const bool b4 = (l31 & 16) != 0, b3 = (l31 & 8) != 0, b2 = (l31 & 4) != 0, b1 = (l31 & 2) != 0;
+      float q8[8], q4[4], q2[2], q1;
+#pragma unroll
+      for (int i = 0; i < 8; i++) q8[i] = (b4 ? pv[i + 8] : pv[i]) + shfl_xor(b4 ? pv[i] : pv[i + 8], 16);
+#pragma unroll
+      for (int i = 0; i < 4; i++) q4[i] = (b3 ? q8[i + 4] : q8[i]) + shfl_xor(b3 ? q8[i] : q8[i + 4], 8);
+#pragma unroll
+      for (int i = 0; i < 2; i++) q2[i] = (b2 ? q4[i + 2] : q4[i]) + shfl_xor(b2 ? q4[i] : q4[i + 2], 4);
+      q1 = (b1 ? q2[1] : q2[0]) + shfl_xor(b1 ? q2[0] : q2[1], 2);
+      q1 += shfl_xor(q1, 1);
+      if ((l31 & 1) == 0) {
+        const int rr = (b1 ? 1 : 0) + (b2 ? 2 : 0) + (b3 ? 4 : 0) + (b4 ? 8 : 0);
+        sm.rdot[wj][hh][32 * wi + (rr & 3) + 8 * (rr >> 2) + 4 * h32] = q1;
       }
     }
     block_sync();   // B2: G, S_in and the tiles of this chunk are no longer read
