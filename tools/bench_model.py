@@ -1,0 +1,101 @@
+"""BASELINE.json configs[2..4] on the synthetic OmniMamba-1.3B stack (random init, synthetic data), 1 GPU or N GPUs via
+torch.distributed.run:   python tools/bench_model.py [decode|train] [--batch B] [--seqlen L] [--steps K]
+Prints one JSON line per workload (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omnimamba_amd.generation import decode  # noqa: E402
+from omnimamba_amd.stack import OmniMambaLM, StackConfig  # noqa: E402
+from omnimamba_amd.train import Stage2Step, TrainConfig, init_distributed, synthetic_batch, wrap_ddp  # noqa: E402
+
+
+def bench_decode(args, dev):
+    """configs[2]: T2I autoregressive decode, 72-token prompt + 256 image tokens, greedy, hipGraph replay, fp32 weights
+    (the reference inference scripts never cast the model: scripts/inference_t2i.py:21-26)."""
+    torch.manual_seed(0)
+    cfg = StackConfig.omnimamba_1_3b()
+    model = OmniMambaLM(cfg, device=dev, dtype=torch.float32).eval()
+    B, P, new = args.batch, 72, 256
+    ids = torch.zeros(B, P, dtype=torch.long, device=dev)
+    emb = torch.randn(B, P, cfg.d_model, device=dev)
+    out = {}
+    for cg in (True, False) if args.eager_too else (True,):
+        decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=cg)          # warm-up (captures the graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seq = decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=cg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert seq.shape == (B, P + new)
+        out["graph" if cg else "eager"] = dt
+    n_param = sum(p.numel() for p in model.parameters())
+    ms_tok = out["graph"] / new * 1e3
+    print(json.dumps({"workload": "OmniMamba-1.3B T2I decode (configs[2])", "batch": B, "prompt": P, "new_tokens": new,
+                      "ms_per_token": round(ms_tok, 3), "tokens_per_s": round(B * new / out["graph"], 1),
+                      "weights_GBs": round(n_param * 4 / (ms_tok * 1e-3) / 1e9, 1), "params": n_param, "dtype": "f32",
+                      "eager_ms_per_token": round(out["eager"] / new * 1e3, 3) if "eager" in out else None}), flush=True)
+
+
+def bench_train(args, dev, rank, world):
+    """configs[3]/[4]-style Stage-2 step: one T2I + one MMU forward, one backward, clip, AdamW; bf16 autocast over fp32
+    master weights; DDP over RCCL when world > 1."""
+    torch.manual_seed(0)
+    L = args.seqlen
+    cfg = StackConfig.omnimamba_1_3b(t2i_positions=max(L, 329), mmu_positions=max(L, 1500))
+    model = OmniMambaLM(cfg, device=dev, dtype=torch.float32)
+    model.set_stage(args.stage)
+    tc = TrainConfig()
+    net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
+    step = Stage2Step(model, tc, ddp_model=net)
+    batch = synthetic_batch(cfg, args.batch, L, dev, torch.bfloat16, rank=rank)
+    for _ in range(args.warmup):
+        step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = (time.perf_counter() - t0) / args.steps
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        print(json.dumps({"workload": f"OmniMamba-1.3B stage-2 step ({args.stage}), 2 tasks x L={L}", "n_gpus": world,
+                          "batch_per_gpu": args.batch, "ms_per_step": round(dt * 1e3, 2),
+                          "tokens_per_s": round(world * 2 * args.batch * L / dt, 1), "trainable_params": trainable,
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "dtype": "bf16 autocast"}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["decode", "train"])
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--seqlen", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--stage", default="finetune")
+    ap.add_argument("--eager-too", action="store_true")
+    args = ap.parse_args()
+    rank, local, world = init_distributed()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if args.what == "decode":
+        bench_decode(args, dev)
+    else:
+        bench_train(args, dev, rank, world)
+
+
+if __name__ == "__main__":
+    main()
