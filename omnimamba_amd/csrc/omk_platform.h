@@ -67,7 +67,14 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 #endif
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef OMK_EMU
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#else
+  typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+  const pk_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pk_bf16x2));   // one v_cvt_pk_bf16_f32 (RNE)
+#endif
 }
 
 // ---- wave-level primitives (wave = 64 lanes on CDNA) --------------------------------------------------
@@ -149,10 +156,39 @@ template <class T> __device__ __forceinline__ T wave_sum(T v) {
 // hardware transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp) for the inner loops of the MFMA kernels
 #ifdef OMK_EMU
 __device__ __forceinline__ float exp2_fast(float x) { return exp2f(x); }
+__device__ __forceinline__ float log2_fast(float x) { return log2f(x); }   // log2(0) = -inf on both builds
 __device__ __forceinline__ float rcp_fast(float x) { return 1.f / x; }
+__device__ __forceinline__ int uniform_i(int v) { return v; }
+// inclusive prefix sum over the 64 lanes of a wave / broadcast of one lane
+__device__ __forceinline__ float wave_incl_scan_add(float v) {
+  for (int off = 1; off < 64; off <<= 1) {
+    float o = shfl_up(v, off);
+    if (lane_id() >= off) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_read_lane(float v, int l) { return shfl(v, l); }
 #else
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 = log2
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }   // wave-uniform value -> SGPR
+// DPP Hillis-Steele inside rows of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals (no LDS traffic)
+__device__ __forceinline__ float wave_incl_scan_add(float v) {
+#define OMK_DPP_ADD(ctrl, rowmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, false))
+  OMK_DPP_ADD(0x111, 0xf);   // row_shr:1
+  OMK_DPP_ADD(0x112, 0xf);   // row_shr:2
+  OMK_DPP_ADD(0x114, 0xf);   // row_shr:4
+  OMK_DPP_ADD(0x118, 0xf);   // row_shr:8
+  OMK_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  OMK_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef OMK_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ float wave_read_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 #endif
 #ifdef OMK_EMU
 __device__ __forceinline__ uint64_t clock64_() { return 0; }

@@ -398,6 +398,671 @@ __global__ __launch_bounds__(512) void ssd_mfma_a_kernel(GScan a) {
 }
 
 // =========================================================================================================
+// class A, version 2: ONE head per 256-thread workgroup (4 waves), 80 KB of LDS so that TWO workgroups share a CU and
+// run out of phase: one workgroup's barrier / LDS-latency bubbles are filled by the other's MFMA and VALU work
+// (version 1 keeps 8 waves of one workgroup in lock-step; PMC: 44 % of its wave cycles are waits).  Each wave owns a
+// complete output tile O[32 wi ..][32 wj ..] (M.U and Q.S_in chains in the same accumulators' sum) and writes it to
+// HBM straight from the MFMA register layout -- no LDS round trip for O -- and the two state tiles
+// S^T[64 wi + 32 kt ..][32 wj ..].  G is stored unpadded with a 16-byte XOR swizzle to fit the LDS budget.
+// =========================================================================================================
+struct SmemA2 {
+  uint16_t K[QC * LDK];
+  uint16_t Qm[QC * LDK];
+  uint16_t U[QC * LDU];
+  float G[QC * 64];        // element (l, s) at l*64 + ((((s >> 2) ^ (l & 15)) << 2) | (s & 3))
+  uint16_t S[64 * LDK];    // [u][k] bf16 copy of S_in
+  float cs[QC], ecs[QC], w[QC], ws[QC];
+  float dtl[2][QC], dta[2][QC];
+  float Dv[64];
+};
+static_assert(sizeof(SmemA2) <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void ssd_mfma_a2_kernel(GScan a) {
+  OMK_DYN_SMEM(smem_raw);
+  SmemA2& sm = *reinterpret_cast<SmemA2*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int h32 = lane >> 5, l31 = lane & 31, g16 = lane >> 4, t16 = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int g = h / (a.H / a.G);
+  const int nC = (a.L + QC - 1) / QC;
+  const bool rev = a.reverse != 0;
+  const int rowdir = rev ? -1 : 1;
+
+  // ---- staging: K, Q four 16-byte segments per thread (rows row0 + 16 r), U two (rows rowu + 32 r)
+  const int rowk = tid >> 4, ck8 = (tid & 15) * 8, rowu = tid >> 3, cu8 = (tid & 7) * 8;
+  const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh + ck8;
+  const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh + ck8;
+  const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh + cu8;
+  const float* dtrow = a.dtp + ((int64_t)b * a.H + h) * a.L;
+  u32x4 rk[4], rq[4], ru[2];
+  float rdt = 0.f, rda = 0.f;
+  int tbase = 0;   // token of LDS row 0 of the chunk held in the staging registers
+  auto chunk_base = [&](int c) -> int { const int id = rev ? nC - 1 - c : c; return rev ? id * QC + (QC - 1) : id * QC; };
+  auto prefetch = [&](int c) {   // unconditional loads from clamped addresses; rows past the end are zeroed at commit
+    tbase = c < nC ? chunk_base(c) : -(1 << 28);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int t = tbase + rowdir * (rowk + 16 * r);
+      const int tc = (t >= 0 && t < a.L) ? t : 0;
+      rk[r] = ld16(Kb + (int64_t)tc * a.K.sl);
+      rq[r] = ld16(Qb + (int64_t)tc * a.Q.sl);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int t = tbase + rowdir * (rowu + 32 * r);
+      const int tc = (t >= 0 && t < a.L) ? t : 0;
+      ru[r] = ld16(Ub + (int64_t)tc * a.U.sl);
+    }
+    {
+      const int t = tbase + rowdir * (tid & 63);
+      const bool okd = t >= 0 && t < a.L;
+      const int ta = rev ? t + 1 : t;
+      const bool oka = okd && ta < a.L;
+      rdt = dtrow[okd ? t : 0];
+      rda = dtrow[oka ? ta : 0];
+      if (!okd) rdt = 0.f;
+      if (!oka) rda = 0.f;
+    }
+  };
+  auto commit = [&](int par) {
+    const u32x4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int t = tbase + rowdir * (rowk + 16 * r);
+      const bool ok = t >= 0 && t < a.L;
+      st16(&sm.K[(rowk + 16 * r) * LDK + ck8], ok ? rk[r] : zero4);
+      st16(&sm.Qm[(rowk + 16 * r) * LDK + ck8], ok ? rq[r] : zero4);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int t = tbase + rowdir * (rowu + 32 * r);
+      const bool ok = t >= 0 && t < a.L;
+      st16(&sm.U[(rowu + 32 * r) * LDU + cu8], ok ? ru[r] : zero4);
+    }
+    if (tid < 64) { sm.dtl[par][tid] = rdt; sm.dta[par][tid] = rda; }
+  };
+
+  // ---- running state
+  f32x16 accS[2];
+  const float Ah = a.A[h];
+  const float Ah2 = Ah * LOG2E;
+#pragma unroll
+  for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = 0.f;
+      if (a.init) {
+        const int k = 64 * wi + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * wj + l31;
+        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+      accS[kt][r] = v;
+    }
+  auto publish_state = [&]() {
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+      for (int rq4 = 0; rq4 < 4; rq4++) {
+        const int k = 64 * wi + 32 * kt + 8 * rq4 + 4 * h32;
+        u32x2 v;
+        v[0] = pack_bf16x2(accS[kt][4 * rq4 + 0], accS[kt][4 * rq4 + 1]);
+        v[1] = pack_bf16x2(accS[kt][4 * rq4 + 2], accS[kt][4 * rq4 + 3]);
+        *reinterpret_cast<u32x2*>(&sm.S[(32 * wj + l31) * LDK + k]) = v;
+      }
+  };
+
+  prefetch(0);
+  commit(0);
+  publish_state();
+  if (tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
+  block_sync();
+  const float Du = sm.Dv[32 * wj + l31];   // this lane's output column never changes
+  uint16_t* outp = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh + 32 * wj + l31;
+  uint16_t* outxp = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh + 32 * wj + l31 : nullptr;
+  const uint16_t* zp = (MODE == GS_Y && a.Z.p) ? (const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)h * a.Z.sh + 32 * wj + l31 : nullptr;
+
+#ifdef OMK_PHASE_PROF   // developer build (tools/phase_prof.py): s_memtime deltas per phase, workgroup 0
+  uint64_t pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+#define PT2(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+  uint64_t tprev = prof ? clock64_() : 0;
+#else
+#define PT2(i) do { } while (0)
+#endif
+  for (int c = 0; c < nC; c++) {
+    const int tb0 = chunk_base(c);
+    prefetch(c + 1);
+    PT2(0);
+    if (wave == 0) {   // scalars: lanes = tokens
+      const int t = tb0 + rowdir * lane;
+      const bool ok = t >= 0 && t < a.L;
+      const float d = sm.dtl[c & 1][lane];
+      float cs = sm.dta[c & 1][lane] * Ah2;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        float o = shfl_up(cs, off);
+        if (lane >= off) cs += o;
+      }
+      const float cs_end = shfl(cs, 63);
+      const float wv = ok ? (a.w_is_dt ? d : 1.f) : 0.f;
+      sm.cs[lane] = cs;
+      sm.ecs[lane] = exp2_fast(cs);
+      sm.w[lane] = wv;
+      sm.ws[lane] = wv * exp2_fast(cs_end - cs);
+    }
+    for (int tile = wave; tile < 10; tile += 4) {   // G^T = K Q^T, lower triangle of 16x16 tiles
+      int ta, tb;
+      if (tile < 1) { tb = 0; ta = tile; } else if (tile < 3) { tb = 1; ta = tile - 1; } else if (tile < 6) { tb = 2; ta = tile - 3; } else { tb = 3; ta = tile - 6; }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        s16x8 fa = as_s16x8(ld16(&sm.K[(16 * ta + t16) * LDK + 32 * kk + 8 * g16]));
+        s16x8 fb = as_s16x8(ld16(&sm.Qm[(16 * tb + t16) * LDK + 32 * kk + 8 * g16]));
+        acc = mfma16x16x32_bf16(fa, fb, acc);
+      }
+      const int l = 16 * tb + t16;
+      *reinterpret_cast<f32x4*>(&sm.G[l * 64 + (((4 * ta + g16) ^ (l & 15)) << 2)]) = acc;
+    }
+    PT2(1);
+    block_sync();   // B1
+    PT2(2);
+
+    f32x16 accD, accO;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { accD[r] = 0.f; accO[r] = 0.f; }
+    {
+      const int l = 32 * wi + l31;
+      const float cs_l = sm.cs[l];
+      const int nks = 2 * (wi + 1);
+      for (int ks = 0; ks < nks; ks++) {
+        const int s0 = 16 * ks + 8 * h32;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&sm.G[l * 64 + ((((s0 >> 2)) ^ (l & 15)) << 2)]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(&sm.G[l * 64 + ((((s0 >> 2) + 1) ^ (l & 15)) << 2)]);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sm.cs[s0]);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sm.cs[s0 + 4]);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(&sm.w[s0]);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(&sm.w[s0 + 4]);
+        u32x4 mp, ml;   // M as hi + lo bf16 (the rounding point that dominates the error of y)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const f32x2 gv = e2 < 2 ? f32x2{g0[2 * e2], g0[2 * e2 + 1]} : f32x2{g1[2 * e2 - 4], g1[2 * e2 - 3]};
+          const f32x2 cv = e2 < 2 ? f32x2{c0[2 * e2], c0[2 * e2 + 1]} : f32x2{c1[2 * e2 - 4], c1[2 * e2 - 3]};
+          const f32x2 wv = e2 < 2 ? f32x2{w0[2 * e2], w0[2 * e2 + 1]} : f32x2{w1[2 * e2 - 4], w1[2 * e2 - 3]};
+          const f32x2 dd = f32x2{cs_l, cs_l} - cv;
+          f32x2 v = gv * wv * f32x2{exp2_fast(dd[0]), exp2_fast(dd[1])};
+          const int s = s0 + 2 * e2;
+          v[0] = (s <= l) ? v[0] : 0.f;
+          v[1] = (s + 1 <= l) ? v[1] : 0.f;
+          const uint32_t hi = pack_bf16x2(v[0], v[1]);
+          mp[e2] = hi;
+          ml[e2] = pack_bf16x2(v[0] - bf_lo(hi), v[1] - bf_hi(hi));
+        }
+        s16x8 fb = tr_frag(sm.U, LDU, 16 * ks, 32 * wj, lane);
+        accD = mfma32x32x16_bf16(as_s16x8(mp), fb, accD);
+        accD = mfma32x32x16_bf16(as_s16x8(ml), fb, accD);
+      }
+    }
+    PT2(3);
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      s16x8 fa = as_s16x8(ld16(&sm.Qm[(32 * wi + l31) * LDK + 16 * ks + 8 * h32]));
+      s16x8 fb = as_s16x8(ld16(&sm.S[(32 * wj + l31) * LDK + 16 * ks + 8 * h32]));
+      accO = mfma32x32x16_bf16(fa, fb, accO);
+    }
+    PT2(4);
+    // O = M.U + exp2(cs_l) Q.S_in + D u : everything this lane needs for its 16 outputs, taken before the tiles die
+    float ov[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+      const float uu = bf16_to_f32(sm.U[l * LDU + 32 * wj + l31]);
+      float o = accD[r] + sm.ecs[l] * accO[r];
+      if (MODE == GS_DX) o *= sm.dtl[c & 1][l];
+      ov[r] = o + Du * uu;
+    }
+    PT2(5);
+    {   // state update: S^T[k][u] = exp(cs_end) S^T + sum_l K^T[k][l] (ws_l U[l][u])
+      const float dec = sm.ecs[QC - 1];
+#pragma unroll
+      for (int kt = 0; kt < 2; kt++) accS[kt] *= dec;
+#pragma unroll
+      for (int ls = 0; ls < 4; ls++) {
+        s16x8 fu = tr_frag(sm.U, LDU, 16 * ls, 32 * wj, lane);
+        const int lb = 16 * ls + 8 * h32;
+        const f32x4 s0v = *reinterpret_cast<const f32x4*>(&sm.ws[lb]);
+        const f32x4 s1v = *reinterpret_cast<const f32x4*>(&sm.ws[lb + 4]);
+        u32x4 up;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const f32x2 uv = {bf16_to_f32((uint16_t)fu[2 * e2]), bf16_to_f32((uint16_t)fu[2 * e2 + 1])};
+          const f32x2 sv = e2 < 2 ? f32x2{s0v[2 * e2], s0v[2 * e2 + 1]} : f32x2{s1v[2 * e2 - 4], s1v[2 * e2 - 3]};
+          const f32x2 pr = uv * sv;
+          up[e2] = pack_bf16x2(pr[0], pr[1]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+          s16x8 fk = tr_frag(sm.K, LDK, 16 * ls, 64 * wi + 32 * kt, lane);
+          accS[kt] = mfma32x32x16_bf16(fk, as_s16x8(up), accS[kt]);
+        }
+      }
+    }
+    PT2(6);
+    block_sync();   // B2: nobody reads S_in, G or this chunk's tiles any more
+    PT2(7);
+    publish_state();
+    commit((c + 1) & 1);
+    PT2(8);
+    // epilogue straight from the MFMA layout: for each register, 32 lanes cover 64 contiguous bytes of one output row
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int l = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h32;
+      const int t = tb0 + rowdir * l;
+      if (t >= 0 && t < a.L) {
+        float v = ov[r];
+        if (MODE == GS_Y) {
+          if (outxp) outxp[(int64_t)t * a.osl] = f32_to_bf16(v);
+          if (zp) v *= silu_fast(bf16_to_f32(zp[(int64_t)t * a.Z.sl]));
+        }
+        outp[(int64_t)t * a.osl] = f32_to_bf16(v);
+      }
+    }
+    PT2(9);
+    block_sync();   // B3: next chunk's tiles and the new bf16 state are visible
+    PT2(10);
+  }
+#ifdef OMK_PHASE_PROF
+  if (prof && lane == 0)
+    for (int i = 0; i < 12; i++) a.prof[wave * 12 + i] = pt[i];
+#endif
+  if (a.fin) {
+    const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 64 * wi + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * wj + l31;
+        a.fin[(int64_t)b * a.fsb + (int64_t)h * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = accS[kt][r] * extra;
+      }
+  }
+}
+
+// =========================================================================================================
+// class A, version 3 ("row strips"): one head per 256-thread workgroup, two workgroups per CU.
+//
+// Wave w owns the output rows l in [16 w, 16 w + 16) of every 64-token chunk (all 64 columns) and the state rows
+// k in [32 w, 32 w + 32) (all 64 columns).  What that buys over versions 1 / 2:
+//   * G never leaves registers.  G^T[s][l] = K_s . Q_l comes out of the 16x16x32 MFMA with the lane's own l in every
+//     register; the MFMA contraction index may be permuted freely as long as both operands agree, so the two G tiles of
+//     a 32-wide s block ARE the A-operand fragment of M (after the decay/mask/bf16 hi+lo split), and U is fetched with
+//     the matching permuted transpose reads.  No fp32 G tile in LDS, no barrier between G and M.
+//   * M is built exactly once per chunk (versions 1 / 2 built it in two waves).
+//   * Q is never staged: its MFMA fragments (rows of the wave's strip) are loaded from global memory one chunk ahead
+//     and serve both G (as B operand) and Q . S_in (as A operand).
+//   * O = exp2(cs_l) (Q . S_in) + M . U accumulates in ONE register tile per wave and goes to HBM from registers.
+//   * K / U tiles are double buffered: two barriers per chunk (after the S_in reads, after the S_out publish).
+// =========================================================================================================
+// LDS layouts of version 3: unpadded rows, the 16-byte segment index XOR-ed with a function of the row so that every
+// access pattern of the kernel is bank-conflict free under the gfx950 lane groups (MI355X_MICROARCH.md, LDS):
+//   K / S tiles (256 B rows): seg ^ swzK(row).  ds_read_b128 "row t16, segment 4 c + g16" (lane groups
+//     {0-3,12-15,20-27}, ...) needs swzK bijective on row & 15 with swzK({4..11}) closed under ^1; the transpose reads
+//     "4 rows x 4 segments per half wave" need swzK(row) >> 2 distinct over 4 consecutive rows.
+//   U tile (128 B rows, two rows per 256 B bank row): seg ^ swzU(row), found the same way for the three U patterns
+//     (8 rows x 2 segments, 4 rows x 4 segments, 16 rows x 1 segment).
+__device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
+__device__ __forceinline__ int swzU(int r) { return ((r & 2) << 1) | ((r >> 1) & 2) | ((r >> 3) & 1); }
+__device__ __forceinline__ int kx3(int row, int col) { return row * 128 + ((((col >> 3) ^ swzK(row)) << 3) | (col & 7)); }
+__device__ __forceinline__ int ux3(int row, int col) { return row * 64 + ((((col >> 3) ^ swzU(row)) << 3) | (col & 7)); }
+// 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
+// rows r0 + 8 h32 + 4 m + {0..3}, column c0 + (lane & 31)
+template <bool KT>
+__device__ __forceinline__ s16x8 tr_frag3(const uint16_t* tile, int r0, int c0, int lane) {
+  const int t16 = lane & 15, g16 = lane >> 4, h32 = lane >> 5;
+  const int row = r0 + 8 * h32 + (t16 >> 2), col = c0 + 16 * (g16 & 1) + 4 * (t16 & 3);
+  const s16x4 a = lds_read_tr16_b64(tile + (KT ? kx3(row, col) : ux3(row, col)));
+  const s16x4 b = lds_read_tr16_b64(tile + (KT ? kx3(row + 4, col) : ux3(row + 4, col)));
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+struct SmemA3 {
+  uint16_t K[2][QC * 128];
+  uint16_t U[2][QC * 64];
+  uint16_t S[64 * 128];      // [u][k] bf16 copy of S_in
+  float cs[2][QC], lw[2][QC], ecs[2][QC], ws[2][QC], dtl[2][QC];   // lw = log2(w) - cs  (M = G exp2(cs_l + lw_s))
+  float Dv[64];
+};
+static_assert(sizeof(SmemA3) <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
+
+template <int MODE, bool EXTRAS>   // EXTRAS: gate z and / or the pre-gate copy of y (forward without the gated norm)
+__global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
+  OMK_DYN_SMEM(smem_raw);
+  SmemA3& sm = *reinterpret_cast<SmemA3*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = uniform_i(tid >> 6);
+  const int h32 = lane >> 5, l31 = lane & 31, g16 = lane >> 4, t16 = lane & 15;
+  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a contiguous range of
+  // (batch, head) so the heads that share B / C rows also share an L2
+  int vid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int b = vid / a.H, h = vid % a.H;
+  const int g = h / (a.H / a.G);
+  const int nC = (a.L + QC - 1) / QC;
+  const bool rev = a.reverse != 0;
+  // chunk row i <-> token tlo + (rev ? 63 - i : i), tlo = 64 * chunk id
+  auto chunk_lo = [&](int c) -> int { return (rev ? nC - 1 - c : c) * QC; };
+  auto rowtok = [&](int i) -> int { return rev ? QC - 1 - i : i; };
+
+  // ---- staging lanes: K four 16-byte segments per thread (rows rowk + 16 r), U two (rows rowu + 32 r), Q fragments
+  const int rowk = tid >> 4, ck8 = (tid & 15) * 8, rowu = tid >> 3, cu8 = (tid & 7) * 8;
+  const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
+  const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
+  const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh;
+  const float* dtrow = a.dtp + ((int64_t)b * a.H + h) * a.L;
+  const int ksl = (int)a.K.sl, qsl = (int)a.Q.sl, usl = (int)a.U.sl, osl = (int)a.osl;
+  const uint32_t koff0 = (uint32_t)(rowtok(rowk) * ksl + ck8), uoff0 = (uint32_t)(rowtok(rowu) * usl + cu8);
+  const uint32_t qoff0 = (uint32_t)(rowtok(16 * w + t16) * qsl + 8 * g16);
+  const int kstep = (rev ? -16 : 16) * ksl, ustep = (rev ? -32 : 32) * usl;
+  u32x4 rk[4], ru[2], qf[4];
+  float rdt = 0.f, rda = 0.f, rwv = 0.f;
+  int stlo = 0;   // tlo of the chunk held in the staging registers
+  // The loads of the next chunk are spread over the phases of the current one (a burst of ten 1 KB loads per wave
+  // stalls on the 64 B/clk address path): K after barrier X, Q fragments, U and dt after the intra phase.  They are
+  // branch-free on purpose: rows past the end of a ragged last chunk read the chunk's first row instead (the commit
+  // zeroes them).  With vector-memory instructions under control flow the compiler can no longer count what is in
+  // flight and falls back to s_waitcnt vmcnt(0) -- which also waits for the output stores of the previous chunk.
+  const int rtk_k = rowtok(rowk), rtk_u = rowtok(rowu), rtk_q = rowtok(16 * w + t16), rtk_l = rowtok(lane);
+  const int dk16 = rev ? -16 : 16, du32 = rev ? -32 : 32;
+  auto prefetch_k = [&]() {
+    const int lim = a.L - stlo;   // rows with rowtok < lim are in range
+    const uint16_t* Kc = Kb + (int64_t)stlo * ksl;
+#pragma unroll
+    for (int r = 0; r < 4; r++) rk[r] = ld16(Kc + (rtk_k + dk16 * r < lim ? koff0 + (uint32_t)(r * kstep) : (uint32_t)ck8));
+  };
+  auto prefetch_q = [&]() {   // straight into the live fragment registers: issued after their last use of the chunk
+    const int lim = a.L - stlo;
+    const uint16_t* Qc = Qb + (int64_t)stlo * qsl;
+    const uint32_t qo = rtk_q < lim ? qoff0 : (uint32_t)(8 * g16);   // rows past the end: any in-range row, never stored
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) qf[kk] = ld16(Qc + 32 * kk + qo);
+  };
+  auto prefetch_u = [&]() {
+    const int lim = a.L - stlo;
+    const uint16_t* Uc = Ub + (int64_t)stlo * usl;
+#pragma unroll
+    for (int r = 0; r < 2; r++) ru[r] = ld16(Uc + (rtk_u + du32 * r < lim ? uoff0 + (uint32_t)(r * ustep) : (uint32_t)cu8));
+    // token scalars (consumed by wave 0, loaded by every wave to keep the instruction stream uniform): lanes = rows
+    const int t = stlo + rtk_l, ta = rev ? t + 1 : t;
+    rdt = dtrow[t < a.L ? t : 0];   // raw loads: the selects wait in scalars() so nothing stalls on them here
+    rda = dtrow[ta < a.L ? ta : 0];
+  };
+  const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
+  auto commit = [&](int buf) {
+    if (stlo + QC <= a.L) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) st16(&sm.K[buf][o_ck + 16 * 128 * r], rk[r]);
+#pragma unroll
+      for (int r = 0; r < 2; r++) st16(&sm.U[buf][o_cu + 32 * 64 * r], ru[r]);
+    } else {
+      const u32x4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) st16(&sm.K[buf][o_ck + 16 * 128 * r], stlo + rowtok(rowk + 16 * r) < a.L ? rk[r] : zero4);
+#pragma unroll
+      for (int r = 0; r < 2; r++) st16(&sm.U[buf][o_cu + 32 * 64 * r], stlo + rowtok(rowu + 32 * r) < a.L ? ru[r] : zero4);
+    }
+  };
+  const float Ah = a.A[h];
+  const float Ah2 = Ah * LOG2E;
+  auto scalars = [&](int buf) {   // wave 0 only; lanes = rows of the staged chunk
+    {
+      const int t = stlo + rowtok(lane);
+      const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
+      rwv = okd ? (a.w_is_dt ? rdt : 1.f) : 0.f;
+      rdt = okd ? rdt : 0.f;
+      rda = oka ? rda : 0.f;
+    }
+    const float cs = wave_incl_scan_add(rda * Ah2);
+    const float cs_end = wave_read_lane(cs, 63);
+    sm.cs[buf][lane] = cs;
+    sm.lw[buf][lane] = log2_fast(rwv) - cs;
+    sm.ecs[buf][lane] = exp2_fast(cs);
+    sm.ws[buf][lane] = rwv * exp2_fast(cs_end - cs);
+    sm.dtl[buf][lane] = rdt;
+  };
+
+  // ---- lane-constant LDS element offsets (the swizzle only depends on row & 15, so tile / chunk-row-block / buffer
+  // selection stays an immediate or scalar offset on top of these)
+  int o_rd[4], o_mu[4], o_xu[4], o_ps[4], o_tu[2][2], o_tk[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    o_rd[i] = kx3(t16, 32 * i + 8 * g16);                         // b128 row reads of K (G) and S (Q.S): row t16
+    o_mu[i] = ux3(4 * g16 + (t16 >> 2), 16 * i + 4 * (t16 & 3));  // permuted transpose reads of U for M.U
+    o_xu[i] = ux3(t16, 16 * i + 4 * g16);                         // x of the lane's output row
+    o_ps[i] = kx3(l31, 8 * i + 4 * h32);                          // publish: S[u = l31][k = 8 i + 4 h32 ..]
+  }
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    o_tk[m] = kx3(8 * h32 + (t16 >> 2) + 4 * m, 16 * (g16 & 1) + 4 * (t16 & 3));
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++) o_tu[ut][m] = ux3(8 * h32 + (t16 >> 2) + 4 * m, 32 * ut + 16 * (g16 & 1) + 4 * (t16 & 3));
+  }
+  // ---- running state: S^T[32 w + ..][32 ut + ..], ut = 0, 1
+  f32x16 accS[2];
+#pragma unroll
+  for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = 0.f;
+      if (a.init) {
+        const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * ut + l31;
+        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+      accS[ut][r] = v;
+    }
+  auto publish_state = [&]() {
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int rq4 = 0; rq4 < 4; rq4++) {
+        u32x2 v;
+        v[0] = pack_bf16x2(accS[ut][4 * rq4 + 0], accS[ut][4 * rq4 + 1]);
+        v[1] = pack_bf16x2(accS[ut][4 * rq4 + 2], accS[ut][4 * rq4 + 3]);
+        *reinterpret_cast<u32x2*>(&sm.S[(o_ps[rq4] ^ (w << 5)) + 32 * 128 * ut]) = v;   // column block 32 w = segment bits 2-3
+      }
+  };
+
+  stlo = chunk_lo(0);
+  prefetch_q();
+  prefetch_k();
+  prefetch_u();
+  commit(0);
+  if (w == 0) scalars(0);
+  publish_state();
+  if (tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
+  block_sync();
+  uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
+  uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
+  const uint16_t* zb = (MODE == GS_Y && a.Z.p) ? (const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)h * a.Z.sh : nullptr;
+  const int zsl = (int)a.Z.sl;
+  // the lane's output row l = 16 w + t16; register r of tile ut is column 16 ut + 4 g16 + r  (8-byte stores)
+  const int erow = rowtok(16 * w + t16);
+  const uint32_t eoff = (uint32_t)(erow * osl + 4 * g16), zoff = (uint32_t)(erow * zsl + 4 * g16);
+
+#ifdef OMK_PHASE_PROF   // developer build (tools/phase_prof.py): s_memtime deltas per phase, workgroup 0
+  uint64_t pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+#define PT3(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+  uint64_t tprev = prof ? clock64_() : 0;
+#else
+#define PT3(i) do { } while (0)
+#endif
+  for (int c = 0; c < nC; c++) {
+    const int cur = c & 1, nxt = cur ^ 1;
+    const int tlo = chunk_lo(c);
+    const int cnext = c + 1 < nC ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
+    PT3(0);
+    // ---- (1) O = exp2(cs_l) * (Q . S_in): A = Q fragments (registers), B = S_in[k][u] as [u][k] bf16 rows
+    f32x4 acc[4];
+#pragma unroll
+    for (int ut = 0; ut < 4; ut++) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int ut = 0; ut < 4; ut++) {
+        const s16x8 fs = as_s16x8(ld16(&sm.S[o_rd[kk] + 16 * 128 * ut]));
+        acc[ut] = mfma16x16x32_bf16(fs, as_s16x8(qf[kk]), acc[ut]);   // O^T[u][l]: 4 consecutive u per lane
+      }
+    {
+      const float e1 = sm.ecs[cur][16 * w + t16];
+#pragma unroll
+      for (int ut = 0; ut < 4; ut++) acc[ut] *= e1;
+    }
+    PT3(1);
+    block_sync();   // X: every wave is done with S_in
+    PT3(2);
+    stlo = chunk_lo(cnext);
+    prefetch_k();
+    prefetch_u();
+    // ---- (2) intra-chunk: G tiles -> M fragments (registers) -> M . U
+    {
+      const float cs_l = sm.cs[cur][16 * w + t16];
+      auto block = [&](int kk, bool second, bool diag0, bool diag1) {
+        // tiles ta = 2 kk + j (j = 0, 1) of G^T: lane holds s = 16 ta + 4 g16 + r (r = 0..3) for its own l = 16 w + t16
+        u32x4 mh, ml;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (j == 1 && !second) { mh[2] = mh[3] = ml[2] = ml[3] = 0u; continue; }
+          const int ta = 2 * kk + j;
+          f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kq = 0; kq < 4; kq++) {
+            const s16x8 fa = as_s16x8(ld16(&sm.K[cur][o_rd[kq] + 16 * 128 * ta]));
+            gt = mfma16x16x32_bf16(fa, as_s16x8(qf[kq]), gt);
+          }
+          const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[cur][16 * ta + 4 * g16]);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            v[r] = gt[r] * exp2_fast(cs_l + lw4[r]);
+            if (j == 0 ? diag0 : diag1) v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+          }
+#pragma unroll
+          for (int p2 = 0; p2 < 2; p2++) {   // bf16 hi + lo: the rounding of M dominates the error of y otherwise
+            const uint32_t hi = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
+            mh[2 * j + p2] = hi;
+            ml[2 * j + p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi), v[2 * p2 + 1] - bf_hi(hi));
+          }
+        }
+#pragma unroll
+        for (int ut = 0; ut < 4; ut++) {
+          // B operand with the SAME permuted contraction order: rows 32 kk + 16 j + 4 g16 + {0..3}, column 16 ut + t16
+          const uint16_t* pu = &sm.U[cur][o_mu[ut] + 32 * 64 * kk];
+          const s16x4 u0 = lds_read_tr16_b64(pu);
+          const s16x4 u1 = lds_read_tr16_b64(pu + 16 * 64);   // + 16 rows: same swizzle
+          s16x8 fu;
+          fu[0] = u0[0]; fu[1] = u0[1]; fu[2] = u0[2]; fu[3] = u0[3]; fu[4] = u1[0]; fu[5] = u1[1]; fu[6] = u1[2]; fu[7] = u1[3];
+          acc[ut] = mfma16x16x32_bf16(fu, as_s16x8(mh), acc[ut]);
+          acc[ut] = mfma16x16x32_bf16(fu, as_s16x8(ml), acc[ut]);
+        }
+      };
+      // strip w: s blocks kk = 0 .. w >> 1; the diagonal tile is ta = w, tiles ta > w are empty
+      if (w == 0) { block(0, false, true, false); }
+      else if (w == 1) { block(0, true, false, true); }
+      else if (w == 2) { block(0, true, false, false); block(1, false, true, false); }
+      else { block(0, true, false, false); block(1, true, false, true); }
+    }
+    PT3(3);
+    prefetch_q();
+    // ---- (3) state update: S^T[k][u] = exp2(cs_end) S^T + sum_l (ws_l K^T[k][l]) U[l][u]
+    {
+      const float dec = sm.ecs[cur][QC - 1];
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++) accS[ut] *= dec;
+#pragma unroll
+      for (int ls = 0; ls < 4; ls++) {
+        s16x8 fk;
+        {
+          const s16x4 k0 = lds_read_tr16_b64(&sm.K[cur][(o_tk[0] ^ (w << 5)) + 16 * 128 * ls]);
+          const s16x4 k1 = lds_read_tr16_b64(&sm.K[cur][(o_tk[1] ^ (w << 5)) + 16 * 128 * ls]);
+          fk[0] = k0[0]; fk[1] = k0[1]; fk[2] = k0[2]; fk[3] = k0[3]; fk[4] = k1[0]; fk[5] = k1[1]; fk[6] = k1[2]; fk[7] = k1[3];
+        }
+        const int lb = 16 * ls + 8 * h32;
+        const f32x4 s0v = *reinterpret_cast<const f32x4*>(&sm.ws[cur][lb]);
+        const f32x4 s1v = *reinterpret_cast<const f32x4*>(&sm.ws[cur][lb + 4]);
+        u32x4 kp;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          const f32x2 kv = {bf16_to_f32((uint16_t)fk[2 * e2]), bf16_to_f32((uint16_t)fk[2 * e2 + 1])};
+          const f32x2 sv = e2 < 2 ? f32x2{s0v[2 * e2], s0v[2 * e2 + 1]} : f32x2{s1v[2 * e2 - 4], s1v[2 * e2 - 3]};
+          const f32x2 pr = kv * sv;
+          kp[e2] = pack_bf16x2(pr[0], pr[1]);
+        }
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+          s16x8 fu;
+          {
+            const s16x4 u0 = lds_read_tr16_b64(&sm.U[cur][o_tu[ut][0] + 16 * 64 * ls]);
+            const s16x4 u1 = lds_read_tr16_b64(&sm.U[cur][o_tu[ut][1] + 16 * 64 * ls]);
+            fu[0] = u0[0]; fu[1] = u0[1]; fu[2] = u0[2]; fu[3] = u0[3]; fu[4] = u1[0]; fu[5] = u1[1]; fu[6] = u1[2]; fu[7] = u1[3];
+          }
+          accS[ut] = mfma32x32x16_bf16(as_s16x8(kp), fu, accS[ut]);
+        }
+      }
+    }
+    PT3(4);
+    // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
+    publish_state();
+    commit(nxt);
+    if (w == 0) scalars(nxt);
+    PT3(5);
+    // ---- epilogue from the MFMA layout: 4 consecutive columns of one row per (lane, ut)
+    {
+      const int trow = tlo + erow;
+      if (trow < a.L) {
+        const float dts = MODE == GS_DX ? sm.dtl[cur][16 * w + t16] : 1.f;
+        uint16_t* oc = ob + (int64_t)tlo * osl;
+#pragma unroll
+        for (int ut = 0; ut < 4; ut++) {
+          const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][o_xu[ut] + 16 * 64 * w]);
+          const f32x4 Du = *reinterpret_cast<const f32x4*>(&sm.Dv[16 * ut + 4 * g16]);   // D of columns 16 ut + 4 g16 + r
+          f32x4 v = acc[ut] * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
+          if (MODE == GS_Y) {
+            if (EXTRAS && oxb) {
+              u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(oxb + (int64_t)tlo * osl + 16 * ut + eoff) = o;
+            }
+            if (EXTRAS && zb) {
+              const u32x2 zr = *reinterpret_cast<const u32x2*>(zb + (int64_t)tlo * zsl + 16 * ut + zoff);
+              v[0] *= silu_fast(bf_lo(zr[0])); v[1] *= silu_fast(bf_hi(zr[0]));
+              v[2] *= silu_fast(bf_lo(zr[1])); v[3] *= silu_fast(bf_hi(zr[1]));
+            }
+          }
+          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(oc + 16 * ut + eoff) = o;
+        }
+      }
+    }
+    PT3(6);
+    block_sync();   // Y: tiles, scalars and the bf16 state of the next chunk are visible
+    PT3(7);
+  }
+#ifdef OMK_PHASE_PROF
+  if (prof && lane == 0)
+    for (int i = 0; i < 12; i++) a.prof[w * 12 + i] = pt[i];
+#endif
+  if (a.fin) {
+    const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * ut + l31;
+        a.fin[(int64_t)b * a.fsb + (int64_t)h * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = accS[ut][r] * extra;
+      }
+  }
+}
+
+// =========================================================================================================
 // class B: U shared by the group and 128 wide (B or C), K / Q per head and 64 wide (x, dy): the dC and dB scans.
 // State tiles S^T[k = p][u = n]; output O_h[l][n] of both heads is scaled (dB: by dt'_l), summed through LDS and
 // written as one fp32 [64][128] tile per chunk to the per-head-pair partial buffer (reduced over head pairs by
@@ -803,6 +1468,35 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (g.outx && ((uintptr_t)g.outx & 15)) return OMK_EUNSUPPORTED;
   if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (dry) return OMK_OK;
+  const int64_t lim = (int64_t)1 << 24;   // the row-strip kernel keeps per-lane offsets in 32 bits
+  const bool small = g.K.sl < lim && g.Q.sl < lim && g.U.sl < lim && g.osl < lim && (!g.Z.p || g.Z.sl < lim);
+  if (small && !getenv("OMK_SSD_A_V1") && !getenv("OMK_SSD_A_V2")) {   // default: row-strip kernel, one head per 256-thread workgroup
+    dim3 grid3((unsigned)(g.B * g.H)), block3(256);
+    const size_t smem3 = sizeof(SmemA3);
+    if (g.mode == GS_Y && (g.Z.p || g.outx)) {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, true>), smem3)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem3);
+      OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, true>), grid3, block3, smem3, stream, g);
+    } else if (g.mode == GS_Y) {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false>), smem3)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem3);
+      OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false>), grid3, block3, smem3, stream, g);
+    } else {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_DX, false>), smem3)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem3);
+      OMK_LAUNCH((ssd_mfma_a3_kernel<GS_DX, false>), grid3, block3, smem3, stream, g);
+    }
+    return OMK_OK;
+  }
+  if (!getenv("OMK_SSD_A_V1")) {   // version 2: 32x32 output tiles, G through LDS
+    dim3 grid2((unsigned)(g.B * g.H)), block2(256);
+    const size_t smem2 = sizeof(SmemA2);
+    if (g.mode == GS_Y) {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a2_kernel<GS_Y>), smem2)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem2);
+      OMK_LAUNCH((ssd_mfma_a2_kernel<GS_Y>), grid2, block2, smem2, stream, g);
+    } else {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a2_kernel<GS_DX>), smem2)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem2);
+      OMK_LAUNCH((ssd_mfma_a2_kernel<GS_DX>), grid2, block2, smem2, stream, g);
+    }
+    return OMK_OK;
+  }
   dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
   const size_t smem = sizeof(SmemA);
   if (g.mode == GS_Y) {

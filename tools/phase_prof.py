@@ -8,7 +8,8 @@ from omnimamba_amd._lib import get_lib
 import omnimamba_amd.ssd_combined as S
 
 dev = torch.device("cuda:0")
-B, L, H, P, N, G = 8, 4096, 64, 64, 128, 1
+B = int(os.environ.get("PB", "8"))
+L, H, P, N, G = 4096, 64, 64, 128, 1
 torch.manual_seed(0)
 xBC = torch.randn(B, L, H * P + 2 * G * N, device=dev).bfloat16()
 x = xBC[..., :H * P].view(B, L, H, P); Bm = xBC[..., H * P:H * P + G * N].view(B, L, G, N); Cm = xBC[..., H * P + G * N:].view(B, L, G, N)
@@ -23,9 +24,20 @@ for _ in range(2):
     K.run(lib, "omk_ssd_scan_fwd", p, x)
 torch.cuda.synchronize()
 off = ((B * H * L * 4 + 255) // 256) * 256
+nC = L // 64
+if not os.environ.get("OMK_SSD_A_V1"):
+    prof = ws[off:off + 4 * 12 * 8].view(torch.int64).cpu().view(4, 12)
+    if os.environ.get("OMK_SSD_A_V2"):
+        names = ["prefetch", "scal+G", "waitB1", "Mbuild+MU", "Q.S", "ov", "S-update", "waitB2", "pub+commit", "epilogue", "waitB3", "-"]
+    else:
+        names = ["prefetch", "Q.S", "waitX", "G+M+MU", "S-update", "pub+commit", "epilogue", "waitY", "-", "-", "-", "-"]
+    print(f"B={B}: cycles per chunk, per wave   " + " ".join(f"{n:>10s}" for n in names) + "      total")
+    for w in range(4):
+        row = prof[w].double() / nC
+        print(f"wave {w}:                         " + " ".join(f"{v:10.0f}" for v in row.tolist()) + f" {row.sum():10.0f}")
+    sys.exit(0)
 prof = ws[off:off + 8 * 10 * 8].view(torch.int64).cpu().view(8, 10)
 names = ["prefetch", "scal+G", "waitB1", "O-chain", "S-update", "waitB2", "pub+add", "waitB3", "epi+commit", "waitB4"]
-nC = L // 64
 print("cycles per chunk, per wave (wave: role)   " + " ".join(f"{n:>10s}" for n in names) + "      total")
 for w in range(8):
     hh, wi, wj = w >> 2, (w >> 1) & 1, w & 1
