@@ -223,17 +223,30 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
   }
 }
 
-// out[col] = sum_p part[p][col]; block = 64 columns x 4 part-groups, folded through LDS
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int nparts, int cols, float* out) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (col < cols)
-    for (int p = pg; p < nparts; p += 4) s += part[(int64_t)p * cols + col];
-  sh[pg][cl] = s;
+// out[col] = sum_p part[p][col]; block = 32 columns (one 128-byte line per partial row) x 32 part-groups, folded
+// through LDS: cols / 32 blocks of 16 waves keep enough loads in flight for the 16 MB of partials of the 1.3B block
+constexpr int RP_COLS = 32, RP_GROUPS = 32;
+__global__ __launch_bounds__(RP_COLS * RP_GROUPS) void reduce_parts_kernel(const float* part, int nparts, int cols, float* out) {
+  __shared__ float sh[RP_GROUPS][RP_COLS + 1];
+  const int cl = threadIdx.x % RP_COLS, pg = threadIdx.x / RP_COLS;
+  const int col = blockIdx.x * RP_COLS + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < cols) {
+    int p = pg;
+    for (; p + RP_GROUPS < nparts; p += 2 * RP_GROUPS) {
+      s0 += part[(int64_t)p * cols + col];
+      s1 += part[(int64_t)(p + RP_GROUPS) * cols + col];
+    }
+    if (p < nparts) s0 += part[(int64_t)p * cols + col];
+  }
+  sh[pg][cl] = s0 + s1;
   block_sync();
-  if (pg == 0 && col < cols) out[col] = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+  if (pg == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < RP_GROUPS; g++) s += sh[g][cl];
+    out[col] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -419,6 +432,7 @@ struct VecPlan { int vec, nchunk, wpr; };
 static bool plan_vec(int64_t seglen, bool can8, VecPlan* out) {
   if (can8 && seglen % 8 == 0) {
     if (seglen <= 1 * 4 * 64 * 8) { *out = {8, 4, 1}; return true; }     // <= 2048
+    if (seglen <= 4 * 2 * 64 * 8) { *out = {8, 2, 4}; return true; }     // <= 4096 (the 1.3B gated norm): half the registers
     if (seglen <= 4 * 4 * 64 * 8) { *out = {8, 4, 4}; return true; }     // <= 8192
   }
   if (seglen <= 4 * 32 * 64) { *out = {1, 32, 4}; return true; }         // <= 8192, any alignment
@@ -440,11 +454,12 @@ static bool rows_ok8(const OmkTensor& t) { return !present(t) || (aligned16(t) &
 
 #define OMK_PLAN_SWITCH(plan, ...)                                                                                   \
   if (plan.vec == 8 && plan.wpr == 1) { constexpr int VEC = 8, NCHUNK = 4, WPR = 1; __VA_ARGS__; }                   \
+  else if (plan.vec == 8 && plan.nchunk == 2) { constexpr int VEC = 8, NCHUNK = 2, WPR = 4; __VA_ARGS__; }           \
   else if (plan.vec == 8) { constexpr int VEC = 8, NCHUNK = 4, WPR = 4; __VA_ARGS__; }                               \
   else { constexpr int VEC = 1, NCHUNK = 32, WPR = 4; __VA_ARGS__; }
 
 static void launch_reduce(const float* part, int nparts, int64_t cols, float* out, omk_stream stream) {
-  dim3 rg((unsigned)((cols + 63) / 64)), rb(256);
+  dim3 rg((unsigned)((cols + RP_COLS - 1) / RP_COLS)), rb(RP_COLS * RP_GROUPS);
   OMK_LAUNCH(reduce_parts_kernel, rg, rb, 0, stream, part, nparts, (int)cols, out);
 }
 

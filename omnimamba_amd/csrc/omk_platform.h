@@ -190,6 +190,8 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
+// float sums take the DPP path (8 VALU ops instead of six ds_bpermute round trips); every lane gets the total
+__device__ __forceinline__ float wave_sum(float v) { return wave_read_lane(wave_incl_scan_add(v), 63); }
 #ifdef OMK_EMU
 __device__ __forceinline__ uint64_t clock64_() { return 0; }
 #else
