@@ -83,8 +83,10 @@ def main():
 
     from omnimamba_amd import _prof
     from omnimamba_amd._lib import get_lib
+    from omnimamba_amd.gemm_tuning import use_tuned_gemms
     from omnimamba_amd.mamba2 import Mamba2
     assert get_lib().omk_is_emulated() == 0
+    tuned = use_tuned_gemms()                  # recorded hipBLASLt / rocBLAS solutions for the block's GEMMs (no tuning here)
 
     torch.manual_seed(0)                       # identical random-init weights on every rank
     block = Mamba2(D_MODEL, d_state=D_STATE, headdim=HEADDIM, layer_idx=0, device=dev)
@@ -142,7 +144,7 @@ def main():
             "config": {"workload": "single Mamba-2 block fwd+bwd (BASELINE.json configs[1])", "batch_per_gpu": B_LOCAL,
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
             "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a_kernel<GS_Y> + dt prep)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4),
