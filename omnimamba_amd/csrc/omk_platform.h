@@ -190,6 +190,13 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
+// Make a lane value opaque to the optimiser at this point: address arithmetic derived from it afterwards stays inside
+// the loop instead of being hoisted into (many) loop-invariant registers.
+#ifdef OMK_EMU
+#define OMK_OPAQUE(x) do { } while (0)
+#else
+#define OMK_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 // float sums take the DPP path (8 VALU ops instead of six ds_bpermute round trips); every lane gets the total
 __device__ __forceinline__ float wave_sum(float v) { return wave_read_lane(wave_incl_scan_add(v), 63); }
 #ifdef OMK_EMU

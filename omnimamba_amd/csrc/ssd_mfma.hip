@@ -707,10 +707,11 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a2_kernel(GScan a) {
 //   K / S tiles (256 B rows): seg ^ swzK(row).  ds_read_b128 "row t16, segment 4 c + g16" (lane groups
 //     {0-3,12-15,20-27}, ...) needs swzK bijective on row & 15 with swzK({4..11}) closed under ^1; the transpose reads
 //     "4 rows x 4 segments per half wave" need swzK(row) >> 2 distinct over 4 consecutive rows.
-//   U tile (128 B rows, two rows per 256 B bank row): seg ^ swzU(row), found the same way for the three U patterns
-//     (8 rows x 2 segments, 4 rows x 4 segments, 16 rows x 1 segment).
+//   64-column tiles (128 B rows, two rows per 256 B bank row): seg ^ swzU(row) with swzU = swzK & 7 -- searched the same
+//     way over every pattern the class A / class B kernels use on them (8 rows x 2 segments, 4 rows x 4 segments,
+//     16 rows x 1 segment, the ds_read_b128 row reads, rows {0-3, 8-11} x 2 segments).
 __device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
-__device__ __forceinline__ int swzU(int r) { return ((r & 2) << 1) | ((r >> 1) & 2) | ((r >> 3) & 1); }
+__device__ __forceinline__ int swzU(int r) { return swzK(r) & 7; }
 __device__ __forceinline__ int kx3(int row, int col) { return row * 128 + ((((col >> 3) ^ swzK(row)) << 3) | (col & 7)); }
 __device__ __forceinline__ int ux3(int row, int col) { return row * 64 + ((((col >> 3) ^ swzU(row)) << 3) | (col & 7)); }
 // 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
@@ -1413,6 +1414,376 @@ __global__ __launch_bounds__(512) void ssd_mfma_b_kernel(GScan a) {
   }
 }
 
+// =========================================================================================================
+// class B, version 3: the row-strip design of ssd_mfma_a3_kernel for the dC / dB scans.  One 512-thread workgroup owns
+// a head PAIR (the unit of the fp32 partial tiles): waves 0-3 are the strips of head 0, waves 4-7 of head 1; the group
+// rows U (B or C) and X4 (C or B) are staged once for both.  Wave (hh, w):
+//   output   O^T[n][l]  l in [16 w, 16 w + 16), all 128 n: eight 16x16 register tiles (G, M never leave registers);
+//   state    S^T[p][n]  p in [16 w, 16 w + 16), all 128 n: eight 16x16 register tiles, updated with 16x16x32 MFMAs;
+//   token scalar  e_l / w_l = X4_l . O_l : 32 products per lane + two cross-lane adds, stored straight to HBM;
+//   head 1 hands its (dt-scaled) tiles to head 0 through a lane-linear LDS buffer; head 0 adds and stores the partial.
+// Tiles are single buffered: everything that reads U / X4 / K / S / the scalars of a chunk sits before barrier E, the
+// commit of the next chunk after it.  Three barriers per chunk (X: S_in reads done, E: exchange, Y: next chunk visible).
+// =========================================================================================================
+struct SmemB3 {
+  uint16_t U[QC * 128];        // group rows, kx3 swizzle
+  uint16_t X4[QC * 128];
+  uint16_t K[2][QC * 64];      // per head, ux3 swizzle
+  uint16_t S[2][128 * 64];     // per head [n][p] bf16 copy of S_in, ux3 swizzle
+  float O[4 * 8 * 64 * 4];     // head 1 -> head 0: [strip][ut][lane] float4, lane-linear
+  float cs[2][QC], lw[2][QC], ecs[2][QC], ws[2][QC], dtl[2][QC];
+  float bred[8];
+  float dred[2][4][64];        // dD fold: [head][strip][column]
+};
+
+template <int MODE, int DMODE>   // DMODE (dB scan): 0 no dD, 1 dD per head (one running sum), 2 dD per (head, column)
+__global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
+  OMK_DYN_SMEM(smem_raw);
+  SmemB3& sm = *reinterpret_cast<SmemB3*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_i(tid >> 6);
+  const int hh = wave >> 2, w = wave & 3;
+  const int h32 = lane >> 5, g16 = lane >> 4, t16 = lane & 15;
+  (void)h32;
+  const int pairs = a.H / 2;
+  int vid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous (batch, pair)
+  const int b = vid / pairs, hp = vid % pairs;
+  const int h0 = hp * 2, hcur = h0 + hh;
+  const int g = h0 / (a.H / a.G);
+  const int nC = (a.L + QC - 1) / QC;
+  const bool rev = a.reverse != 0;
+  auto chunk_lo = [&](int c) -> int { return (rev ? nC - 1 - c : c) * QC; };
+  auto rowtok = [&](int i) -> int { return rev ? QC - 1 - i : i; };
+
+  // ---- staging: U, X4 two 16-byte segments per thread (rows rowg + 32 r); K one segment per thread per head
+  const int rowg = tid >> 4, cg8 = (tid & 15) * 8, rowk = tid >> 3, ck8 = (tid & 7) * 8;
+  const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)g * a.U.sh;
+  const uint16_t* Xb = (const uint16_t*)a.X4.p + (int64_t)b * a.X4.sb + (int64_t)g * a.X4.sh;
+  const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)h0 * a.K.sh;
+  const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)hcur * a.Q.sh;
+  const float* dtrow = a.dtp + ((int64_t)b * a.H + hcur) * a.L;
+  const int usl = (int)a.U.sl, xsl = (int)a.X4.sl, ksl = (int)a.K.sl, qsl = (int)a.Q.sl, ksh = (int)a.K.sh;
+  const int rtk_g = rowtok(rowg), rtk_k = rowtok(rowk), rtk_q = rowtok(16 * w + t16), rtk_l = rowtok(lane);
+  const uint32_t uoff0 = (uint32_t)(rtk_g * usl + cg8), xoff0 = (uint32_t)(rtk_g * xsl + cg8);
+  const uint32_t koff0 = (uint32_t)(rtk_k * ksl + ck8), qoff0 = (uint32_t)(rtk_q * qsl + 8 * g16);
+  const int d32 = rev ? -32 : 32;
+  u32x4 ruu[2], rx4[2], rk[2], qf[2];
+  float rdt = 0.f, rda = 0.f;
+  int stlo = 0;
+  // branch-free loads (see ssd_mfma_a3_kernel): rows past the end of a ragged chunk read the chunk's first row
+  auto prefetch_tiles = [&]() {
+    const int lim = a.L - stlo;
+    const uint16_t* Uc = Ub + (int64_t)stlo * usl;
+    const uint16_t* Xc = Xb + (int64_t)stlo * xsl;
+    const uint16_t* Kc = Kb + (int64_t)stlo * ksl;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const bool ok = rtk_g + d32 * r < lim;
+      ruu[r] = ld16(Uc + (ok ? uoff0 + (uint32_t)(r * d32 * usl) : (uint32_t)cg8));
+      rx4[r] = ld16(Xc + (ok ? xoff0 + (uint32_t)(r * d32 * xsl) : (uint32_t)cg8));
+    }
+    const uint32_t ko = rtk_k < lim ? koff0 : (uint32_t)ck8;
+#pragma unroll
+    for (int r = 0; r < 2; r++) rk[r] = ld16(Kc + r * ksh + ko);
+  };
+  auto prefetch_q = [&]() {
+    const int lim = a.L - stlo;
+    const uint16_t* Qc = Qb + (int64_t)stlo * qsl;
+    const uint32_t qo = rtk_q < lim ? qoff0 : (uint32_t)(8 * g16);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) qf[kk] = ld16(Qc + 32 * kk + qo);
+    const int t = stlo + rtk_l, ta = rev ? t + 1 : t;
+    rdt = dtrow[t < a.L ? t : 0];
+    rda = dtrow[ta < a.L ? ta : 0];
+  };
+  const int o_cg = kx3(rowg, cg8), o_ck = ux3(rowk, ck8);
+  auto commit = [&]() {
+    const u32x4 zero4 = {0, 0, 0, 0};
+    const int lim = a.L - stlo;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const bool ok = rtk_g + d32 * r < lim;
+      st16(&sm.U[o_cg + 32 * 128 * r], ok ? ruu[r] : zero4);
+      st16(&sm.X4[o_cg + 32 * 128 * r], ok ? rx4[r] : zero4);
+    }
+    const bool okk = rtk_k < lim;
+#pragma unroll
+    for (int r = 0; r < 2; r++) st16(&sm.K[r][o_ck], okk ? rk[r] : zero4);
+  };
+  const float Ah = a.A[hcur];
+  const float Ah2 = Ah * LOG2E;
+  auto scalars = [&]() {   // waves with w == 0; lanes = rows of the staged chunk of head hh
+    const int t = stlo + rtk_l;
+    const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
+    const float wv = okd ? (a.w_is_dt ? rdt : 1.f) : 0.f;
+    const float cs = wave_incl_scan_add((oka ? rda : 0.f) * Ah2);
+    const float cs_end = wave_read_lane(cs, 63);
+    sm.cs[hh][lane] = cs;
+    sm.lw[hh][lane] = log2_fast(wv) - cs;
+    sm.ecs[hh][lane] = exp2_fast(cs);
+    sm.ws[hh][lane] = wv * exp2_fast(cs_end - cs);
+    sm.dtl[hh][lane] = okd ? rdt : 0.f;
+  };
+
+  // ---- lane-constant LDS element offsets
+  // (a 16-column block index ut only touches segment bits 1-3, which the swizzle XORs: offset(ut) = offset(0) ^ (ut << 4))
+  int o_rdk[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) o_rdk[i] = ux3(t16, 32 * i + 8 * g16);        // b128 row reads of K (G) and S (Q.S): row t16
+  int o_mu = kx3(4 * g16 + (t16 >> 2), 4 * (t16 & 3));                // permuted transpose reads of U for M.U
+  int o_su = kx3(8 * g16 + (t16 >> 2), 4 * (t16 & 3));                // transpose reads of U for the state update
+  int o_x4 = kx3(t16, 4 * g16);                                       // X4 of the lane's output row
+  int o_ps = ux3(t16, 4 * g16);                                       // publish: rows 16 ut + t16
+  int o_tk = ux3(8 * g16 + (t16 >> 2), 4 * (t16 & 3));                // transpose reads of K^T (columns 16 w + ..)
+
+  // ---- running state S^T[p = 16 w + 4 g16 + r][n = 16 ut + t16]
+  f32x4 accS[8];
+#pragma unroll
+  for (int ut = 0; ut < 8; ut++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float v = 0.f;
+      if (a.init) {
+        const int k = 16 * w + 4 * g16 + r, u = 16 * ut + t16;
+        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)hcur * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+      accS[ut][r] = v;
+    }
+  auto publish_state = [&]() {   // sm.S[hh][n][p]: 4 consecutive p per lane
+#pragma unroll
+    for (int ut = 0; ut < 8; ut++) {
+      u32x2 v = {pack_bf16x2(accS[ut][0], accS[ut][1]), pack_bf16x2(accS[ut][2], accS[ut][3])};
+      *reinterpret_cast<u32x2*>(&sm.S[hh][(o_ps ^ (w << 4)) + 16 * 64 * ut]) = v;   // column block 16 w = segment bits 1-2
+    }
+  };
+
+  stlo = chunk_lo(0);
+  prefetch_tiles();
+  prefetch_q();
+  commit();
+  if (w == 0) scalars();
+  publish_state();
+  block_sync();
+  float* part = a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
+  // state checkpoints in fragment order: [b][pair][chunk][wave 8][ut 8][reg pair 2][lane 64] packed bf16 pairs (u32)
+  uint32_t* ck = a.ckpt ? (uint32_t*)a.ckpt + ((int64_t)b * pairs + hp) * (int64_t)nC * 8192 : nullptr;
+  float* tokscal = a.tokscal + ((int64_t)b * a.H + hcur) * a.L;
+  float dDp[DMODE == 2 ? 2 : 1][DMODE == 2 ? 8 : 1];
+#pragma unroll
+  for (int i = 0; i < (DMODE == 2 ? 2 : 1); i++)
+#pragma unroll
+    for (int e = 0; e < (DMODE == 2 ? 8 : 1); e++) dDp[i][e] = 0.f;
+  const bool want_bnd = MODE == GS_DB && ck != nullptr && a.bnd != nullptr;
+  // checkpoint of the chunk the NEXT iteration closes, fetched while the output registers are dead
+  uint32_t ckv[16];
+  auto load_ckpt = [&](int c) {
+    const uint32_t* cp = ck + (int64_t)(nC - 1 - c) * 8192 + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 16; i++) ckv[i] = cp[i * 64 + lane];
+  };
+  if (want_bnd) load_ckpt(0);
+
+  for (int c = 0; c < nC; c++) {
+    const int tlo = chunk_lo(c);
+    const int cnext = c + 1 < nC ? c + 1 : c;
+    OMK_OPAQUE(o_mu); OMK_OPAQUE(o_su); OMK_OPAQUE(o_x4); OMK_OPAQUE(o_ps); OMK_OPAQUE(o_tk);
+    if (want_bnd) {
+      // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
+      //   bnd[id + 1] = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan checkpoint of chunk id) >
+      float dot = 0.f;
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) dot += accS[ut][2 * j] * bf_lo(ckv[2 * ut + j]) + accS[ut][2 * j + 1] * bf_hi(ckv[2 * ut + j]);
+      dot = wave_sum(dot);
+      if (lane == 0) sm.bred[wave] = dot;
+    }
+    // ---- (1) O^T = exp2(cs_l) * (S_in^T . Q^T)
+    f32x4 acc[8];
+#pragma unroll
+    for (int ut = 0; ut < 8; ut++) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) {
+        const s16x8 fs = as_s16x8(ld16(&sm.S[hh][o_rdk[kk] + 16 * 64 * ut]));
+        acc[ut] = mfma16x16x32_bf16(fs, as_s16x8(qf[kk]), acc[ut]);
+      }
+    {
+      const float e1 = sm.ecs[hh][16 * w + t16];
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) acc[ut] *= e1;
+    }
+    block_sync();   // X: every wave is done with S_in (and bred is complete)
+    if (want_bnd && tid < 2) {
+      const int id = nC - 1 - c, hd = h0 + tid;
+      const int tnext = (id + 1) * QC;
+      const float ex = tnext < a.L ? expf(a.dtp[((int64_t)b * a.H + hd) * a.L + tnext] * a.A[hd]) : 1.f;
+      a.bnd[((int64_t)b * a.H + hd) * (nC + 1) + id + 1] = ex * (sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3]);
+    }
+    stlo = chunk_lo(cnext);
+    prefetch_tiles();
+    // ---- (2) intra-chunk: G tiles -> M fragments (registers) -> U^T . M^T
+    {
+      const float cs_l = sm.cs[hh][16 * w + t16];
+      auto block = [&](int kk, bool second, bool diag0, bool diag1) {
+        u32x4 mh, ml;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (j == 1 && !second) { mh[2] = mh[3] = ml[2] = ml[3] = 0u; continue; }
+          const int ta = 2 * kk + j;
+          f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kq = 0; kq < 2; kq++) {
+            const u32x4 fa = ld16(&sm.K[hh][o_rdk[kq] + 16 * 64 * ta]);
+            gt = mfma16x16x32_bf16(as_s16x8(fa), as_s16x8(qf[kq]), gt);
+            if (MODE == GS_DB && DMODE != 0 && (j == 0 ? diag0 : diag1)) {   // the diagonal tile holds K rows 16 w + t16: dD += dy . x
+#pragma unroll
+              for (int e2 = 0; e2 < 4; e2++) {
+                dDp[DMODE == 2 ? kq : 0][DMODE == 2 ? 2 * e2 : 0] += bf_lo(fa[e2]) * bf_lo(qf[kq][e2]);
+                dDp[DMODE == 2 ? kq : 0][DMODE == 2 ? 2 * e2 + 1 : 0] += bf_hi(fa[e2]) * bf_hi(qf[kq][e2]);
+              }
+            }
+          }
+          const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[hh][16 * ta + 4 * g16]);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            v[r] = gt[r] * exp2_fast(cs_l + lw4[r]);
+            if (j == 0 ? diag0 : diag1) v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+          }
+#pragma unroll
+          for (int p2 = 0; p2 < 2; p2++) {
+            const uint32_t hi = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
+            mh[2 * j + p2] = hi;
+            ml[2 * j + p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi), v[2 * p2 + 1] - bf_hi(hi));
+          }
+        }
+#pragma unroll
+        for (int ut = 0; ut < 8; ut++) {
+          const uint16_t* pu = &sm.U[(o_mu ^ (ut << 4)) + 32 * 128 * kk];
+          const s16x4 u0 = lds_read_tr16_b64(pu);
+          const s16x4 u1 = lds_read_tr16_b64(pu + 16 * 128);
+          s16x8 fu;
+          fu[0] = u0[0]; fu[1] = u0[1]; fu[2] = u0[2]; fu[3] = u0[3]; fu[4] = u1[0]; fu[5] = u1[1]; fu[6] = u1[2]; fu[7] = u1[3];
+          acc[ut] = mfma16x16x32_bf16(fu, as_s16x8(mh), acc[ut]);
+          acc[ut] = mfma16x16x32_bf16(fu, as_s16x8(ml), acc[ut]);
+        }
+      };
+      if (w == 0) { block(0, false, true, false); }
+      else if (w == 1) { block(0, true, false, true); }
+      else if (w == 2) { block(0, true, false, false); block(1, false, true, false); }
+      else { block(0, true, false, false); block(1, true, false, true); }
+    }
+    prefetch_q();
+    // ---- (3) state update: S^T[p][n] = exp2(cs_end) S^T + sum_l (ws_l K[l][p]) U[l][n]
+    {
+      const float dec = sm.ecs[hh][QC - 1];
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) accS[ut] *= dec;
+#pragma unroll
+      for (int lb = 0; lb < 2; lb++) {
+        const s16x4 k0 = lds_read_tr16_b64(&sm.K[hh][(o_tk ^ (w << 4)) + 32 * 64 * lb]);
+        // rows + 4 flip row bit 2: the swizzle changes by swzK(4) = 3 segments
+        const s16x4 k1 = lds_read_tr16_b64(&sm.K[hh][(o_tk ^ (w << 4) ^ (3 << 3)) + 32 * 64 * lb + 4 * 64]);
+        const f32x4 s0v = *reinterpret_cast<const f32x4*>(&sm.ws[hh][32 * lb + 8 * g16]);
+        const f32x4 s1v = *reinterpret_cast<const f32x4*>(&sm.ws[hh][32 * lb + 8 * g16 + 4]);
+        u32x4 kp;
+        kp[0] = pack_bf16x2(bf16_to_f32((uint16_t)k0[0]) * s0v[0], bf16_to_f32((uint16_t)k0[1]) * s0v[1]);
+        kp[1] = pack_bf16x2(bf16_to_f32((uint16_t)k0[2]) * s0v[2], bf16_to_f32((uint16_t)k0[3]) * s0v[3]);
+        kp[2] = pack_bf16x2(bf16_to_f32((uint16_t)k1[0]) * s1v[0], bf16_to_f32((uint16_t)k1[1]) * s1v[1]);
+        kp[3] = pack_bf16x2(bf16_to_f32((uint16_t)k1[2]) * s1v[2], bf16_to_f32((uint16_t)k1[3]) * s1v[3]);
+#pragma unroll
+        for (int ut = 0; ut < 8; ut++) {
+          const s16x4 u0 = lds_read_tr16_b64(&sm.U[(o_su ^ (ut << 4)) + 32 * 128 * lb]);
+          const s16x4 u1 = lds_read_tr16_b64(&sm.U[(o_su ^ (ut << 4) ^ (3 << 3)) + 32 * 128 * lb + 4 * 128]);
+          s16x8 fu;
+          fu[0] = u0[0]; fu[1] = u0[1]; fu[2] = u0[2]; fu[3] = u0[3]; fu[4] = u1[0]; fu[5] = u1[1]; fu[6] = u1[2]; fu[7] = u1[3];
+          accS[ut] = mfma16x16x32_bf16(as_s16x8(kp), fu, accS[ut]);
+        }
+      }
+    }
+    if (MODE == GS_DC && ck) {   // forward state at the END of this chunk, fragment order, bf16 pairs
+      uint32_t* cp = ck + (int64_t)c * 8192 + wave * 1024;
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) cp[(2 * ut + j) * 64 + lane] = pack_bf16x2(accS[ut][2 * j], accS[ut][2 * j + 1]);
+    }
+    // ---- (4) token scalar of this head: X4_l . O_l (row l = 16 w + t16: 32 products per lane, 4 lanes per row)
+    const int trow = tlo + rtk_q;
+    {
+      float pv = 0.f;
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) {
+        const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.X4[(o_x4 ^ (ut << 4)) + 16 * 128 * w]);
+        pv += bf_lo(xr[0]) * acc[ut][0] + bf_hi(xr[0]) * acc[ut][1] + bf_lo(xr[1]) * acc[ut][2] + bf_hi(xr[1]) * acc[ut][3];
+      }
+      pv += shfl_xor(pv, 16);
+      pv += shfl_xor(pv, 32);
+      if (g16 == 0 && trow < a.L) tokscal[trow] = pv;
+    }
+    // ---- (5) dB: scale by dt'_l; head 1 hands its tiles over
+    if (MODE == GS_DB) {
+      const float dts = sm.dtl[hh][16 * w + t16];
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) acc[ut] *= dts;
+    }
+    if (hh == 1) {
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) *reinterpret_cast<f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]) = acc[ut];
+    }
+    block_sync();   // E: exchange buffer complete; nobody reads this chunk's tiles / scalars any more
+    if (hh == 0 && trow < a.L) {
+      float* prow = part + (int64_t)trow * 128 + 4 * g16;
+#pragma unroll
+      for (int ut = 0; ut < 8; ut++) {
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]);
+        *reinterpret_cast<f32x4*>(prow + 16 * ut) = acc[ut] + o1;
+      }
+    }
+    if (want_bnd) load_ckpt(cnext);
+    publish_state();
+    commit();
+    if (w == 0) scalars();
+    block_sync();   // Y
+  }
+  if (MODE == GS_DB && DMODE == 1) {
+    float v = wave_sum(dDp[0][0]);
+    if (lane == 0) sm.bred[wave] = v;
+    block_sync();
+    if (tid < 2) atomic_add_f32(a.dD + (int64_t)(h0 + tid) * a.dDsh, sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3]);
+  }
+  if (MODE == GS_DB && DMODE == 2) {
+    // dDp[kq][e]: column 32 kq + 8 g16 + e summed over this lane's rows; fold the 16 row lanes, then the 4 strips
+#pragma unroll
+    for (int kq = 0; kq < 2; kq++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = dDp[kq][e];
+        v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4); v += shfl_xor(v, 8);
+        if (t16 == 0) sm.dred[hh][w][32 * kq + 8 * g16 + e] = v;
+      }
+    block_sync();
+    if (tid < 128) {
+      const int r = tid >> 6, col = tid & 63;
+      float v = sm.dred[r][0][col] + sm.dred[r][1][col] + sm.dred[r][2][col] + sm.dred[r][3][col];
+      atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)col * a.dDsp, v);
+    }
+  }
+  if (a.fin) {
+    const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
+#pragma unroll
+    for (int ut = 0; ut < 8; ut++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int k = 16 * w + 4 * g16 + r, u = 16 * ut + t16;
+        a.fin[(int64_t)b * a.fsb + (int64_t)hcur * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = accS[ut][r] * extra;
+      }
+  }
+}
+
 // out[b][t][g][n] = sum over the head pairs of group g of part[b][pair][t][n]
 __global__ void ssd_reduce_partials_kernel(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt,
                                            int B, int L, int G, int pairs) {
@@ -1448,6 +1819,19 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
   if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !src_ok16(g.Q, true) || !src_ok16(g.X4, false)) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
   dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
+  const int64_t lim = (int64_t)1 << 24;   // the row-strip kernel keeps per-lane offsets in 32 bits
+  if (g.X4.p && g.tokscal && g.U.sl < lim && g.K.sl < lim && g.Q.sl < lim && g.X4.sl < lim && g.K.sh < lim && !getenv("OMK_SSD_B_V1")) {
+    const size_t smem3 = sizeof(SmemB3);
+#define OMK_B3(MODE_, DM_) do { \
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_b3_kernel<MODE_, DM_>), smem3)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem3); \
+      OMK_LAUNCH((ssd_mfma_b3_kernel<MODE_, DM_>), grid, block, smem3, stream, g); } while (0)
+    if (g.mode == GS_DC) OMK_B3(GS_DC, 0);
+    else if (!g.dD) OMK_B3(GS_DB, 0);
+    else if (g.dDsp == 0) OMK_B3(GS_DB, 1);
+    else OMK_B3(GS_DB, 2);
+#undef OMK_B3
+    return OMK_OK;
+  }
   const size_t smem = sizeof(SmemB);
   if (g.mode == GS_DC) {
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_b_kernel<GS_DC>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);

@@ -1,7 +1,8 @@
 """Developer tool: causal conv1d fwd / bwd timing at the 1.3B block shape (channel-last xBC slice of zxbcdt)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd.causal_conv1d import causal_conv1d_fn  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd.ssd_combined import ssd_scan_fwd, ssd_scan_bwd  # noqa: E402
 
 

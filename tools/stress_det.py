@@ -1,7 +1,8 @@
 """Developer tool: run the forward / backward scans repeatedly on identical inputs and compare bitwise (race detector)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd.ssd_combined import ssd_scan_fwd, ssd_scan_bwd  # noqa: E402
 
 dev = torch.device("cuda:0")
