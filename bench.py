@@ -137,6 +137,14 @@ def main():
         n_b, ms_b = prof.get("ssd_scan_bwd", (0, float("nan")))
         fwd_bytes = tok * SCAN_FWD_BYTES_PER_TOK
         ach = fwd_bytes / (ms_f * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of the same kernel at this shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot be read inside this process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "ssd_fwd_traffic.json")) as fh:
+                traffic = int(json.load(fh)["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "selective-scan M-elements/sec", "value": round(value, 1), "unit": "M-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -145,9 +153,10 @@ def main():
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
                        "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
-            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a_kernel<GS_Y> + dt prep)",
+            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4),
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_ssd_fwd_v3.txt" if traffic else None,
+                         "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4),
                          "launches_timed": n_f},
             "scan_bwd": {"launch_ms": round(ms_b, 4), "algorithmic_bytes_per_launch": tok * SCAN_BWD_BYTES_PER_TOK,
                          "achieved_GBs": round(tok * SCAN_BWD_BYTES_PER_TOK / (ms_b * 1e-3) / 1e9, 1), "launches_timed": n_b},
