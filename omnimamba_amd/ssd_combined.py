@@ -9,6 +9,7 @@ hipBLASLt through torch.  No PyTorch fallback for the scan.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -158,7 +159,9 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bia
 
 class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
     """conv1d+SiLU -> SSD scan -> gated RMSNorm -> out_proj as ONE autograd node (upstream K2; SURVEY.md section 8
-    row a9).  Saves only zxbcdt, the pre-norm y and the parameters; the conv output is recomputed in backward."""
+    row a9).  Saves zxbcdt, the pre-norm y and the parameters.  Upstream recomputes the conv output and the norm output
+    in backward to save memory; with 288 GB of HBM the default here keeps them (0.55 GB per 32k-token block call, 0.33 ms
+    of recompute saved per block backward).  OMK_RECOMPUTE=1 restores upstream's memory behaviour."""
 
     @staticmethod
     def forward(ctx, zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None, seq_idx=None,
@@ -202,14 +205,17 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
             out = F.linear(out_n, w, None if outproj_bias is None else outproj_bias.to(out_n.dtype))
         else:
             out = out_n
+        keep = os.environ.get("OMK_RECOMPUTE", "0") != "1"
         ctx.save_for_backward(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, y_pre, rmsnorm_weight, outproj_weight,
-                              outproj_bias, initial_states)
+                              outproj_bias, initial_states, xBC_c if keep else None,
+                              out_n if (keep and use_norm and outproj_weight is not None) else None)
         ctx.cfg = (H, P, G, N, chunk_size, dt_limit, activation, rmsnorm_eps, norm_before_gate, return_final_states)
         return (out, fin) if return_final_states else out
 
     @staticmethod
     def backward(ctx, dout, *args):
-        (zxbcdt, conv_w, conv_b, dt_bias, A, D, y_pre, norm_w, outproj_w, outproj_b, initial_states) = ctx.saved_tensors
+        (zxbcdt, conv_w, conv_b, dt_bias, A, D, y_pre, norm_w, outproj_w, outproj_b, initial_states, xBC_saved,
+         on_saved) = ctx.saved_tensors
         H, P, G, N, chunk_size, dt_limit, activation, eps, nbg, ret_fin = ctx.cfg
         dfinal = args[0] if ret_fin and args else None
         Bsz, L, _ = zxbcdt.shape
@@ -219,16 +225,19 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
         dzxbcdt = torch.empty_like(zxbcdt)
         dz, dxBC, ddt_v = torch.split(dzxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
-        # ---- out_proj (recompute the cheap norm output: it is the GEMM's other operand)
+        # ---- out_proj: its wgrad needs the norm output (kept, or recomputed when OMK_RECOMPUTE=1)
         dout = dout.to(adt)
         d_outproj_w = d_outproj_b = None
         y2 = y_pre.reshape(Bsz, L, d_ssm)
+        lib = get_lib()
         if use_norm:
-            with torch.enable_grad():
-                yd, zd = y2.detach().requires_grad_(), z.detach().requires_grad_()
-                wd = norm_w.detach().requires_grad_()
-                out_n = rmsnorm_fn(yd, wd, None, z=zd, eps=eps, group_size=d_ssm // G, norm_before_gate=nbg)
-            on = out_n.detach()
+            if on_saved is not None:
+                on = on_saved
+            elif outproj_w is not None:
+                with torch.no_grad():
+                    on = rmsnorm_fn(y2, norm_w, None, z=z, eps=eps, group_size=d_ssm // G, norm_before_gate=nbg)
+            else:
+                on = None
         else:
             on = (y2.float() * F.silu(z.float())).to(adt)
         if outproj_w is not None:
@@ -238,19 +247,35 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
                 d_outproj_b = dout.reshape(-1, dout.shape[-1]).sum(0).to(outproj_b.dtype)
         else:
             d_outn = dout
-        # ---- gated norm (or plain gate) backward
+        # ---- gated norm (or plain gate) backward: dz lands in the z slice of dzxbcdt, no copy
         d_norm_w = None
         if use_norm:
-            gy, gz, gw = torch.autograd.grad(out_n, [yd, zd, wd], d_outn)
-            dy = gy
-            dz.copy_(gz)
+            rows = Bsz * L
+            y_r = y2.reshape(rows, d_ssm)
+            z_r = z.as_strided((rows, d_ssm), (zxbcdt.stride(1), 1), z.storage_offset()) if zxbcdt.stride(0) == L * zxbcdt.stride(1) else z.reshape(rows, d_ssm)
+            dz_r = dz.as_strided((rows, d_ssm), (dzxbcdt.stride(1), 1), dz.storage_offset())
+            g_r = d_outn.reshape(rows, d_ssm)
+            if g_r.dtype != adt:
+                g_r = g_r.to(adt)
+            if g_r.stride(-1) != 1:
+                g_r = g_r.contiguous()
+            dy = torch.empty(Bsz, L, d_ssm, dtype=adt, device=dev)
+            gw = torch.zeros(d_ssm, dtype=torch.float32, device=dev)
+            pn = K.NormGatedBwd(dy=K.T(g_r), x=K.T(y_r), z=K.T(z_r), weight=K.T(norm_w), dx=K.T(dy.reshape(rows, d_ssm)),
+                                dz=K.T(dz_r), dweight=K.T(gw), group_size=d_ssm // G, eps=eps, norm_before_gate=int(nbg))
+            wsn = K.workspace(lib, "omk_norm_gated_bwd_workspace_bytes", pn, g_r)  # noqa: F841
+            K.run(lib, "omk_norm_gated_bwd", pn, g_r)
             d_norm_w = gw.to(norm_w.dtype)
         else:
             zf = z.float()
             dz.copy_((d_outn.float() * y2.float() * _silu_grad(zf)).to(adt))
             dy = (d_outn.float() * F.silu(zf)).to(adt)
-        # ---- recompute conv, SSD backward writes straight into the dxBC_conv buffer
-        xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv_w, conv_b, activation=activation).transpose(1, 2)
+        # ---- conv output (kept or recomputed); the SSD backward writes straight into the dxBC_conv buffer
+        if xBC_saved is not None:
+            xBC_c = xBC_saved
+        else:
+            with torch.no_grad():
+                xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv_w, conv_b, activation=activation).transpose(1, 2)
         x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
         dxBC_c = torch.empty_like(xBC_c)
         dx_v, dB_v, dC_v = torch.split(dxBC_c, [d_ssm, G * N, G * N], dim=-1)
@@ -261,7 +286,6 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
                          dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)))
         ddt_v.copy_(g["ddt"])
         # ---- conv backward: dx lands in the xBC slice of dzxbcdt
-        lib = get_lib()
         dw = torch.zeros(conv_w.shape, dtype=torch.float32, device=dev)
         db = None if conv_b is None else torch.zeros(conv_b.shape, dtype=torch.float32, device=dev)
         p = K.Conv1dBwd(x=K.T(xBC.transpose(1, 2)), weight=K.T(conv_w), bias=K.T(conv_b), initial_states=K.T(None),
