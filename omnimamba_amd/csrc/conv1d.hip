@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
   const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
   // groups of TG tokens: all TG row loads are issued before the first one is consumed (a strictly sequential walk
   // exposes one HBM latency per token)
+#pragma unroll 1
   for (int lg = l0; lg < lend; lg += TG) {
     vec_t<T, VEC> raw[TG];
 #pragma unroll
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
   // dpre of the W-1 positions before l0 is NOT needed: dx[lo] only uses dpre[lo .. lo+W-1], lo >= l0.
   const int pend = lend + W - 1;
   const T* xb = x + (int64_t)b * a.xsb + c0;
+#pragma unroll 1
   for (int pg = l0; pg < pend; pg += TG) {
     vec_t<T, VEC> rawx[TG], rawg[TG];
 #pragma unroll

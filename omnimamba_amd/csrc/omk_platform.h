@@ -190,6 +190,12 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
+// Register budget hint: at least N waves per SIMD (the compiler caps VGPRs at 512 / N)
+#ifdef OMK_EMU
+#define OMK_WAVES_PER_EU(n)
+#else
+#define OMK_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 // Make a lane value opaque to the optimiser at this point: address arithmetic derived from it afterwards stays inside
 // the loop instead of being hoisted into (many) loop-invariant registers.
 #ifdef OMK_EMU

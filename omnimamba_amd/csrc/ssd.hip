@@ -252,6 +252,43 @@ __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   }
 }
 
+// MFMA path: with the exact restart values bnd every 64-token tile is independent.  One 1024-thread block per (b, h),
+// wave w takes tiles w, w + 16, ...; the dA / d(dt_bias) partials meet in LDS so each block issues two atomics.
+__global__ __launch_bounds__(1024) void ssd_bwd_finish_par_kernel(FinishArgs a) {
+  __shared__ float red[2][16];
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)bh * a.L;
+  const float Ah = a.A[h];
+  const int nT = (a.L + 63) / 64;
+  float dAacc = 0.f, dbacc = 0.f;
+  for (int ti = wave; ti < nT; ti += 16) {
+    const float carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1];
+    const int t = ti * 64 + lane;
+    const bool ok = t < a.L;
+    const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
+    const float ds = ok ? a.dsoft[base + t] : 0.f;
+    const float v0 = ok ? a.e[base + t] - d * w : 0.f;
+    // inclusive suffix sum = total - exclusive prefix
+    const float incl = wave_incl_scan_add(v0);
+    const float dl = wave_read_lane(incl, 63) - incl + v0 + carry;
+    if (ok) {
+      const float draw = (w + Ah * dl) * ds;
+      dAacc += d * dl;
+      dbacc += draw;
+      store_rt(a.ddt, (int64_t)b * a.dsb + (int64_t)t * a.dsl + (int64_t)h * a.dsh, a.ddt_dt, draw);
+    }
+  }
+  dAacc = wave_sum(dAacc); dbacc = wave_sum(dbacc);
+  if (lane == 0) { red[0][wave] = dAacc; red[1][wave] = dbacc; }
+  block_sync();
+  if (threadIdx.x < 2) {
+    float s = 0.f;
+    for (int i = 0; i < 16; i++) s += red[threadIdx.x][i];
+    if (threadIdx.x == 0) atomic_add_f32(a.dA + h, s);
+    else if (a.ddtb) atomic_add_f32(a.ddtb + h, s);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -475,8 +512,13 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     f.ddt = p->ddt.data; f.dsb = p->ddt.stride[0]; f.dsl = p->ddt.stride[1]; f.dsh = p->ddt.stride[2]; f.ddt_dt = p->ddt.dtype;
     f.bnd = mfma ? w.bnd : nullptr;
     f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
-    dim3 grid((unsigned)(d.B * d.H)), block(64);
-    OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);
+    if (f.bnd && !f.dfin) {
+      dim3 grid((unsigned)(d.B * d.H)), block(1024);
+      OMK_LAUNCH(ssd_bwd_finish_par_kernel, grid, block, 0, stream, f);
+    } else {
+      dim3 grid((unsigned)(d.B * d.H)), block(64);
+      OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);
+    }
   }
   if (!mfma) {
     int64_t blocks = (blgn + 255) / 256;
