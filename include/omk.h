@@ -223,9 +223,8 @@ typedef struct {
   OmkTensor x, dt, A, Bm, Cm, D, dt_bias, initial_states; /* as forward.  z gating is NOT part of this call: the
                                 caller passes dout * silu(z) and forms dz = dout * out_x * silu'(z) itself (out_x = the
                                 forward's pre-gate output) */
-  OmkTensor y;               /* optional (B, L, H, P): the forward's pre-gate output (D*x included).  Required by the
-                                MFMA path (it turns dt/A gradients into one elementwise pass); without it the
-                                shape-generic kernels are used */
+  OmkTensor y;               /* optional (B, L, H, P): the forward's pre-gate output.  Accepted for signature parity with
+                                upstream's backward; no kernel reads it (the scans recompute what they need) */
   OmkTensor dout;            /* (B, L, H, P) grad of the (pre-gate) output */
   OmkTensor dfinal_states;   /* optional (B, H, P, N) f32 */
   OmkTensor dx;              /* out (B, L, H, P) */

@@ -37,11 +37,7 @@ struct GScan {
   const void* D; int64_t Dsh, Dsp; int D_dt;                     // Y, DX
   float* acc32;                                                  // DC/DB: (B, L, G, DU) f32, atomically accumulated
   float* tokscal;                                                // DC: e, DB: wsum  (B, H, L) f32, atomically accumulated
-  float* dD; int64_t dDsh, dDsp;                                 // DB (or DX with XE): optional grad of D
-  // DX only, optional: x (XE) and the forward's pre-gate output y (YE) -> the scan also emits the two token
-  // scalars of the backward (wsum_t = sum_p x O, esum_t = sum_p dy (y - D x)) and dD, with plain stores
-  Src XE, YE;
-  float* esum; float* wsum;                                      // (B, H, L) f32
+  float* dD; int64_t dDsh, dDsp;                                 // DB: optional grad of D
   float* part;                                                   // DC/DB (MFMA): (B, H/2, L, 128) f32 per-head-pair partial tiles
   // DC/DB (MFMA): forward-state checkpoints at every chunk end, written by the dC scan in MFMA fragment order
   // (bf16 pairs) and read back by the dB scan, which emits the exact decay-gradient restart values bnd (B, H, nC + 1)

@@ -25,22 +25,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 off = ((B * H * L * 4 + 255) // 256) * 256
 nC = L // 64
-if not os.environ.get("OMK_SSD_A_V1"):
-    prof = ws[off:off + 4 * 12 * 8].view(torch.int64).cpu().view(4, 12)
-    if os.environ.get("OMK_SSD_A_V2"):
-        names = ["prefetch", "scal+G", "waitB1", "Mbuild+MU", "Q.S", "ov", "S-update", "waitB2", "pub+commit", "epilogue", "waitB3", "-"]
-    else:
-        names = ["prefetch", "Q.S", "waitX", "G+M+MU", "S-update", "pub+commit", "epilogue", "waitY", "-", "-", "-", "-"]
-    print(f"B={B}: cycles per chunk, per wave   " + " ".join(f"{n:>10s}" for n in names) + "      total")
-    for w in range(4):
-        row = prof[w].double() / nC
-        print(f"wave {w}:                         " + " ".join(f"{v:10.0f}" for v in row.tolist()) + f" {row.sum():10.0f}")
-    sys.exit(0)
-prof = ws[off:off + 8 * 10 * 8].view(torch.int64).cpu().view(8, 10)
-names = ["prefetch", "scal+G", "waitB1", "O-chain", "S-update", "waitB2", "pub+add", "waitB3", "epi+commit", "waitB4"]
-print("cycles per chunk, per wave (wave: role)   " + " ".join(f"{n:>10s}" for n in names) + "      total")
-for w in range(8):
-    hh, wi, wj = w >> 2, (w >> 1) & 1, w & 1
-    role = "D" if ((wj ^ hh) & 1) == 0 else "S"
-    row = prof[w].double() / nC
-    print(f"wave {w} (h{hh} l{wi} {role}):                      " + " ".join(f"{v:10.0f}" for v in row.tolist()) + f" {row.sum():10.0f}")
+prof = ws[off:off + 4 * 12 * 8].view(torch.int64).cpu().view(4, 12)
+names = ["top", "Q.S", "waitX", "G+M+MU", "S-update", "pub+commit", "epilogue", "waitY"]
+print(f"B={B}: cycles per chunk, per wave (= strip)   " + " ".join(f"{n:>10s}" for n in names) + "      total")
+for w in range(4):
+    row = prof[w].double()[:8] / nC
+    print(f"wave {w}:                         " + " ".join(f"{v:10.0f}" for v in row.tolist()) + f" {row.sum():10.0f}")
