@@ -446,7 +446,9 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
       if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, VEC_, TL, 4, TG_>), grid, block, 0, stream, a); \
       else if (a.W == 3) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, VEC_, TL, 3, TG_>), grid, block, 0, stream, a); \
       else OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, VEC_, TL, 2, TG_>), grid, block, 0, stream, a); } while (0)
-    if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 4, 4); else CONV_BWD_V(f16_t, 4, 4);
+    // 2 channels per lane: 86 VGPRs / 5 waves per SIMD; the silu' recompute makes this kernel VALU- and latency-heavy
+    // (4 channels: 154 VGPRs, 383 us; 2 channels: ~290 us on the 1.3B shape)
+    if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 4); else CONV_BWD_V(f16_t, 2, 4);
 #undef CONV_BWD_V
   } else {
     int64_t n = (int64_t)a.B * a.C;

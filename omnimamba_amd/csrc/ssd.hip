@@ -204,7 +204,7 @@ struct FinishArgs {
   const float* dfin; int64_t dfsb, dfsh, dfsp, dfsn; const float* sfin;   // sfin: (B, H, N, P) contiguous f32 from the dC scan
   void* ddt; int64_t dsb, dsl, dsh; int ddt_dt;
   float* dA; float* ddtb;
-  const float* bnd;   // optional (B, H, nT + 1): exact value of dl at the first token of tile ti + 1 (MFMA path)
+  const float* bnd;   // optional (B, H, nT + 1): < g, h > at the boundary behind tile ti (MFMA path): dl restarts from exp(a) * bnd
   int B, H, L, P, N;
 };
 __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
@@ -224,7 +224,10 @@ __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   const int nT = (a.L + 63) / 64;
   for (int ti = nT - 1; ti >= 0; ti--) {
     // bf16-level errors in e / w must not accumulate over the whole sequence: restart from the exact boundary value
-    if (a.bnd) carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1];
+    if (a.bnd) {
+      const int tn = (ti + 1) * 64;   // bnd holds < g, h > at the boundary; the decay of the first token behind it is applied here
+      carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
+    }
     const int t = ti * 64 + lane;
     const bool ok = t < a.L;
     const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(1024) void ssd_bwd_finish_par_kernel(FinishArgs a) 
   const int nT = (a.L + 63) / 64;
   float dAacc = 0.f, dbacc = 0.f;
   for (int ti = wave; ti < nT; ti += 16) {
-    const float carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1];
+    const int tn = (ti + 1) * 64;   // bnd holds < g, h > at the boundary; apply the decay of the first token behind it
+    const float carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
     const int t = ti * 64 + lane;
     const bool ok = t < a.L;
     const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;

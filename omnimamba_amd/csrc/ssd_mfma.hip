@@ -557,7 +557,9 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
   publish_state();
   block_sync();
   float* part = a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
-  // state checkpoints in fragment order: [b][pair][chunk][wave 8][ut 8][reg pair 2][lane 64] packed bf16 pairs (u32)
+  // state checkpoints in fragment order: [b][pair][chunk][wave 8][q 4][lane 64][4] packed bf16 pairs (u32), entry
+  // (q, i) = tile ut = 2 q + (i >> 1), register pair i & 1: four fully coalesced 16-byte accesses per lane (sixteen
+  // 4-byte loads per lane cost the dB scan 108 us)
   uint32_t* ck = a.ckpt ? (uint32_t*)a.ckpt + ((int64_t)b * pairs + hp) * (int64_t)nC * 8192 : nullptr;
   float* tokscal = a.tokscal + ((int64_t)b * a.H + hcur) * a.L;
   float dDp[DMODE == 2 ? 2 : 1][DMODE == 2 ? 8 : 1];
@@ -567,11 +569,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     for (int e = 0; e < (DMODE == 2 ? 8 : 1); e++) dDp[i][e] = 0.f;
   const bool want_bnd = MODE == GS_DB && ck != nullptr && a.bnd != nullptr;
   // checkpoint of the chunk the NEXT iteration closes, fetched while the output registers are dead
-  uint32_t ckv[16];
+  u32x4 ckv[4];
   auto load_ckpt = [&](int c) {
-    const uint32_t* cp = ck + (int64_t)(nC - 1 - c) * 8192 + wave * 1024;
+    const uint32_t* cp = ck + (int64_t)(nC - 1 - c) * 8192 + wave * 1024 + lane * 4;
 #pragma unroll
-    for (int i = 0; i < 16; i++) ckv[i] = cp[i * 64 + lane];
+    for (int i = 0; i < 4; i++) ckv[i] = ld16(cp + 256 * i);
   };
   if (want_bnd) load_ckpt(0);
 
@@ -581,12 +583,16 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     OMK_OPAQUE(o_mu); OMK_OPAQUE(o_su); OMK_OPAQUE(o_x4); OMK_OPAQUE(o_ps); OMK_OPAQUE(o_tk);
     if (want_bnd) {
       // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
-      //   bnd[id + 1] = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan checkpoint of chunk id) >
+      //   dl(first token of chunk id + 1) = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan
+      //   checkpoint of chunk id) >;  bnd[id + 1] holds the inner product
       float dot = 0.f;
 #pragma unroll
       for (int ut = 0; ut < 8; ut++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) dot += accS[ut][2 * j] * bf_lo(ckv[2 * ut + j]) + accS[ut][2 * j + 1] * bf_hi(ckv[2 * ut + j]);
+        for (int j = 0; j < 2; j++) {
+          const uint32_t hv = ckv[ut >> 1][2 * (ut & 1) + j];
+          dot += accS[ut][2 * j] * bf_lo(hv) + accS[ut][2 * j + 1] * bf_hi(hv);
+        }
       dot = wave_sum(dot);
       if (lane == 0) sm.bred[wave] = dot;
     }
@@ -607,12 +613,8 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       for (int ut = 0; ut < 8; ut++) acc[ut] *= e1;
     }
     block_sync();   // X: every wave is done with S_in (and bred is complete)
-    if (want_bnd && tid < 2) {
-      const int id = nC - 1 - c, hd = h0 + tid;
-      const int tnext = (id + 1) * QC;
-      const float ex = tnext < a.L ? expf(a.dtp[((int64_t)b * a.H + hd) * a.L + tnext] * a.A[hd]) : 1.f;
-      a.bnd[((int64_t)b * a.H + hd) * (nC + 1) + id + 1] = ex * (sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3]);
-    }
+    if (want_bnd && tid < 2)   // raw < g, h >; the finish pass applies exp(a_first(id + 1)) (no dependent global load here)
+      a.bnd[((int64_t)b * a.H + h0 + tid) * (nC + 1) + (nC - 1 - c) + 1] = sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3];
     stlo = chunk_lo(cnext);
     prefetch_tiles();
     // ---- (2) intra-chunk: G tiles -> M fragments (registers) -> U^T . M^T
@@ -696,11 +698,17 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       }
     }
     if (MODE == GS_DC && ck) {   // forward state at the END of this chunk, fragment order, bf16 pairs
-      uint32_t* cp = ck + (int64_t)c * 8192 + wave * 1024;
+      uint32_t* cp = ck + (int64_t)c * 8192 + wave * 1024 + lane * 4;
 #pragma unroll
-      for (int ut = 0; ut < 8; ut++)
+      for (int q = 0; q < 4; q++) {
+        u32x4 v;
 #pragma unroll
-        for (int j = 0; j < 2; j++) cp[(2 * ut + j) * 64 + lane] = pack_bf16x2(accS[ut][2 * j], accS[ut][2 * j + 1]);
+        for (int i = 0; i < 4; i++) {
+          const int ut = 2 * q + (i >> 1), j = i & 1;
+          v[i] = pack_bf16x2(accS[ut][2 * j], accS[ut][2 * j + 1]);
+        }
+        st16(cp + 256 * q, v);
+      }
     }
     // ---- (4) token scalar of this head: X4_l . O_l (row l = 16 w + t16: 32 products per lane, 4 lanes per row)
     const int trow = tlo + rtk_q;
