@@ -1,7 +1,9 @@
 """Plain library GEMMs (in_proj / out_proj and their gradients) stay with hipBLASLt / rocBLAS; this module only picks
 WHICH library solution runs, through PyTorch's TunableOp, from a results file recorded on an MI355X
 (`tools/tune_gemms.py`, 1.3B block shapes: tokens 32768 x {2048 -> 8512, 4096 -> 2048} and their dgrad / wgrad forms).
-The default heuristic leaves ~20 % on the table for these shapes (e.g. in_proj forward 1.49 ms -> 0.60 ms).
+Measured effect on real activations (`tools/gemm_ab.py`): 1-3 % of the GEMM time -- TunableOp times its candidates on
+idle-clock buffers, so the 0.6 ms it records for the in_proj forward is 0.96 ms under load.  The weight-gradient GEMMs
+are helped more by the token split in `omnimamba_amd/linear.py`.
 
 The file carries validators (PyTorch / ROCm / hipBLASLt versions, gfx arch); on any mismatch TunableOp ignores it and
 the default solutions run, so enabling this is always safe.

@@ -1,0 +1,102 @@
+"""Dense projections of the block (in_proj, out_proj): plain library GEMMs through torch, with one MI355X-specific
+choice -- how the WEIGHT gradient is formed.
+
+dW = dy^T x contracts over the tokens (K = batch * seqlen = 32 768 at the benchmark shape) into a small (out, in) matrix.
+For in_proj that is 8512 x 2048 = 34 x 8 = 272 output tiles of 256 x 256 on a 256-CU device: one full round plus a
+16-tile tail, i.e. half the chip idles for half the GEMM (measured 1.45-1.5 ms = 0.76 PFLOP/s with every hipBLASLt /
+rocBLAS solution TunableOp could find).  Splitting the token dimension into S slices and running ONE batched GEMM
+(S x tiles work items, fp32 partial outputs) followed by an fp32 sum fills the rounds: 1.15 ms at S = 4.  The fp32
+partials make the result more accurate than the single bf16-output GEMM it replaces (the weights are fp32 masters).
+
+`linear(x, weight, bias)` is `F.linear` with that backward; it is what `Mamba2` uses for a plain `nn.Linear` in_proj and
+what `TaskLoRALinear` uses for its base weight.  Anything unusual (no GPU, fp32 autocast-off training, tiny token counts)
+takes the ordinary matmul.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+_TILE = 256
+
+
+def _n_cu(device) -> int:
+    try:
+        return torch.cuda.get_device_properties(device).multi_processor_count
+    except Exception:
+        return 256
+
+
+def split_factor(m: int, n: int, k: int, device) -> int:
+    """Slices of the contraction dimension for a (m x n) output: the smallest S in {2, 4, 8} whose S * tiles work items
+    fill at least 80 % of the CU rounds, when the unsplit GEMM fills less than 75 %."""
+    if os.environ.get("OMK_WGRAD_SPLITK", "1") == "0":
+        return 1
+    cu = _n_cu(device)
+    tiles = -(-m // _TILE) * -(-n // _TILE)
+
+    def eff(s):
+        items = s * tiles
+        return items / (-(-items // cu) * cu)
+
+    if eff(1) >= 0.75:
+        return 1
+    best = 1
+    for s in (2, 4, 8):
+        if k % s or k // s < 2048:
+            break
+        best = s
+        if eff(s) >= 0.8:
+            break
+    return best
+
+
+def weight_grad(dy2d: torch.Tensor, x2d: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """dW (out, in) = dy2d^T (tokens, out) @ x2d (tokens, in), accumulated in fp32."""
+    k, m = dy2d.shape
+    n = x2d.shape[1]
+    if (dy2d.is_cuda and dy2d.dtype in (torch.bfloat16, torch.float16) and dy2d.is_contiguous() and x2d.is_contiguous()):
+        s = split_factor(m, n, k, dy2d.device)
+        if s > 1:
+            part = torch.bmm(dy2d.view(s, k // s, m).transpose(1, 2), x2d.view(s, k // s, n), out_dtype=torch.float32)
+            return part.sum(0).to(out_dtype)
+    return (dy2d.t() @ x2d).to(out_dtype)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.wdtype, ctx.bdtype = weight.dtype, None if bias is None else bias.dtype
+        if torch.is_autocast_enabled():
+            adt = torch.get_autocast_dtype("cuda")
+            x, weight = x.to(adt), weight.to(adt)
+            bias = None if bias is None else bias.to(adt)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight.to(dy.dtype)
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if ctx.needs_input_grad[1]:
+            dy2c = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            x2 = x.reshape(-1, x.shape[-1])
+            dw = weight_grad(dy2c, x2 if x2.is_contiguous() else x2.contiguous(), ctx.wdtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0).to(ctx.bdtype)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear whose weight gradient is formed with `weight_grad` (same forward arithmetic)."""
+    if not x.is_cuda:
+        return F.linear(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias)

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 from .layernorm_gated import RMSNorm as RMSNormGated
+from .linear import linear
 from .selective_state_update import selective_state_update
 from .ssd_combined import mamba_chunk_scan_combined, mamba_split_conv1d_scan_combined
 
@@ -109,7 +110,9 @@ class Mamba2(nn.Module):
                 out, _, _ = self.step(u, conv_state, ssm_state)
                 return out
 
-        zxbcdt = self.in_proj(u)
+        # a plain nn.Linear in_proj goes through omnimamba_amd.linear (same forward GEMM, token-split weight gradient);
+        # any replacement module (the reference's LoRA wrapper) is simply called
+        zxbcdt = linear(u, self.in_proj.weight, self.in_proj.bias) if type(self.in_proj) is nn.Linear else self.in_proj(u)
         if seqlen_og is not None:
             zxbcdt = zxbcdt.view(batch, seqlen, -1)
         A = -torch.exp(self.A_log.float())

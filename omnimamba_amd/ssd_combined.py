@@ -19,6 +19,7 @@ from . import _prof
 from ._lib import get_lib, require_device
 from .causal_conv1d import causal_conv1d_fn
 from .layernorm_gated import rmsnorm_fn
+from .linear import weight_grad
 
 _INF = float("inf")
 
@@ -242,7 +243,9 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
             on = (y2.float() * F.silu(z.float())).to(adt)
         if outproj_w is not None:
             d_outn = dout @ outproj_w.to(adt)
-            d_outproj_w = (dout.reshape(-1, dout.shape[-1]).t() @ on.reshape(-1, d_ssm)).to(outproj_w.dtype)
+            do2, on2 = dout.reshape(-1, dout.shape[-1]), on.reshape(-1, d_ssm)
+            d_outproj_w = weight_grad(do2 if do2.is_contiguous() else do2.contiguous(), on2 if on2.is_contiguous() else on2.contiguous(),
+                                      outproj_w.dtype)
             if outproj_b is not None:
                 d_outproj_b = dout.reshape(-1, dout.shape[-1]).sum(0).to(outproj_b.dtype)
         else:

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layer_norm import RMSNorm, layer_norm_fn
+from .linear import linear
 from .mamba2 import Mamba2
 
 CausalLMOutput = namedtuple("CausalLMOutput", ["t2i_logits", "mmu_logits"])
@@ -73,7 +74,7 @@ class TaskLoRALinear(nn.Linear):
             nn.init.zeros_(getattr(self, f"{task}_lora_B0").weight)
 
     def forward(self, x):
-        result = F.linear(x, self.weight, self.bias)
+        result = linear(x, self.weight, self.bias)   # F.linear; token-split weight gradient when the base weight trains
         if self.disable_adapters or self.task_types not in ("t2i", "mmu"):
             return result
         A = getattr(self, f"{self.task_types}_lora_A0")
