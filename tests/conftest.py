@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng():
+    """Several tests draw module-style parameters (A, dt_bias, upstream gradients) from torch's global generator; without a
+    seed their inputs -- and with them a few tolerance-edge assertions -- depended on which tests ran before."""
+    import torch
+    torch.manual_seed(20240928)
+    yield
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
