@@ -186,13 +186,16 @@ typedef struct {
   OmkTensor dout;                                  /* (B, D, L) */
   OmkTensor du, ddelta;                            /* out (B, D, L) */
   OmkTensor dA;                                    /* out (D, N) f32 accumulated */
-  OmkTensor dB, dC;                                /* out (B, G, N, L) f32 accumulated (variable B/C only) */
+  OmkTensor dB, dC;                                /* out f32 accumulated: (B, G, N, L) for variable B / C, (D, N) for constant */
   OmkTensor dD;                                    /* optional out (D) f32 accumulated */
   OmkTensor dz;                                    /* optional out (B, D, L) */
   OmkTensor ddelta_bias;                           /* optional out (D) f32 accumulated */
+  void* workspace;                                 /* state checkpoints of the recomputed forward */
+  size_t workspace_bytes;
   int32_t delta_softplus;
 } OmkSelScanBwd;
-int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);
+size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p);
+int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* d_state <= 16 */
 
 /* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------
  * upstream mamba_ssm.ops.triton.ssd_combined.mamba_chunk_scan_combined (+ the scan stage of

@@ -64,7 +64,7 @@ StateUpdate = _S("OmkStateUpdate", [(n, _t) for n in ("state", "x", "dt", "A", "
 SelScanFwd = _S("OmkSelScanFwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "out",
                                                     "last_state")] + [("delta_softplus", _i)])
 SelScanBwd = _S("OmkSelScanBwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "dout", "du",
-                                                    "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")]
+                                                    "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")] + _ws
                 + [("delta_softplus", _i)])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states")] + _ws
@@ -84,7 +84,7 @@ SYMBOLS = [
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
     "omk_selective_state_update",
-    "omk_selective_scan_fwd", "omk_selective_scan_bwd",
+    "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
 ]
 

@@ -1,4 +1,4 @@
-// selscan.hip -- Mamba-1 selective scan forward (selective_scan_fn signature, BASELINE.json configs[0]).
+// selscan.hip -- Mamba-1 selective scan, forward and backward (selective_scan_fn signature, BASELINE.json configs[0]).
 //
 //   x_t = exp(delta_t A[d,:]) x_{t-1} + delta_t B_t u_t ;  y_t = <C_t, x_t> ;  out = (y + D u) * silu(z)
 //
@@ -17,37 +17,38 @@ constexpr int SS_TL = 32;
 struct SsArgs {
   const void* u; const void* delta; const void* A; const void* Bm; const void* Cm; const void* D; const void* z; const void* dbias;
   void* out; float* last;
+  float* ckpt; int TLB, nTB;   // optional: state at the start of every TLB-token tile, (B, D, nTB, N) f32 (backward)
   int64_t usb, usd, usl, dsb, dsd, dsl, zsb, zsd, zsl, osb, osd, osl;
   int64_t Asd, Asn, Bsb, Bsg, Bsn, Bsl, Csb, Csg, Csn, Csl;   // for constant B/C: Bsg = stride over d, Bsn over n
   int B, Dm, L, N, G, DT, softplus, Bvar, Cvar, adt, bdt, cdt, ddt, dbdt;
 };
 
-template <class T>
+template <class T, int TL = SS_TL>
 __device__ __forceinline__ void ss_load_tile(const T* g, int64_t sd, int64_t sl, int d0, int nd, int l0, int nl, T* s, int DT) {
   // s[t][c] <- g[(d0+c)*sd + (l0+t)*sl]
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (sl == 1 && sd != 1) {
-    for (int i = tid; i < DT * SS_TL; i += nthr) {
-      int c = i / SS_TL, t = i % SS_TL;
+    for (int i = tid; i < DT * TL; i += nthr) {
+      int c = i / TL, t = i % TL;
       s[t * DT + c] = (c < nd && t < nl) ? g[(int64_t)(d0 + c) * sd + (int64_t)(l0 + t)] : T{};
     }
   } else {
-    for (int i = tid; i < DT * SS_TL; i += nthr) {
+    for (int i = tid; i < DT * TL; i += nthr) {
       int t = i / DT, c = i % DT;
       s[t * DT + c] = (c < nd && t < nl) ? g[(int64_t)(d0 + c) * sd + (int64_t)(l0 + t) * sl] : T{};
     }
   }
 }
-template <class T>
+template <class T, int TL = SS_TL>
 __device__ __forceinline__ void ss_store_tile(T* g, int64_t sd, int64_t sl, int d0, int nd, int l0, int nl, const T* s, int DT) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (sl == 1 && sd != 1) {
-    for (int i = tid; i < DT * SS_TL; i += nthr) {
-      int c = i / SS_TL, t = i % SS_TL;
+    for (int i = tid; i < DT * TL; i += nthr) {
+      int c = i / TL, t = i % TL;
       if (c < nd && t < nl) g[(int64_t)(d0 + c) * sd + (int64_t)(l0 + t)] = s[t * DT + c];
     }
   } else {
-    for (int i = tid; i < DT * SS_TL; i += nthr) {
+    for (int i = tid; i < DT * TL; i += nthr) {
       int t = i / DT, c = i % DT;
       if (c < nd && t < nl) g[(int64_t)(d0 + c) * sd + (int64_t)(l0 + t) * sl] = s[t * DT + c];
     }
@@ -85,7 +86,7 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
   const T* ug = (const T*)a.u + (int64_t)b * a.usb;
   const T* dg = (const T*)a.delta + (int64_t)b * a.dsb;
   const T* zg = a.z ? (const T*)a.z + (int64_t)b * a.zsb : nullptr;
-  T* og = (T*)a.out + (int64_t)b * a.osb;
+  T* og = a.out ? (T*)a.out + (int64_t)b * a.osb : nullptr;
   for (int l0 = 0; l0 < a.L; l0 += SS_TL) {
     const int nl = (a.L - l0) < SS_TL ? (a.L - l0) : SS_TL;
     ss_load_tile<T>(ug, a.usd, a.usl, d0, nd, l0, nl, su, DT);
@@ -98,6 +99,12 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
     }
     block_sync();
     for (int t = 0; t < nl; t++) {
+      if (a.ckpt && live && ((l0 + t) % a.TLB) == 0) {   // state BEFORE token l0 + t (backward restarts here)
+        float* cp = a.ckpt + (((int64_t)b * a.Dm + d) * a.nTB + (l0 + t) / a.TLB) * a.N;
+#pragma unroll
+        for (int n = 0; n < NREG; n++)
+          if (n < a.N) cp[n] = x[n];
+      }
       float uu = to_f32(su[t * DT + c]);
       float dl = to_f32(sd[t * DT + c]) + db;
       if (a.softplus) dl = softplus_f(dl);
@@ -117,7 +124,7 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
       so[t * DT + c] = from_f32<T>(y);
     }
     block_sync();
-    ss_store_tile<T>(og, a.osd, a.osl, d0, nd, l0, nl, so, DT);
+    if (a.out) ss_store_tile<T>(og, a.osd, a.osl, d0, nd, l0, nl, so, DT);
     // the next iteration's loads overwrite su/sd/sz only (not so); its first block_sync orders them after this store
   }
   if (a.last && live) {
@@ -127,50 +134,275 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// backward.  With a_t = exp(delta_t A), the adjoint g_t of the state x_t runs backwards in time:
+//   g_t = C_t dy_t + a_{t+1} g_{t+1}                       dy_t = dout_t * silu(z_t) (or dout_t)
+//   dA   += g_t x_{t-1} delta_t a_t          ddelta_t = sum_n g_t (x_{t-1} A a_t + B_t u_t)   (* softplus' when enabled)
+//   du_t  = delta_t sum_n g_t B_t + D dy_t   dB_t = g_t delta_t u_t (summed over the channels of the group)
+//   dC_t  = dy_t x_t (same sum)              dz_t = dout_t (y_t + D u_t) silu'(z_t)
+// x_t is rebuilt per tile of SSB_TL tokens from the checkpoints the forward kernel leaves in the workspace (a.ckpt) and
+// parked in LDS ([t][n][channel]); one wave = 64 channels of one group and batch element, tiles walked last to first.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SSB_TL = 16, SSB_DT = 64, SSB_N = 16;
+
+struct SsBwdArgs {
+  SsArgs f;
+  const void* dout; int64_t gsb, gsd, gsl;
+  void* du; void* ddelta; void* dz; int64_t dusb, dusd, dusl, ddsb, ddsd, ddsl, dzsb, dzsd, dzsl;
+  float* dA; float* dB; float* dC; float* dD; float* ddb;
+  int64_t dBsb, dBsg, dBsn, dBsl, dCsb, dCsg, dCsn, dCsl;   // variable: (B, G, N, L); constant: dBsg = stride over d, dBsn over n
+};
+
+template <class T>
+__global__ __launch_bounds__(SSB_DT) void selscan_bwd_kernel(SsBwdArgs q) {
+  const SsArgs& a = q.f;
+  OMK_DYN_SMEM(smem);
+  constexpr int DT = SSB_DT, TL = SSB_TL, NR = SSB_N;
+  float* sx = (float*)smem;                  // [TL][NR][DT]
+  float* sB = sx + TL * NR * DT;             // [TL][N]
+  float* sC = sB + TL * NR;
+  float* sdB = sC + TL * NR;
+  float* sdC = sdB + TL * NR;
+  T* su = (T*)(sdC + TL * NR);
+  T* sd = su + TL * DT;
+  T* sz = sd + TL * DT;
+  T* sg = sz + TL * DT;
+  T* sdu = sg + TL * DT;
+  T* sdd = sdu + TL * DT;
+  T* sdz = sdd + TL * DT;
+  const int dpg = a.Dm / a.G;
+  const int tiles_per_group = (dpg + DT - 1) / DT;
+  const int tg = blockIdx.x % tiles_per_group, g = (blockIdx.x / tiles_per_group) % a.G, b = blockIdx.x / (tiles_per_group * a.G);
+  const int d0 = g * dpg + tg * DT;
+  const int nd = (dpg - tg * DT) < DT ? (dpg - tg * DT) : DT;
+  const int c = threadIdx.x;
+  const bool live = c < nd;
+  const int d = d0 + (live ? c : 0);
+  float A[NR], gx[NR], Bc[NR], Cc[NR], dAacc[NR], dBc[NR], dCc[NR];
+#pragma unroll
+  for (int n = 0; n < NR; n++) {
+    A[n] = n < a.N ? load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) : 0.f;
+    gx[n] = 0.f; dAacc[n] = 0.f; dBc[n] = 0.f; dCc[n] = 0.f;
+    Bc[n] = (!a.Bvar && n < a.N) ? load_rt(a.Bm, (int64_t)d * a.Bsg + (int64_t)n * a.Bsn, a.bdt) : 0.f;
+    Cc[n] = (!a.Cvar && n < a.N) ? load_rt(a.Cm, (int64_t)d * a.Csg + (int64_t)n * a.Csn, a.cdt) : 0.f;
+  }
+  const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+  const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+  float dDacc = 0.f, ddbacc = 0.f;
+  const T* ug = (const T*)a.u + (int64_t)b * a.usb;
+  const T* dg = (const T*)a.delta + (int64_t)b * a.dsb;
+  const T* zg = a.z ? (const T*)a.z + (int64_t)b * a.zsb : nullptr;
+  const T* gg = (const T*)q.dout + (int64_t)b * q.gsb;
+  const int nT = (a.L + TL - 1) / TL;
+  for (int ti = nT - 1; ti >= 0; ti--) {
+    const int l0 = ti * TL;
+    const int nl = (a.L - l0) < TL ? (a.L - l0) : TL;
+    ss_load_tile<T, TL>(ug, a.usd, a.usl, d0, nd, l0, nl, su, DT);
+    ss_load_tile<T, TL>(dg, a.dsd, a.dsl, d0, nd, l0, nl, sd, DT);
+    ss_load_tile<T, TL>(gg, q.gsd, q.gsl, d0, nd, l0, nl, sg, DT);
+    if (zg) ss_load_tile<T, TL>(zg, a.zsd, a.zsl, d0, nd, l0, nl, sz, DT);
+    for (int i = c; i < TL * NR; i += DT) {   // every slot is written: the state loops run over all NR entries
+      const int n = i / TL, t = i % TL;
+      const bool ok = n < a.N && t < nl;
+      sB[t * NR + n] = (a.Bvar && ok) ? load_rt(a.Bm, (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn + (int64_t)(l0 + t) * a.Bsl, a.bdt) : 0.f;
+      sC[t * NR + n] = (a.Cvar && ok) ? load_rt(a.Cm, (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn + (int64_t)(l0 + t) * a.Csl, a.cdt) : 0.f;
+      sdB[t * NR + n] = 0.f;
+      sdC[t * NR + n] = 0.f;
+    }
+    block_sync();
+    // ---- rebuild x_t of this tile from the checkpoint
+    float x0[NR], x[NR];
+    {
+      const float* cp = a.ckpt + (((int64_t)b * a.Dm + d) * a.nTB + ti) * a.N;
+#pragma unroll
+      for (int n = 0; n < NR; n++) { x0[n] = (n < a.N && live) ? cp[n] : 0.f; x[n] = x0[n]; }
+    }
+    for (int t = 0; t < nl; t++) {
+      const float uu = to_f32(su[t * DT + c]);
+      float dl = to_f32(sd[t * DT + c]) + db;
+      if (a.softplus) dl = softplus_f(dl);
+#pragma unroll
+      for (int n = 0; n < NR; n++) {
+        const float Bv = a.Bvar ? sB[t * NR + n] : Bc[n];
+        x[n] = expf(dl * A[n]) * x[n] + dl * uu * Bv;
+        sx[(t * NR + n) * DT + c] = x[n];
+      }
+    }
+    // ---- adjoint sweep
+    for (int t = nl - 1; t >= 0; t--) {
+      const float uu = to_f32(su[t * DT + c]);
+      const float draw = to_f32(sd[t * DT + c]) + db;
+      const float dl = a.softplus ? softplus_f(draw) : draw;
+      const float go = live ? to_f32(sg[t * DT + c]) : 0.f;
+      float dy = go;
+      if (zg) {
+        const float zz = to_f32(sz[t * DT + c]);
+        float ypre = Dv * uu;
+#pragma unroll
+        for (int n = 0; n < NR; n++) ypre += sx[(t * NR + n) * DT + c] * (a.Cvar ? sC[t * NR + n] : Cc[n]);
+        const float sig = 1.f / (1.f + expf(-zz));
+        sdz[t * DT + c] = from_f32<T>(go * ypre * sig * (1.f + zz * (1.f - sig)));
+        dy = go * zz * sig;
+      }
+      dDacc += dy * uu;
+      float duv = dy * Dv, ddl = 0.f;
+#pragma unroll
+      for (int n = 0; n < NR; n++) {
+        const float Bv = a.Bvar ? sB[t * NR + n] : Bc[n];
+        const float Cv = a.Cvar ? sC[t * NR + n] : Cc[n];
+        const float xt = sx[(t * NR + n) * DT + c];
+        const float xp = t > 0 ? sx[((t - 1) * NR + n) * DT + c] : x0[n];
+        const float at = expf(dl * A[n]);
+        const float gn = gx[n] + dy * Cv;            // adjoint of x_t
+        const float dCn = dy * xt, dBn = gn * dl * uu;
+        dAacc[n] += gn * xp * dl * at;
+        ddl += gn * (xp * A[n] * at + Bv * uu);
+        duv += gn * dl * Bv;
+        gx[n] = at * gn;                             // carried to t - 1
+        if (a.Bvar) { const float s = wave_sum(dBn); if (c == 0) sdB[t * NR + n] += s; } else dBc[n] += dBn;
+        if (a.Cvar) { const float s = wave_sum(dCn); if (c == 0) sdC[t * NR + n] += s; } else dCc[n] += dCn;
+      }
+      const float ddraw = a.softplus ? ddl * (1.f / (1.f + expf(-draw))) : ddl;
+      ddbacc += live ? ddraw : 0.f;
+      sdu[t * DT + c] = from_f32<T>(duv);
+      sdd[t * DT + c] = from_f32<T>(ddraw);
+    }
+    block_sync();
+    ss_store_tile<T, TL>((T*)q.du + (int64_t)b * q.dusb, q.dusd, q.dusl, d0, nd, l0, nl, sdu, DT);
+    ss_store_tile<T, TL>((T*)q.ddelta + (int64_t)b * q.ddsb, q.ddsd, q.ddsl, d0, nd, l0, nl, sdd, DT);
+    if (zg && q.dz) ss_store_tile<T, TL>((T*)q.dz + (int64_t)b * q.dzsb, q.dzsd, q.dzsl, d0, nd, l0, nl, sdz, DT);
+    for (int i = c; i < TL * a.N; i += DT) {
+      const int n = i / TL, t = i % TL;
+      if (t < nl) {
+        if (a.Bvar) atomic_add_f32(q.dB + (int64_t)b * q.dBsb + (int64_t)g * q.dBsg + (int64_t)n * q.dBsn + (int64_t)(l0 + t) * q.dBsl, sdB[t * NR + n]);
+        if (a.Cvar) atomic_add_f32(q.dC + (int64_t)b * q.dCsb + (int64_t)g * q.dCsg + (int64_t)n * q.dCsn + (int64_t)(l0 + t) * q.dCsl, sdC[t * NR + n]);
+      }
+    }
+    block_sync();
+  }
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+      if (n < a.N) {
+        atomic_add_f32(q.dA + (int64_t)d * a.N + n, dAacc[n]);
+        if (!a.Bvar) atomic_add_f32(q.dB + (int64_t)d * q.dBsg + (int64_t)n * q.dBsn, dBc[n]);
+        if (!a.Cvar) atomic_add_f32(q.dC + (int64_t)d * q.dCsg + (int64_t)n * q.dCsn, dCc[n]);
+      }
+    }
+    if (q.dD) atomic_add_f32(q.dD + d, dDacc);
+    if (q.ddb) atomic_add_f32(q.ddb + d, ddbacc);
+  }
+}
+
 }  // namespace omk
 
 using namespace omk;
 
-extern "C" int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream) {
-  OMK_REQUIRE(p && present(p->u) && present(p->delta) && present(p->A) && present(p->Bm) && present(p->Cm) && present(p->out), "selective_scan_fwd: u, delta, A, B, C, out required");
-  OMK_REQUIRE(p->u.ndim == 3 && p->delta.ndim == 3 && p->out.ndim == 3 && p->A.ndim == 2, "selective_scan_fwd: u/delta/out (B, D, L), A (D, N)");
-  SsArgs a = {};
-  a.B = (int)p->u.shape[0]; a.Dm = (int)p->u.shape[1]; a.L = (int)p->u.shape[2]; a.N = (int)p->A.shape[1];
-  OMK_REQUIRE(p->A.shape[0] == a.Dm, "selective_scan_fwd: A must be (D, N)");
-  OMK_REQUIRE(p->delta.dtype == p->u.dtype && p->out.dtype == p->u.dtype && (!present(p->z) || p->z.dtype == p->u.dtype), "selective_scan_fwd: delta, z, out must have u's dtype");
-  a.Bvar = p->Bm.ndim == 4; a.Cvar = p->Cm.ndim == 4;
-  OMK_REQUIRE((a.Bvar || p->Bm.ndim == 2) && (a.Cvar || p->Cm.ndim == 2), "selective_scan_fwd: B/C must be (B, G, N, L) or (D, N)");
+// shared argument marshalling of forward and backward; `who` names the entry point in error messages
+static int ss_fill(SsArgs& a, const OmkTensor& u, const OmkTensor& delta, const OmkTensor& A, const OmkTensor& Bm, const OmkTensor& Cm,
+                   const OmkTensor& D, const OmkTensor& z, const OmkTensor& dbias, int softplus, const char* who) {
+  OMK_REQUIRE(present(u) && present(delta) && present(A) && present(Bm) && present(Cm), "%s: u, delta, A, B, C required", who);
+  OMK_REQUIRE(u.ndim == 3 && delta.ndim == 3 && A.ndim == 2, "%s: u/delta (B, D, L), A (D, N)", who);
+  a.B = (int)u.shape[0]; a.Dm = (int)u.shape[1]; a.L = (int)u.shape[2]; a.N = (int)A.shape[1];
+  OMK_REQUIRE(A.shape[0] == a.Dm, "%s: A must be (D, N)", who);
+  OMK_REQUIRE(delta.dtype == u.dtype && (!present(z) || z.dtype == u.dtype), "%s: delta, z must have u's dtype", who);
+  a.Bvar = Bm.ndim == 4; a.Cvar = Cm.ndim == 4;
+  OMK_REQUIRE((a.Bvar || Bm.ndim == 2) && (a.Cvar || Cm.ndim == 2), "%s: B/C must be (B, G, N, L) or (D, N)", who);
   a.G = 1;
-  if (a.Bvar) a.G = (int)p->Bm.shape[1];
-  if (a.Cvar) { OMK_REQUIRE(!a.Bvar || p->Cm.shape[1] == a.G, "selective_scan_fwd: B and C group counts differ"); a.G = (int)p->Cm.shape[1]; }
-  OMK_REQUIRE(a.G > 0 && a.Dm % a.G == 0, "selective_scan_fwd: D must be a multiple of ngroups");
-  OMK_REQUIRE(a.N <= 64, "selective_scan_fwd: d_state > 64 is not supported by the Mamba-1 kernel");
-  a.u = p->u.data; a.delta = p->delta.data; a.A = p->A.data; a.Bm = p->Bm.data; a.Cm = p->Cm.data; a.D = p->D.data; a.z = p->z.data;
-  a.dbias = p->delta_bias.data; a.out = p->out.data; a.last = (float*)p->last_state.data;
-  OMK_REQUIRE(!present(p->last_state) || p->last_state.dtype == OMK_F32, "selective_scan_fwd: last_state must be f32");
-  a.usb = p->u.stride[0]; a.usd = p->u.stride[1]; a.usl = p->u.stride[2];
-  a.dsb = p->delta.stride[0]; a.dsd = p->delta.stride[1]; a.dsl = p->delta.stride[2];
-  if (present(p->z)) { a.zsb = p->z.stride[0]; a.zsd = p->z.stride[1]; a.zsl = p->z.stride[2]; }
-  a.osb = p->out.stride[0]; a.osd = p->out.stride[1]; a.osl = p->out.stride[2];
-  a.Asd = p->A.stride[0]; a.Asn = p->A.stride[1];
-  if (a.Bvar) { a.Bsb = p->Bm.stride[0]; a.Bsg = p->Bm.stride[1]; a.Bsn = p->Bm.stride[2]; a.Bsl = p->Bm.stride[3]; }
-  else { a.Bsg = p->Bm.stride[0]; a.Bsn = p->Bm.stride[1]; }
-  if (a.Cvar) { a.Csb = p->Cm.stride[0]; a.Csg = p->Cm.stride[1]; a.Csn = p->Cm.stride[2]; a.Csl = p->Cm.stride[3]; }
-  else { a.Csg = p->Cm.stride[0]; a.Csn = p->Cm.stride[1]; }
-  a.softplus = p->delta_softplus; a.adt = p->A.dtype; a.bdt = p->Bm.dtype; a.cdt = p->Cm.dtype; a.ddt = p->D.dtype; a.dbdt = p->delta_bias.dtype;
-  if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
+  if (a.Bvar) a.G = (int)Bm.shape[1];
+  if (a.Cvar) { OMK_REQUIRE(!a.Bvar || Cm.shape[1] == a.G, "%s: B and C group counts differ", who); a.G = (int)Cm.shape[1]; }
+  OMK_REQUIRE(a.G > 0 && a.Dm % a.G == 0, "%s: D must be a multiple of ngroups", who);
+  OMK_REQUIRE(a.N <= 64, "%s: d_state > 64 is not supported by the Mamba-1 kernel", who);
+  a.u = u.data; a.delta = delta.data; a.A = A.data; a.Bm = Bm.data; a.Cm = Cm.data; a.D = D.data; a.z = z.data; a.dbias = dbias.data;
+  a.usb = u.stride[0]; a.usd = u.stride[1]; a.usl = u.stride[2];
+  a.dsb = delta.stride[0]; a.dsd = delta.stride[1]; a.dsl = delta.stride[2];
+  if (present(z)) { a.zsb = z.stride[0]; a.zsd = z.stride[1]; a.zsl = z.stride[2]; }
+  a.Asd = A.stride[0]; a.Asn = A.stride[1];
+  if (a.Bvar) { a.Bsb = Bm.stride[0]; a.Bsg = Bm.stride[1]; a.Bsn = Bm.stride[2]; a.Bsl = Bm.stride[3]; }
+  else { a.Bsg = Bm.stride[0]; a.Bsn = Bm.stride[1]; }
+  if (a.Cvar) { a.Csb = Cm.stride[0]; a.Csg = Cm.stride[1]; a.Csn = Cm.stride[2]; a.Csl = Cm.stride[3]; }
+  else { a.Csg = Cm.stride[0]; a.Csn = Cm.stride[1]; }
+  a.softplus = softplus; a.adt = A.dtype; a.bdt = Bm.dtype; a.cdt = Cm.dtype; a.ddt = D.dtype; a.dbdt = dbias.dtype;
+  return OMK_OK;
+}
+
+static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
   const int dpg = a.Dm / a.G;
   a.DT = dpg >= 128 ? 128 : ((dpg + 63) / 64) * 64;
   const int tiles_per_group = (dpg + a.DT - 1) / a.DT;
   dim3 grid((unsigned)((int64_t)a.B * a.G * tiles_per_group)), block(a.DT);
-  const size_t smem = (size_t)4 * SS_TL * a.DT * dtype_size(p->u.dtype) + (size_t)2 * SS_TL * a.N * 4;
+  const size_t smem = (size_t)4 * SS_TL * a.DT * dtype_size(udt) + (size_t)2 * SS_TL * a.N * 4;
 #define SS_GO(T, NREG) OMK_LAUNCH((selscan_fwd_kernel<T, NREG>), grid, block, smem, stream, a)
-  OMK_DISPATCH_DTYPE(p->u.dtype, T, { if (a.N <= 16) SS_GO(T, 16); else SS_GO(T, 64); });
+  OMK_DISPATCH_DTYPE(udt, T, { if (a.N <= 16) SS_GO(T, 16); else SS_GO(T, 64); });
 #undef SS_GO
+  return OMK_OK;
+}
+
+extern "C" int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->out), "selective_scan_fwd: out required");
+  SsArgs a = {};
+  int rc = ss_fill(a, p->u, p->delta, p->A, p->Bm, p->Cm, p->D, p->z, p->delta_bias, p->delta_softplus, "selective_scan_fwd");
+  if (rc) return rc;
+  OMK_REQUIRE(p->out.ndim == 3 && p->out.dtype == p->u.dtype, "selective_scan_fwd: out must be (B, D, L) of u's dtype");
+  OMK_REQUIRE(!present(p->last_state) || p->last_state.dtype == OMK_F32, "selective_scan_fwd: last_state must be f32");
+  a.out = p->out.data; a.last = (float*)p->last_state.data;
+  a.osb = p->out.stride[0]; a.osd = p->out.stride[1]; a.osl = p->out.stride[2];
+  if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
+  if ((rc = ss_launch_fwd(a, p->u.dtype, stream))) return rc;
   return finish_launch("selective_scan_fwd");
 }
 
-extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd*, omk_stream) {
-  return fail(OMK_EUNSUPPORTED, "selective_scan_bwd: the Mamba-1 backward is not implemented (OmniMamba configs use Mamba2 only, "
-                                "models/stage2/config_mamba.py:16)");
+extern "C" size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p) {
+  if (!p || p->u.ndim != 3 || p->A.ndim != 2) return 0;
+  const int64_t nTB = (p->u.shape[2] + SSB_TL - 1) / SSB_TL;
+  return (size_t)(p->u.shape[0] * p->u.shape[1] * nTB * p->A.shape[1]) * 4;   // state checkpoints (B, D, nTB, N) f32
+}
+
+extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->dout) && present(p->du) && present(p->ddelta) && present(p->dA) && present(p->dB) && present(p->dC),
+              "selective_scan_bwd: dout, du, ddelta, dA, dB, dC required");
+  SsBwdArgs q = {};
+  SsArgs& a = q.f;
+  int rc = ss_fill(a, p->u, p->delta, p->A, p->Bm, p->Cm, p->D, p->z, p->delta_bias, p->delta_softplus, "selective_scan_bwd");
+  if (rc) return rc;
+  if (a.N > SSB_N) return fail(OMK_EUNSUPPORTED, "selective_scan_bwd: d_state %d > %d is not supported by the Mamba-1 backward", a.N, SSB_N);
+  const int udt = p->u.dtype;
+  OMK_REQUIRE(p->dout.ndim == 3 && p->du.ndim == 3 && p->ddelta.ndim == 3, "selective_scan_bwd: dout, du, ddelta must be (B, D, L)");
+  OMK_REQUIRE(p->dout.dtype == udt && p->du.dtype == udt && p->ddelta.dtype == udt && (!present(p->dz) || p->dz.dtype == udt),
+              "selective_scan_bwd: dout, du, ddelta, dz must have u's dtype");
+  OMK_REQUIRE(p->dA.dtype == OMK_F32 && is_contig_last(p->dA) && p->dA.ndim == 2 && p->dA.stride[0] == a.N, "selective_scan_bwd: dA must be contiguous f32 (D, N)");
+  OMK_REQUIRE(p->dB.dtype == OMK_F32 && p->dC.dtype == OMK_F32, "selective_scan_bwd: dB, dC must be f32 (accumulated into: caller zeroes)");
+  OMK_REQUIRE(p->dB.ndim == (a.Bvar ? 4 : 2) && p->dC.ndim == (a.Cvar ? 4 : 2), "selective_scan_bwd: dB / dC must have the rank of B / C");
+  OMK_REQUIRE(!present(p->dD) || (p->dD.dtype == OMK_F32 && is_contig_last(p->dD)), "selective_scan_bwd: dD must be contiguous f32 (D)");
+  OMK_REQUIRE(!present(p->ddelta_bias) || (p->ddelta_bias.dtype == OMK_F32 && is_contig_last(p->ddelta_bias)), "selective_scan_bwd: ddelta_bias must be contiguous f32 (D)");
+  OMK_REQUIRE(!present(p->z) || present(p->dz), "selective_scan_bwd: dz required when z is given");
+  OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_selective_scan_bwd_workspace_bytes(p), "selective_scan_bwd: workspace too small");
+  if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
+  // pass 1: the forward recurrence once more, leaving the state at every SSB_TL-token boundary in the workspace
+  a.ckpt = (float*)p->workspace; a.TLB = SSB_TL; a.nTB = (a.L + SSB_TL - 1) / SSB_TL;
+  {
+    SsArgs f = a;
+    f.out = nullptr; f.last = nullptr; f.z = nullptr;
+    if ((rc = ss_launch_fwd(f, udt, stream))) return rc;
+  }
+  // pass 2: adjoint sweep, tiles last to first
+  q.dout = p->dout.data; q.gsb = p->dout.stride[0]; q.gsd = p->dout.stride[1]; q.gsl = p->dout.stride[2];
+  q.du = p->du.data; q.dusb = p->du.stride[0]; q.dusd = p->du.stride[1]; q.dusl = p->du.stride[2];
+  q.ddelta = p->ddelta.data; q.ddsb = p->ddelta.stride[0]; q.ddsd = p->ddelta.stride[1]; q.ddsl = p->ddelta.stride[2];
+  if (present(p->dz)) { q.dz = p->dz.data; q.dzsb = p->dz.stride[0]; q.dzsd = p->dz.stride[1]; q.dzsl = p->dz.stride[2]; }
+  q.dA = (float*)p->dA.data; q.dB = (float*)p->dB.data; q.dC = (float*)p->dC.data; q.dD = (float*)p->dD.data; q.ddb = (float*)p->ddelta_bias.data;
+  if (a.Bvar) { q.dBsb = p->dB.stride[0]; q.dBsg = p->dB.stride[1]; q.dBsn = p->dB.stride[2]; q.dBsl = p->dB.stride[3]; }
+  else { q.dBsg = p->dB.stride[0]; q.dBsn = p->dB.stride[1]; }
+  if (a.Cvar) { q.dCsb = p->dC.stride[0]; q.dCsg = p->dC.stride[1]; q.dCsn = p->dC.stride[2]; q.dCsl = p->dC.stride[3]; }
+  else { q.dCsg = p->dC.stride[0]; q.dCsn = p->dC.stride[1]; }
+  const int dpg = a.Dm / a.G;
+  a.DT = SSB_DT;
+  const int tiles_per_group = (dpg + SSB_DT - 1) / SSB_DT;
+  dim3 grid((unsigned)((int64_t)a.B * a.G * tiles_per_group)), block(SSB_DT);
+  const size_t smem = (size_t)SSB_TL * SSB_N * SSB_DT * 4 + (size_t)4 * SSB_TL * SSB_N * 4 + (size_t)7 * SSB_TL * SSB_DT * dtype_size(udt);
+#define SSB_GO(T) do { if (OMK_SET_MAX_DYN_SMEM((selscan_bwd_kernel<T>), smem)) return fail(OMK_ELAUNCH, "selective_scan_bwd: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((selscan_bwd_kernel<T>), grid, block, smem, stream, q); } while (0)
+  OMK_DISPATCH_DTYPE(udt, T, SSB_GO(T));
+#undef SSB_GO
+  return finish_launch("selective_scan_bwd");
 }

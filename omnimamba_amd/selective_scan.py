@@ -1,7 +1,7 @@
 """Mamba-1 selective scan on the MI355X (``selective_scan_fn`` signature; BASELINE.json configs[0]).
 
 Mirrors ``mamba_ssm.ops.selective_scan_interface.selective_scan_fn`` (importable mixer alternative at
-/root/reference/models/stage2/mixer_seq_simple.py:16,197-201).  Kernel: omk_selective_scan_fwd
+/root/reference/models/stage2/mixer_seq_simple.py:16,197-201).  Kernels: omk_selective_scan_fwd / _bwd
 (omnimamba_amd/csrc/selscan.hip), coalesced for both (B, D, L) and channel-last (B, L, D) storage.
 """
 from __future__ import annotations
@@ -35,12 +35,38 @@ class SelectiveScanFn(torch.autograd.Function):
                              last_state=K.T(last), delta_softplus=int(delta_softplus))
             K.run(lib, "omk_selective_scan_fwd", p, u)
         ctx.return_last_state = return_last_state
+        ctx.delta_softplus = bool(delta_softplus)
+        ctx.b3, ctx.c3 = B.dim() == 3, C.dim() == 3
+        ctx.save_for_backward(u, delta, A, B4, C4, D, z, delta_bias)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
         return (out, last) if return_last_state else out
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError("selective_scan_fn backward (Mamba-1) is not implemented: OmniMamba's shipped "
-                                  "configs only build Mamba2 mixers (models/stage2/config_mamba.py:16)")
+    def backward(ctx, dout, *unused):
+        """Recomputes the states per 16-token tile from checkpoints of a second forward pass (omk_selective_scan_bwd);
+        d_state <= 16 (the Mamba-1 default)."""
+        lib = get_lib()
+        u, delta, A, B4, C4, D, z, delta_bias = ctx.saved_tensors
+        dout = dout.to(u.dtype)
+        Af = A.float() if A.dtype != torch.float32 else A
+        f32 = dict(dtype=torch.float32, device=u.device)
+        du, ddelta = torch.empty_like(u), torch.empty_like(delta)
+        dz = None if z is None else torch.empty_like(z)
+        dA = torch.zeros(A.shape, **f32)
+        dB, dC = torch.zeros(B4.shape, **f32), torch.zeros(C4.shape, **f32)
+        dD = None if D is None else torch.zeros(D.shape, **f32)
+        ddb = None if delta_bias is None else torch.zeros(delta_bias.shape, **f32)
+        if u.numel() > 0:
+            p = K.SelScanBwd(u=K.T(u), delta=K.T(delta), A=K.T(Af), Bm=K.T(B4), Cm=K.T(C4), D=K.T(D), z=K.T(z),
+                             delta_bias=K.T(delta_bias), dout=K.T(dout), du=K.T(du), ddelta=K.T(ddelta), dA=K.T(dA), dB=K.T(dB),
+                             dC=K.T(dC), dD=K.T(dD), dz=K.T(dz), ddelta_bias=K.T(ddb), delta_softplus=int(ctx.delta_softplus))
+            ws = K.workspace(lib, "omk_selective_scan_bwd_workspace_bytes", p, u)  # noqa: F841
+            K.run(lib, "omk_selective_scan_bwd", p, u)
+        dB = (dB.squeeze(1) if ctx.b3 else dB).to(B4.dtype)
+        dC = (dC.squeeze(1) if ctx.c3 else dC).to(C4.dtype)
+        return (du, ddelta, dA.to(A.dtype), dB, dC, None if D is None else dD.to(D.dtype), dz,
+                None if delta_bias is None else ddb.to(delta_bias.dtype), None, None)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,

@@ -153,6 +153,9 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, std::function<void(
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) {
         b.bIdx = dim3(bx, by, bz);
+        // LDS holds garbage on the GPU: poison the dynamic segment (NaN as f32 / bf16) so that a kernel reading LDS it
+        // never wrote fails here too instead of silently seeing zeros
+        memset(smem.data(), 0xFF, smem.size());
         b.alive = nthreads;
         b.arrived = 0;
         b.gen = 0;
