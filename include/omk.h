@@ -197,6 +197,27 @@ typedef struct {
 size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p);
 int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* d_state <= 16 */
 
+/* ---- decode-step projection fused with the normalisation in front of it ----------------------------------
+ * one launch for: reference block.py:86-95 (fused add + RMSNorm) -> lora.py:185-279 (base + task LoRA) at one token
+ * per sequence, and for Mamba2.step's gated RMSNorm -> out_proj (upstream mamba2.py step()).  Batch 1 (larger batches: separate ops).           */
+typedef struct {
+  OmkTensor x;             /* (B, in) */
+  OmkTensor residual;      /* optional (B, in): added before the norm */
+  OmkTensor z;             /* optional (B, in): gate of the gated norm (dtype of x) */
+  OmkTensor norm_weight;   /* optional (in): RMSNorm weight; absent = no normalisation */
+  OmkTensor weight;        /* (out, in) f32 / bf16 / f16, 16-byte aligned rows */
+  OmkTensor bias;          /* optional (out) */
+  OmkTensor lora_a;        /* optional (r, in), r <= 16 */
+  OmkTensor lora_b;        /* optional (out, r) */
+  OmkTensor residual_out;  /* optional out (B, in): x + residual */
+  OmkTensor out;           /* out (B, out) */
+  int64_t group_size;      /* norm group size (0 = in) */
+  float eps;
+  float lora_scale;
+  int32_t norm_before_gate;
+} OmkNormLinear;
+int omk_norm_linear(const OmkNormLinear* p, omk_stream stream);
+
 /* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------
  * upstream mamba_ssm.ops.triton.ssd_combined.mamba_chunk_scan_combined (+ the scan stage of
  * mamba_split_conv1d_scan_combined); reference reach: models/stage2/block.py:117 -> Mamba2.forward              */

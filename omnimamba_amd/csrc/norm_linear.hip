@@ -1,0 +1,313 @@
+// norm_linear.hip -- the decode-step projections fused with the normalisation in front of them (SURVEY.md section 8 rows
+// a2, a3, a9, a10 at one token per sequence):
+//
+//   n   = rmsnorm(x [+ residual]) * w                         (pre-norm of the block; residual_out = x + residual)
+//      or rmsnorm(x * silu(z)) * w  /  rmsnorm(x) * w * silu(z) (the gated norm in front of out_proj, grouped)
+//      or x                                                    (no norm weight)
+//   out = n W^T [+ bias] [+ scale * (n A^T) B^T]               (LoRA of the task, dropout is off at decode time)
+//
+// At batch 1 the eager step spends one launch each on add+norm, the A GEMV, the base GEMV and the B addmm (7 + 13 + 19 +
+// 9 us per layer measured, against 12 us of pure weight streaming for the 70 MB of in_proj).  Here every workgroup
+// rebuilds the normalised activation (a few KB, served by L2) and the rank-r LoRA vector in LDS, then streams its rows
+// of W once with 16-byte loads: wave = NR rows at a time, lane = 4 (fp32) or 8 (16-bit) consecutive columns per step,
+// one DPP wave sum per (row, batch element).  HBM-bound on W: out * in * sizeof(W) bytes per call.
+#include "omk_common.h"
+
+namespace omk {
+
+constexpr int NL_MAXB = 8;        // batch elements kept in LDS at once
+constexpr int NL_MAXR = 16;       // LoRA rank
+constexpr int NL_THREADS = 256;
+
+struct NlArgs {
+  const void* x; const void* res; const void* z; const void* nw; const void* W; const void* bias; const void* la; const void* lb;
+  void* ro; void* out;
+  int64_t xs, rs, zs, ros, os, Ws, las, lbs;     // row strides (elements)
+  int B, In, Out, R, G, xdt, rdt, rodt, nwdt, bdt, odt, ldt, nbg;   // G = norm groups, nbg = norm_before_gate
+  float eps, scale;
+};
+
+// four consecutive elements of a runtime-typed array as floats (8- or 16-byte load)
+__device__ __forceinline__ void ld4_rt(const void* p, int64_t idx, int dt, float (&o)[4]) {
+  if (dt == OMK_F32) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)p + idx);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  } else if (dt == OMK_BF16) {
+    load_vec<bf16_t, 4>((const bf16_t*)p + idx, o);
+  } else {
+    load_vec<f16_t, 4>((const f16_t*)p + idx, o);
+  }
+}
+
+template <class TW, int NB>   // NB = batch elements (compile time: prunes the per-batch accumulators)
+__global__ __launch_bounds__(NL_THREADS) void norm_linear_kernel(NlArgs a) {
+  OMK_DYN_SMEM(smem);
+  float* sn = (float*)smem;                       // [NB][In] normalised activation
+  float* sh = sn + (size_t)NB * a.In;             // [NB][R]  LoRA hidden
+  float* part = sh + NL_MAXB * NL_MAXR;           // [waves][NB * R]
+  __shared__ float red[NL_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gs = a.In / a.G;
+  // ---- the first pair of weight rows is requested before anything else: the preamble below (norm, LoRA hidden) runs
+  // while those 2 * UN 16-byte loads per lane are in flight
+  constexpr int VEC = 16 / sizeof(TW);
+  constexpr int UN = 8;                            // column steps issued together: In <= 64 * VEC * UN per sweep
+  const TW* W = (const TW*)a.W;
+  const int nwaves = gridDim.x * (NL_THREADS / 64);
+  int row0 = blockIdx.x * (NL_THREADS / 64) + wave;
+  float w0[UN][VEC], w1[UN][VEC];
+#define NL_ISSUE(r0_, cb_) do {                                                                                   \
+    const int r0c_ = (r0_) < a.Out ? (r0_) : a.Out - 1, r1c_ = (r0_) + nwaves < a.Out ? (r0_) + nwaves : r0c_;     \
+    _Pragma("unroll") for (int u = 0; u < UN; u++) {                                                               \
+      const int c0_ = (cb_) + u * 64 * VEC < a.In ? (cb_) + u * 64 * VEC : lane * VEC;   /* clamped: unconditional */ \
+      load_vec<TW, VEC>(W + (int64_t)r0c_ * a.Ws + c0_, w0[u]);                                                    \
+      load_vec<TW, VEC>(W + (int64_t)r1c_ * a.Ws + c0_, w1[u]);                                                    \
+    } } while (0)
+  if (NB == 1) NL_ISSUE(row0, lane * VEC);   // (larger batches keep the registers for the per-batch preamble state)
+  // ---- normalised activation of every batch element (each workgroup rebuilds it: NB * In * 4 bytes out of L2).
+  // A thread owns the 4-column groups tid, tid + 256, ...; all its loads are issued before the first use -- a strided
+  // scalar loop here costs one memory latency per iteration and was 40 of the kernel's first 50 us.
+  constexpr int MAXQ = 8;                           // 4-column groups per thread: In <= 8192
+  const int nq = a.In / (4 * NL_THREADS);           // the host guarantees In % 1024 == 0
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    float v[MAXQ][4];
+#pragma unroll
+    for (int k = 0; k < MAXQ; k++) {
+      if (k < nq) {
+        const int c = 4 * (tid + NL_THREADS * k);
+        ld4_rt(a.x, (int64_t)b * a.xs + c, a.xdt, v[k]);
+      }
+    }
+    if (a.res) {
+#pragma unroll
+      for (int k = 0; k < MAXQ; k++) {
+        if (k < nq) {
+          float r4[4];
+          ld4_rt(a.res, (int64_t)b * a.rs + 4 * (tid + NL_THREADS * k), a.rdt, r4);
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[k][i] += r4[i];
+        }
+      }
+    }
+    if (a.ro && blockIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < MAXQ; k++)
+        if (k < nq)
+#pragma unroll
+          for (int i = 0; i < 4; i++) store_rt(a.ro, (int64_t)b * a.ros + 4 * (tid + NL_THREADS * k) + i, a.rodt, v[k][i]);
+    }
+    float zg[MAXQ][4];
+    if (a.z) {
+#pragma unroll
+      for (int k = 0; k < MAXQ; k++) {
+        if (k < nq) {
+          ld4_rt(a.z, (int64_t)b * a.zs + 4 * (tid + NL_THREADS * k), a.xdt, zg[k]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            zg[k][i] = silu_f(zg[k][i]);
+            if (!a.nbg) v[k][i] *= zg[k][i];
+          }
+        }
+      }
+    }
+    if (a.nw) {
+      // group sums: a 4-column group never straddles a norm group (gs % 4 == 0); per-thread partials per group
+      for (int g = 0; g < a.G; g++) {
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXQ; k++) {
+          if (k < nq && (4 * (tid + NL_THREADS * k)) / gs == g)
+#pragma unroll
+            for (int i = 0; i < 4; i++) ss += v[k][i] * v[k][i];
+        }
+        ss = wave_sum(ss);
+        block_sync();
+        if (lane == 0) red[wave] = ss;
+        block_sync();
+        const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)gs + a.eps);
+#pragma unroll
+        for (int k = 0; k < MAXQ; k++) {
+          const int c = 4 * (tid + NL_THREADS * k);
+          if (k < nq && c / gs == g) {
+            float w4[4];
+            ld4_rt(a.nw, c, a.nwdt, w4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              v[k][i] *= rstd * w4[i];
+              if (a.z && a.nbg) v[k][i] *= zg[k][i];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXQ; k++)
+      if (k < nq) *reinterpret_cast<f32x4*>(&sn[(size_t)b * a.In + 4 * (tid + NL_THREADS * k)]) = f32x4{v[k][0], v[k][1], v[k][2], v[k][3]};
+    // ---- LoRA hidden partials of this thread's columns, all ranks
+    if (a.la) {
+      float hr[NL_MAXR];
+#pragma unroll
+      for (int r = 0; r < NL_MAXR; r++) {
+        hr[r] = 0.f;
+        if (r < a.R) {
+#pragma unroll
+          for (int k = 0; k < MAXQ; k++) {
+            if (k < nq) {
+              float a4[4];
+              ld4_rt(a.la, (int64_t)r * a.las + 4 * (tid + NL_THREADS * k), a.ldt, a4);
+#pragma unroll
+              for (int i = 0; i < 4; i++) hr[r] += v[k][i] * a4[i];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NL_MAXR; r++) {
+        if (r < a.R) {
+          const float s = wave_sum(hr[r]);
+          if (lane == 0) part[wave * (NL_MAXB * NL_MAXR) + b * a.R + r] = s;
+        }
+      }
+    }
+  }
+  block_sync();
+  if (a.la) {
+    if (tid < NB * a.R) {
+      float s = 0.f;
+      for (int wv = 0; wv < NL_THREADS / 64; wv++) s += part[wv * (NL_MAXB * NL_MAXR) + tid];
+      sh[tid] = s;
+    }
+    block_sync();
+  }
+  // ---- rows of W: every wave walks the row pairs (w, w + nwaves), (w + 2 nwaves, ...) -- balanced to one row -- sweeping a
+  // pair with lane = VEC consecutive columns per step.  The next pair's loads are issued as soon as the registers are
+  // free, so the wave reductions and stores of one pair overlap the memory latency of the next.
+  const int sweep = 64 * VEC * UN;
+  int cb = lane * VEC;
+  if (NB != 1) NL_ISSUE(row0, cb);
+  float acc[2][NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) { acc[0][b] = 0.f; acc[1][b] = 0.f; }
+  while (row0 < a.Out) {
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int c0 = cb + u * 64 * VEC;
+      if (c0 < a.In) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+          for (int i = 0; i < VEC; i++) {
+            const float nv = sn[(size_t)b * a.In + c0 + i];
+            acc[0][b] += w0[u][i] * nv;
+            acc[1][b] += w1[u][i] * nv;
+          }
+        }
+      }
+    }
+    const bool row_done = cb - lane * VEC + sweep >= a.In;
+    const int prow = row0;
+    if (row_done) { row0 += 2 * nwaves; cb = lane * VEC; } else { cb += sweep; }
+    OMK_SCHED_FENCE();   // keep the next pair's loads below the products: hoisted, they need a second register set
+    if (row0 < a.Out) NL_ISSUE(row0, cb);
+    if (row_done) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int row = prow + j * nwaves;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          float v = wave_sum(acc[j][b]);
+          acc[j][b] = 0.f;
+          if (lane == 0 && row < a.Out) {
+            if (a.bias) v += load_rt(a.bias, row, a.bdt);
+            if (a.la) {
+              float l = 0.f;
+              for (int q = 0; q < a.R; q++) l += sh[b * a.R + q] * load_rt(a.lb, (int64_t)row * a.lbs + q, a.ldt);
+              v += a.scale * l;
+            }
+            store_rt(a.out, (int64_t)b * a.os + row, a.odt, v);
+          }
+        }
+      }
+    }
+  }
+}
+#undef NL_ISSUE
+
+// compute units of the current device (cached; 256 on the MI355X and under the emulator)
+static int cu_count() {
+#ifdef OMK_EMU
+  return 256;
+#else
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+#endif
+}
+
+}  // namespace omk
+
+using namespace omk;
+
+extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
+  OMK_REQUIRE(p && present(p->x) && present(p->weight) && present(p->out), "norm_linear: x, weight, out required");
+  OMK_REQUIRE(p->x.ndim == 2 && p->out.ndim == 2 && p->weight.ndim == 2, "norm_linear: x (B, in), weight (out, in), out (B, out)");
+  NlArgs a = {};
+  a.B = (int)p->x.shape[0]; a.In = (int)p->x.shape[1]; a.Out = (int)p->weight.shape[0];
+  OMK_REQUIRE(p->weight.shape[1] == a.In && p->out.shape[0] == a.B && p->out.shape[1] == a.Out, "norm_linear: shape mismatch");
+  OMK_REQUIRE(p->x.stride[1] == 1 && p->out.stride[1] == 1 && p->weight.stride[1] == 1, "norm_linear: last dims must be contiguous");
+  if (a.B == 0 || a.Out == 0) return OMK_OK;
+  // one sequence per call: with more, the per-batch preamble state and the double register set of the pipelined row loop
+  // no longer fit (the kernel template takes NB, the launcher only instantiates 1); callers use the separate ops instead
+  if (a.B > 1) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d > 1 is served by the unfused ops", a.B);
+  const int wdt = p->weight.dtype;
+  const int vec = wdt == OMK_F32 ? 4 : 8;
+  if (a.In % 1024 != 0 || a.In > 8192 || !aligned16(p->weight) || p->weight.stride[0] % vec != 0)
+    return fail(OMK_EUNSUPPORTED, "norm_linear: in_features %d must be a multiple of 1024 (<= 8192) with 16-byte aligned weight rows", a.In);
+  {
+    auto ok4 = [](const OmkTensor& t) { return !present(t) || (aligned16(t) && (t.ndim < 2 || t.stride[0] % 4 == 0)); };
+    if (!ok4(p->x) || !ok4(p->residual) || !ok4(p->z) || !ok4(p->norm_weight) || !ok4(p->lora_a) || !ok4(p->residual_out))
+      return fail(OMK_EUNSUPPORTED, "norm_linear: activation / LoRA rows must be 16-byte aligned");
+  }
+  a.G = 1;
+  if (present(p->norm_weight)) {
+    OMK_REQUIRE(numel(p->norm_weight) == a.In && is_contig_last(p->norm_weight), "norm_linear: norm_weight must be contiguous (in)");
+    const int64_t gsz = p->group_size > 0 ? p->group_size : a.In;
+    OMK_REQUIRE(a.In % gsz == 0 && gsz % 4 == 0, "norm_linear: group_size must divide in_features and be a multiple of 4");
+    a.G = (int)(a.In / gsz);
+  }
+  if (present(p->residual)) OMK_REQUIRE(p->residual.ndim == 2 && p->residual.shape[0] == a.B && p->residual.shape[1] == a.In && p->residual.stride[1] == 1, "norm_linear: residual mismatch");
+  if (present(p->residual_out)) OMK_REQUIRE(p->residual_out.ndim == 2 && p->residual_out.shape[0] == a.B && p->residual_out.shape[1] == a.In && p->residual_out.stride[1] == 1, "norm_linear: residual_out mismatch");
+  if (present(p->z)) OMK_REQUIRE(p->z.ndim == 2 && p->z.shape[0] == a.B && p->z.shape[1] == a.In && p->z.stride[1] == 1 && p->z.dtype == p->x.dtype, "norm_linear: z mismatch");
+  if (present(p->bias)) OMK_REQUIRE(numel(p->bias) == a.Out && is_contig_last(p->bias), "norm_linear: bias must be contiguous (out)");
+  a.R = 0;
+  if (present(p->lora_a) || present(p->lora_b)) {
+    OMK_REQUIRE(present(p->lora_a) && present(p->lora_b) && p->lora_a.ndim == 2 && p->lora_b.ndim == 2, "norm_linear: lora_a (r, in) and lora_b (out, r) come together");
+    a.R = (int)p->lora_a.shape[0];
+    OMK_REQUIRE(a.R <= NL_MAXR && p->lora_a.shape[1] == a.In && p->lora_b.shape[0] == a.Out && p->lora_b.shape[1] == a.R, "norm_linear: LoRA shapes");
+    OMK_REQUIRE(p->lora_a.stride[1] == 1 && p->lora_b.stride[1] == 1 && p->lora_a.dtype == p->lora_b.dtype, "norm_linear: LoRA factors must be row-major of one dtype");
+    a.la = p->lora_a.data; a.lb = p->lora_b.data; a.las = p->lora_a.stride[0]; a.lbs = p->lora_b.stride[0]; a.ldt = p->lora_a.dtype;
+  }
+  a.x = p->x.data; a.res = p->residual.data; a.z = p->z.data; a.nw = p->norm_weight.data; a.W = p->weight.data; a.bias = p->bias.data;
+  a.ro = p->residual_out.data; a.out = p->out.data;
+  a.xs = p->x.stride[0]; a.rs = present(p->residual) ? p->residual.stride[0] : 0; a.zs = present(p->z) ? p->z.stride[0] : 0;
+  a.ros = present(p->residual_out) ? p->residual_out.stride[0] : 0; a.os = p->out.stride[0]; a.Ws = p->weight.stride[0];
+  a.xdt = p->x.dtype; a.rdt = p->residual.dtype; a.rodt = p->residual_out.dtype; a.nwdt = p->norm_weight.dtype; a.bdt = p->bias.dtype; a.odt = p->out.dtype;
+  a.nbg = p->norm_before_gate; a.eps = p->eps; a.scale = p->lora_scale;
+  const size_t smem = ((size_t)a.B * a.In + (size_t)NL_MAXB * NL_MAXR * (1 + NL_THREADS / 64)) * 4;
+  // two workgroups per CU; small matrices get one wave per row pair
+  const int ncu = 2 * cu_count();
+  const int want = (a.Out + 7) / 8;   // workgroups if every wave took exactly one row pair
+  dim3 grid((unsigned)(want < ncu ? want : ncu)), block(NL_THREADS);
+#define NL_GO(TW_, NB_) do { if (OMK_SET_MAX_DYN_SMEM((norm_linear_kernel<TW_, NB_>), smem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((norm_linear_kernel<TW_, NB_>), grid, block, smem, stream, a); } while (0)
+#define NL_NB(TW_) NL_GO(TW_, 1)
+  if (wdt == OMK_F32) NL_NB(float); else if (wdt == OMK_BF16) NL_NB(bf16_t); else NL_NB(f16_t);
+#undef NL_NB
+#undef NL_GO
+  return finish_launch("norm_linear");
+}

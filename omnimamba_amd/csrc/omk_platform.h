@@ -190,6 +190,12 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
+// Instruction-scheduling fence: nothing moves across it
+#ifdef OMK_EMU
+#define OMK_SCHED_FENCE() do { } while (0)
+#else
+#define OMK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // Register budget hint: at least N waves per SIMD (the compiler caps VGPRs at 512 / N)
 #ifdef OMK_EMU
 #define OMK_WAVES_PER_EU(n)

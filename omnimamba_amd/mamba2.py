@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 from .layernorm_gated import RMSNorm as RMSNormGated
+from . import norm_linear as NL
 from .linear import linear
 from .selective_state_update import selective_state_update
 from .ssd_combined import mamba_chunk_scan_combined, mamba_split_conv1d_scan_combined
@@ -156,16 +157,32 @@ class Mamba2(nn.Module):
             y = y.reshape(batch * seqlen, -1)
         return self.out_proj(y)
 
+    def _A_inference(self):
+        """-exp(A_log), cached between optimizer updates when autograd is off (two tiny launches per layer-step otherwise)."""
+        if torch.is_grad_enabled() and self.A_log.requires_grad:
+            return -torch.exp(self.A_log.float())
+        c = getattr(self, "_A_cache", None)
+        if c is None or c[0] != self.A_log._version or c[1].device != self.A_log.device:
+            with torch.no_grad():
+                c = (self.A_log._version, -torch.exp(self.A_log.float()))
+            self._A_cache = c
+        return c[1]
+
     def step(self, hidden_states, conv_state, ssm_state):
         """hidden_states: (batch, 1, d_model); both states updated in place. -> (out (batch, 1, d_model), conv, ssm)"""
         assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
         zxbcdt = self.in_proj(hidden_states.squeeze(1))
+        return self.step_from_zxbcdt(zxbcdt, conv_state, ssm_state).unsqueeze(1), conv_state, ssm_state
+
+    def step_from_zxbcdt(self, zxbcdt, conv_state, ssm_state):
+        """The decode step after in_proj: zxbcdt (batch, d_in_proj) -> out (batch, d_model).  Split out so that callers
+        which fuse the block's pre-norm into the in_proj GEMV (stack.ResidualBlock) can enter here."""
         d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * self.ngroups * self.d_state - self.nheads) // 2
         z0, x0, z, xBC, dt = torch.split(
             zxbcdt, [d_mlp, d_mlp, self.d_ssm, self.d_ssm + 2 * self.ngroups * self.d_state, self.nheads], dim=-1)
         xBC = causal_conv1d_update(xBC, conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
         x, B, C = torch.split(xBC, [self.d_ssm, self.ngroups * self.d_state, self.ngroups * self.d_state], dim=-1)
-        A = -torch.exp(self.A_log.float())
+        A = self._A_inference()
         H, P, N = self.nheads, self.headdim, self.d_state
         batch = x.shape[0]
         # stride-0 expansions: the kernel takes the tied-head fast path (A/dt/dt_bias constant over (p, n))
@@ -177,12 +194,16 @@ class Mamba2(nn.Module):
                                    C.view(batch, self.ngroups, N), D_e, z=z.view(batch, H, P) if not self.rmsnorm else None,
                                    dt_bias=dt_bias_e, dt_softplus=True)
         y = y.reshape(batch, H * P)
+        if (self.rmsnorm and d_mlp == 0 and type(self.out_proj) is nn.Linear and self.norm.bias is None
+                and NL.applies(y, self.out_proj.weight)):
+            # gated RMSNorm + out_proj in one launch (weights streamed once)
+            return NL.norm_linear(y, self.out_proj.weight, self.out_proj.bias, norm_weight=self.norm.weight, eps=self.norm.eps,
+                                  z=z, group_size=self.norm.group_size, norm_before_gate=self.norm.norm_before_gate)
         if self.rmsnorm:
             y = self.norm(y, z)
         if d_mlp > 0:
             y = torch.cat([F.silu(z0) * x0, y], dim=-1)
-        out = self.out_proj(y)
-        return out.unsqueeze(1), conv_state, ssm_state
+        return self.out_proj(y)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         device = self.out_proj.weight.device

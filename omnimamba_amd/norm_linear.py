@@ -1,0 +1,47 @@
+"""Decode-step projections fused with the normalisation in front of them (omk_norm_linear, csrc/norm_linear.hip).
+
+At one token per sequence the reference runs `layer_norm_fn` (block.py:86-95), the task LoRA `Linear` (lora.py:185-279:
+base GEMV, A GEMV, B GEMV, scale, add) and later `RMSNormGated` + `out_proj` (upstream Mamba2.step) as separate launches
+of a few microseconds each; here each group is ONE kernel that streams the weight matrix once.  Inference only (no
+autograd); batch 1.  Callers fall back to the unfused ops when `applies()` says no.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _capi as K
+from ._lib import get_lib, require_device
+
+MAX_BATCH = 1     # one sequence per call; larger decode batches take the separate ops
+
+
+def applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Fused path preconditions (shape / dtype / no autograd)."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return False
+    if x.dim() != 2 or x.shape[0] > MAX_BATCH or x.shape[0] * x.shape[1] * 4 > 96 * 1024:
+        return False
+    vec = 4 if weight.dtype == torch.float32 else 8
+    return (weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 1024 == 0 and weight.shape[1] <= 8192
+            and weight.stride(0) % vec == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def norm_linear(x, weight, bias=None, *, norm_weight=None, eps=1e-5, residual=None, residual_out_dtype=None, z=None,
+                group_size=None, norm_before_gate=False, lora_a=None, lora_b=None, lora_scale=0.0, out_dtype=None):
+    """out = norm(x [+ residual] | gated by z) @ weight^T [+ bias] [+ lora_scale * (n @ lora_a^T) @ lora_b^T].
+    x: (B, in).  Returns out, or (out, residual_out) when `residual_out_dtype` is given (residual_out = x + residual)."""
+    lib = get_lib()
+    require_device(lib, x, weight, bias, norm_weight, residual, z, lora_a, lora_b)
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    if z is not None and (z.dtype != x.dtype or z.stride(-1) != 1):
+        z = z.to(x.dtype).contiguous()
+    B = x.shape[0]
+    out = torch.empty(B, weight.shape[0], dtype=out_dtype or x.dtype, device=x.device)
+    ro = None if residual_out_dtype is None else torch.empty(B, x.shape[1], dtype=residual_out_dtype, device=x.device)
+    p = K.NormLinear(x=K.T(x), residual=K.T(residual), z=K.T(z), norm_weight=K.T(norm_weight), weight=K.T(weight), bias=K.T(bias),
+                     lora_a=K.T(lora_a), lora_b=K.T(lora_b), residual_out=K.T(ro), out=K.T(out),
+                     group_size=0 if group_size is None else int(group_size), eps=float(eps), lora_scale=float(lora_scale),
+                     norm_before_gate=int(bool(norm_before_gate)))
+    K.run(lib, "omk_norm_linear", p, x)
+    return out if ro is None else (out, ro)

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import norm_linear as NL
 from .layer_norm import RMSNorm, layer_norm_fn
 from .linear import linear
 from .mamba2 import Mamba2
@@ -98,10 +99,37 @@ class ResidualBlock(nn.Module):
         self.layer_idx = layer_idx
 
     def forward(self, hidden_states, residual=None, inference_params=None):
+        if inference_params is not None and inference_params.seqlen_offset > 0 and hidden_states.shape[1] == 1:
+            fused = self._decode_step_fused(hidden_states, residual, inference_params)
+            if fused is not None:
+                return fused
         hidden_states, residual = layer_norm_fn(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
                                                 prenorm=True, residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps,
                                                 is_rms_norm=True)
         return self.mixer(hidden_states, inference_params=inference_params), residual
+
+    def _decode_step_fused(self, hidden_states, residual, inference_params):
+        """One-token step with add + RMSNorm + in_proj (+ the task's LoRA) as a single launch (omk_norm_linear), then the
+        rest of Mamba2.step.  Returns None when the fused kernel does not apply (training, large batch, odd shapes)."""
+        ip = self.mixer.in_proj
+        x2 = hidden_states.squeeze(1)
+        if self.norm.bias is not None or not isinstance(ip, nn.Linear) or not NL.applies(x2, ip.weight):
+            return None
+        lora = {}
+        if isinstance(ip, TaskLoRALinear):
+            if not ip.disable_adapters and ip.task_types in ("t2i", "mmu"):
+                if ip.training and not isinstance(ip.lora_dropout, nn.Identity):
+                    return None                       # dropout on the LoRA input: only the unfused path implements it
+                lora = dict(lora_a=getattr(ip, f"{ip.task_types}_lora_A0").weight, lora_b=getattr(ip, f"{ip.task_types}_lora_B0").weight,
+                            lora_scale=ip.scaling)
+        elif type(ip) is not nn.Linear:
+            return None
+        ro_dtype = torch.float32 if (self.residual_in_fp32 or (residual is not None and residual.dtype == torch.float32)) else x2.dtype
+        zxbcdt, new_res = NL.norm_linear(x2, ip.weight, ip.bias, norm_weight=self.norm.weight, eps=self.norm.eps,
+                                         residual=None if residual is None else residual.squeeze(1), residual_out_dtype=ro_dtype, **lora)
+        conv_state, ssm_state = self.mixer._get_states_from_cache(inference_params, x2.shape[0])
+        out = self.mixer.step_from_zxbcdt(zxbcdt, conv_state, ssm_state)
+        return out.unsqueeze(1), new_res.unsqueeze(1)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

@@ -1,0 +1,49 @@
+"""omk_norm_linear (fused norm + projection + LoRA of the decode step) vs the plain PyTorch composition."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle as O
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("B,In,Out,wdtype,xdtype", [(1, 1024, 40, torch.float32, torch.float32), (1, 2048, 70, torch.float32, torch.float32),
+                                                    (1, 1024, 33, torch.bfloat16, torch.bfloat16), (1, 1024, 600, torch.float32, torch.bfloat16)])
+def test_prenorm_linear_lora(dev, B, In, Out, wdtype, xdtype):
+    from omnimamba_amd.norm_linear import norm_linear
+    x, res = torch.randn(B, In).to(xdtype), torch.randn(B, In)
+    nw, W, bias = torch.rand(In) + 0.5, (torch.randn(Out, In) * 0.05).to(wdtype), torch.randn(Out)
+    la, lb = torch.randn(8, In) * 0.05, torch.randn(Out, 8) * 0.05
+    out, ro = norm_linear(x.to(dev), W.to(dev), bias.to(dev), norm_weight=nw.to(dev), eps=1e-5, residual=res.to(dev),
+                          residual_out_dtype=torch.float32, lora_a=la.to(dev), lora_b=lb.to(dev), lora_scale=4.0)
+    n0, r0 = O.add_norm_ref(x, nw, None, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=True, is_rms_norm=True,
+                            compute_dtype=torch.float64)
+    n0 = n0.double()
+    y0 = n0 @ W.double().t() + bias.double() + 4.0 * (n0 @ la.double().t()) @ lb.double().t()
+    tol = 2e-5 if xdtype == torch.float32 and wdtype == torch.float32 else 6e-3
+    assert out.dtype == xdtype and rel(ro, r0) < 1e-6
+    # the oracle rounds n to the activation dtype (a separate kernel would); the fused kernel keeps it in fp32
+    assert rel(out, y0) < (tol if xdtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("B,In,Out,G,nbg", [(1, 1024, 48, 1, False), (1, 2048, 48, 2, False), (1, 1024, 20, 1, True)])
+def test_gated_norm_linear(dev, B, In, Out, G, nbg):
+    from omnimamba_amd.norm_linear import norm_linear
+    x, z = torch.randn(B, In), torch.randn(B, In)
+    nw, W = torch.rand(In) + 0.5, torch.randn(Out, In) * 0.05
+    out = norm_linear(x.to(dev), W.to(dev), None, norm_weight=nw.to(dev), eps=1e-5, z=z.to(dev), group_size=In // G,
+                      norm_before_gate=nbg)
+    n0 = O.rmsnorm_gated_ref(x, nw, z=z, eps=1e-5, group_size=In // G, norm_before_gate=nbg, compute_dtype=torch.float64)
+    assert rel(out, n0.double() @ W.double().t()) < 2e-5
+
+
+def test_plain_linear_and_limits(dev):
+    from omnimamba_amd import norm_linear as NL
+    x, W = torch.randn(1, 1024), torch.randn(10, 1024)
+    out = NL.norm_linear(x.to(dev), W.to(dev))
+    assert rel(out, F.linear(x, W)) < 2e-5
+    assert NL.applies(x, W) and not NL.applies(torch.randn(2, 1024), W) and not NL.applies(torch.randn(1, 256), torch.randn(10, 256))
+    assert not NL.applies(x, W.requires_grad_())

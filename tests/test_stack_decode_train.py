@@ -84,6 +84,53 @@ def test_greedy_decode_trace_and_tokens(dev):
     assert torch.equal(full[:, Pn - 1:].argmax(-1).cpu(), toks.cpu())
 
 
+@pytest.mark.parametrize("task", ["t2i", "mmu"])
+def test_fused_decode_step_equals_unfused(dev, task, monkeypatch):
+    """The one-launch add + norm + in_proj + LoRA and gated-norm + out_proj of the decode step (omk_norm_linear) against the
+    same step through the separate ops, on a stack wide enough for the fused kernel to apply (d_model 1024)."""
+    from omnimamba_amd import norm_linear as NL
+    from omnimamba_amd.generation import InferenceParams
+    from omnimamba_amd.stack import OmniMambaLM, StackConfig
+    cfg = StackConfig(d_model=1024, n_layer=1, vocab_size=50, pad_vocab_size_multiple=16, vqvae_vocab_size=40, num_tokens=8,
+                      t2i_positions=24, mmu_positions=40, ssm_cfg=dict(d_state=16, headdim=64, chunk_size=16), lora_dropout=0.05)
+    torch.manual_seed(0)
+    model = OmniMambaLM(cfg).to(dev).eval()
+    with torch.no_grad():
+        for blk in model.backbone.layers:       # non-trivial adapters
+            for t in ("t2i", "mmu"):
+                getattr(blk.mixer.in_proj, f"{t}_lora_B0").weight.normal_(std=0.05)
+    emb = torch.randn(1, 6, cfg.d_model).to(dev)
+    calls = {"n": 0}
+    real = NL.norm_linear
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setattr(NL, "applies", lambda x, w: False)
+        monkeypatch.setattr(NL, "norm_linear", counting)
+        ip = InferenceParams(max_seqlen=32, max_batch_size=1)
+        with torch.no_grad():
+            model(None, emb, task=task, inference_params=ip, num_last_tokens=1)
+            ip.seqlen_offset = 6
+            ids = torch.tensor([[3]]).to(dev)
+            pos = torch.full((1, 1), 6, dtype=torch.long).to(dev)
+            logits = []
+            for step in range(2):
+                o = model(ids, None, position_ids=pos + step, task=task, inference_params=ip, num_last_tokens=1)
+                ip.seqlen_offset += 1
+                logits.append(o.t2i_logits if task == "t2i" else o.mmu_logits)
+        states = [ip.key_value_memory_dict[i][1].clone() for i in range(cfg.n_layer)]
+        outs.append((torch.cat(logits, 1), states))
+    assert calls["n"] == 2 * cfg.n_layer * 2          # pre-norm + in_proj and gated norm + out_proj, every layer, every step
+    assert rel(outs[0][0], outs[1][0]) < 2e-5
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert rel(a, b) < 2e-5
+
+
 @pytest.mark.gpu
 def test_decode_hipgraph_equals_eager():
     from omnimamba_amd.generation import decode
