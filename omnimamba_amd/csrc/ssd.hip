@@ -19,19 +19,39 @@ struct DtPrepArgs {
   const void* dt; const void* bias; float* dtp; float* dsoft;
   int64_t sb, sl, sh; int B, L, H, dt_dt, bias_dt, softplus; float lo, hi;
 };
-__global__ void ssd_dt_prep_kernel(DtPrepArgs a) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (int64_t)a.B * a.L * a.H) return;
-  const int h = (int)(g % a.H), t = (int)((g / a.H) % a.L), b = (int)(g / ((int64_t)a.H * a.L));
-  float v = load_rt(a.dt, (int64_t)b * a.sb + (int64_t)t * a.sl + (int64_t)h * a.sh, a.dt_dt);
-  if (a.bias) v += load_rt(a.bias, h, a.bias_dt);
-  float d = 1.f;
-  if (a.softplus) { d = v > 20.f ? 1.f : sigmoid_f(v); v = softplus_f(v); }
-  if (v < a.lo) { v = a.lo; d = 0.f; }
-  if (v > a.hi) { v = a.hi; d = 0.f; }
-  const int64_t o = ((int64_t)b * a.H + h) * a.L + t;
-  a.dtp[o] = v;
-  if (a.dsoft) a.dsoft[o] = d;
+// block = 32 tokens x 32 heads of one batch element: loads follow the unit-stride head dimension of (B, L, H), the stores
+// the unit-stride token dimension of (B, H, L); the tile turns in LDS (a direct per-element mapping writes 4 bytes per
+// lane into H different rows: 26 us instead of 6 for the 1.3B shape)
+__global__ __launch_bounds__(256) void ssd_dt_prep_kernel(DtPrepArgs a) {
+  __shared__ float sv[32][33], sd[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int nth = (a.H + 31) / 32, ntl = (a.L + 31) / 32;
+  const int hb = blockIdx.x % nth, lb = (blockIdx.x / nth) % ntl, b = blockIdx.x / (nth * ntl);
+  const int h = hb * 32 + tx;
+  const float bias = (a.bias && h < a.H) ? load_rt(a.bias, h, a.bias_dt) : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int t = lb * 32 + ty + 8 * j;
+    float v = 0.f, d = 1.f;
+    if (t < a.L && h < a.H) {
+      v = load_rt(a.dt, (int64_t)b * a.sb + (int64_t)t * a.sl + (int64_t)h * a.sh, a.dt_dt) + bias;
+      if (a.softplus) { d = v > 20.f ? 1.f : sigmoid_f(v); v = softplus_f(v); }
+      if (v < a.lo) { v = a.lo; d = 0.f; }
+      if (v > a.hi) { v = a.hi; d = 0.f; }
+    }
+    sv[ty + 8 * j][tx] = v;
+    sd[ty + 8 * j][tx] = d;
+  }
+  block_sync();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int hh = hb * 32 + ty + 8 * j, t = lb * 32 + tx;
+    if (hh < a.H && t < a.L) {
+      const int64_t o = ((int64_t)b * a.H + hh) * a.L + t;
+      a.dtp[o] = sv[tx][ty + 8 * j];
+      if (a.dsoft) a.dsoft[o] = sd[tx][ty + 8 * j];
+    }
+  }
 }
 
 __global__ void zero_f32_kernel(float* p, int64_t n) {
@@ -324,8 +344,7 @@ static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdD
   a.dt = dt.data; a.bias = dtb.data; a.dtp = dtp; a.dsoft = dsoft; a.sb = dt.stride[0]; a.sl = dt.stride[1]; a.sh = dt.stride[2];
   a.B = d.B; a.L = d.L; a.H = d.H; a.dt_dt = dt.dtype; a.bias_dt = dtb.dtype; a.softplus = softplus; a.lo = lo;
   a.hi = hi > 0.f ? hi : INFINITY;
-  int64_t n = (int64_t)d.B * d.L * d.H;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 31) / 32))), block(256);
   OMK_LAUNCH(ssd_dt_prep_kernel, grid, block, 0, stream, a);
 }
 static void launch_zero(float* p, int64_t n, omk_stream stream) {
