@@ -40,6 +40,16 @@ def test_gated_norm_linear(dev, B, In, Out, G, nbg):
     assert rel(out, n0.double() @ W.double().t()) < 2e-5
 
 
+def test_residual_out_without_incoming_residual(dev):
+    """First block of a stack: no residual yet, residual_out must still be x (in the requested dtype)."""
+    from omnimamba_amd.norm_linear import norm_linear
+    x, nw, W = torch.randn(1, 1024), torch.rand(1024) + 0.5, torch.randn(16, 1024) * 0.05
+    out, ro = norm_linear(x.to(dev), W.to(dev), None, norm_weight=nw.to(dev), eps=1e-5, residual_out_dtype=torch.float32)
+    n0, r0 = O.add_norm_ref(x, nw, None, residual=None, eps=1e-5, prenorm=True, residual_in_fp32=True, is_rms_norm=True,
+                            compute_dtype=torch.float64)
+    assert rel(ro, x) < 1e-7 and rel(out, n0.double() @ W.double().t()) < 2e-5
+
+
 def test_plain_linear_and_limits(dev):
     from omnimamba_amd import norm_linear as NL
     x, W = torch.randn(1, 1024), torch.randn(10, 1024)
