@@ -20,10 +20,11 @@ def bench_decode(args, dev):
     (the reference inference scripts never cast the model: scripts/inference_t2i.py:21-26)."""
     torch.manual_seed(0)
     cfg = StackConfig.omnimamba_1_3b()
-    model = OmniMambaLM(cfg, device=dev, dtype=torch.float32).eval()
+    wdt = torch.bfloat16 if args.weights == "bf16" else torch.float32   # the reference keeps fp32; bf16 = a model cast by the user
+    model = OmniMambaLM(cfg, device=dev, dtype=wdt).eval()
     B, P, new = args.batch, 72, 256
     ids = torch.zeros(B, P, dtype=torch.long, device=dev)
-    emb = torch.randn(B, P, cfg.d_model, device=dev)
+    emb = torch.randn(B, P, cfg.d_model, device=dev, dtype=wdt)
     out = {}
     for cg in (True, False) if args.eager_too else (True,):
         decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=cg)          # warm-up (captures the graph)
@@ -38,7 +39,8 @@ def bench_decode(args, dev):
     ms_tok = out["graph"] / new * 1e3
     print(json.dumps({"workload": "OmniMamba-1.3B T2I decode (configs[2])", "batch": B, "prompt": P, "new_tokens": new,
                       "ms_per_token": round(ms_tok, 3), "tokens_per_s": round(B * new / out["graph"], 1),
-                      "weights_GBs": round(n_param * 4 / (ms_tok * 1e-3) / 1e9, 1), "params": n_param, "dtype": "f32",
+                      "weights_GBs": round(n_param * (2 if wdt == torch.bfloat16 else 4) / (ms_tok * 1e-3) / 1e9, 1), "params": n_param,
+                      "dtype": "bf16" if wdt == torch.bfloat16 else "f32",
                       "eager_ms_per_token": round(out["eager"] / new * 1e3, 3) if "eager" in out else None}), flush=True)
 
 
@@ -87,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--stage", default="finetune")
     ap.add_argument("--eager-too", action="store_true")
+    ap.add_argument("--weights", choices=["f32", "bf16"], default="f32")
     args = ap.parse_args()
     rank, local, world = init_distributed()
     dev = torch.device("cuda", local)
