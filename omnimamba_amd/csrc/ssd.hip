@@ -367,7 +367,8 @@ using namespace omk;
 
 extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
   if (!p) return 0;
-  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024;   // + developer profiling slots
+  // dt' + developer profiling slots + the segment states of a split sequence (ssd_scan.h)
+  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024 + ssd_seg_bytes((int)(p->x.shape[0] * p->x.shape[2]), (int)p->x.shape[1]);
 }
 
 extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
@@ -399,12 +400,16 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   g.out = p->out.data; g.osb = p->out.stride[0]; g.osl = p->out.stride[1]; g.osh = p->out.stride[2]; g.out_dt = p->out.dtype; g.outx = p->out_x.data;
   if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
   if (getenv("OMK_PROF") && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p)) g.prof = (unsigned long long*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4));
+#ifdef OMK_PHASE_PROF
+  if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
+#endif
+  if (ssd_seg_bytes(d.B * d.H, d.L) && !getenv("OMK_SSD_NO_SPLIT")) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
   rc = run_scan(g, p->force_generic, stream);
   if (rc) return rc;
   return finish_launch("ssd_scan_fwd");
 }
 
-struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd; size_t total; };
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg; size_t total; };
 static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, bool need_part) {
   BwdWs w; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
@@ -415,6 +420,7 @@ static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N,
   const size_t nC = (size_t)(L + 63) / 64;
   w.ckpt = need_part ? take((size_t)B * (H / 2) * nC * (8 * 2 * 8 * 64) * 4) : nullptr;
   w.bnd = need_part ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
+  w.seg = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;   // dx scan, split sequence
   w.total = off;
   return w;
 }
@@ -451,6 +457,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.fin = (float*)p->dinitial_states.data; g.fin_extra_decay = 1;
       g.fsb = p->dinitial_states.stride[0]; g.fsh = p->dinitial_states.stride[1]; g.fsu = p->dinitial_states.stride[2]; g.fsk = p->dinitial_states.stride[3];
     }
+    g.seg = getenv("OMK_SSD_NO_SPLIT") ? nullptr : w.seg;
     g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
     if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
     *gdx = g;

@@ -77,7 +77,11 @@ struct SmemA3 {
 };
 static_assert(sizeof(SmemA3) <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
 
-template <int MODE, bool EXTRAS>   // EXTRAS: gate z and / or the pre-gate copy of y (forward without the gated norm)
+// EXTRAS: gate z and / or the pre-gate copy of y (forward without the gated norm).
+// STATE: the state-only pass of a split sequence (ssd_scan.h, GScan::seg): segments 0 .. nseg - 2, no output, the
+// segment's end state from a zero start and its total decay go to the workspace; the scan proper (STATE = false,
+// nseg workgroups per head) starts every segment from the fold of the earlier segments' states.
+template <int MODE, bool EXTRAS, bool STATE>
 __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA3& sm = *reinterpret_cast<SmemA3*>(smem_raw);
@@ -88,9 +92,12 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   // (batch, head) so the heads that share B / C rows also share an L2
   int vid = blockIdx.x;
   if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int b = vid / a.H, h = vid % a.H;
+  // workgroup order (b, segment, h): the heads of one (batch, segment) share B / C rows and an XCD
+  const int nwseg = STATE ? a.nseg - 1 : a.nseg;
+  const int h = vid % a.H, seg = (vid / a.H) % nwseg, b = vid / (a.H * nwseg);
   const int g = h / (a.H / a.G);
   const int nC = (a.L + QC - 1) / QC;
+  const int c0 = seg * a.cps, c1 = (c0 + a.cps < nC) ? c0 + a.cps : nC;   // chunks of this workgroup, scan order
   const bool rev = a.reverse != 0;
   // chunk row i <-> token tlo + (rev ? 63 - i : i), tlo = 64 * chunk id
   auto chunk_lo = [&](int c) -> int { return (rev ? nC - 1 - c : c) * QC; };
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   };
   const float Ah = a.A[h];
   const float Ah2 = Ah * LOG2E;
-  auto scalars = [&](int buf) {   // wave 0 only; lanes = rows of the staged chunk
+  float segdec = 0.f;   // STATE: log2 of the segment's total decay (wave 0)
+  auto scalars = [&](int buf, bool fresh) {   // wave 0 only; lanes = rows of the staged chunk (fresh: not a re-stage)
     {
       const int t = stlo + rowtok(lane);
       const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
@@ -166,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     }
     const float cs = wave_incl_scan_add(rda * Ah2);
     const float cs_end = wave_read_lane(cs, 63);
+    if (STATE && fresh) segdec += cs_end;
     sm.cs[buf][lane] = cs;
     sm.lw[buf][lane] = log2_fast(rwv) - cs;
     sm.ecs[buf][lane] = exp2_fast(cs);
@@ -191,17 +200,37 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   }
   // ---- running state: S^T[32 w + ..][32 ut + ..], ut = 0, 1
   f32x16 accS[2];
+  float init_scale = 1.f;   // decay of the caller's initial state down to this segment's start
 #pragma unroll
   for (int ut = 0; ut < 2; ut++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      float v = 0.f;
-      if (a.init) {
-        const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * ut + l31;
-        v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
-      }
-      accS[ut][r] = v;
+    for (int r = 0; r < 16; r++) accS[ut][r] = 0.f;
+  const int64_t bh = (int64_t)b * a.H + h;
+  // accumulator order of the segment states: element (w, ut, r, lane) at ((2 w + ut) * 16 + r) * 64 + lane
+  const int segoff = (2 * w * 16) * 64 + lane;
+  if (!STATE && seg > 0) {
+    const float* sdec = a.seg + (int64_t)a.B * a.H * a.nseg * SEG_STATE + bh * a.nseg;
+    float run = 0.f;   // log2 decay from the end of segment i to the start of this one
+    for (int i = seg - 1; i >= 0; i--) {
+      const float cf = exp2_fast(run);
+      const float* sp = a.seg + (bh * a.nseg + i) * SEG_STATE + segoff;
+#pragma unroll
+      for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accS[ut][r] += cf * sp[(ut * 16 + r) * 64];
+      run += sdec[i];
     }
+    init_scale = exp2_fast(run);
+  }
+  if (a.init && !STATE) {
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * ut + l31;
+        accS[ut][r] += init_scale * load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+      }
+  }
   auto publish_state = [&]() {
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
@@ -214,14 +243,16 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       }
   };
 
-  stlo = chunk_lo(0);
-  prefetch_q();
+  stlo = chunk_lo(c0);
+  if (!STATE) prefetch_q();
   prefetch_k();
   prefetch_u();
   commit(0);
-  if (w == 0) scalars(0);
-  publish_state();
-  if (tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
+  if (w == 0) scalars(0, true);
+  if (!STATE) {
+    publish_state();
+    if (tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
+  }
   block_sync();
   uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
   uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
@@ -236,38 +267,41 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const bool prof = a.prof != nullptr && blockIdx.x == 0;
 #define PT3(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
   uint64_t tprev = prof ? clock64_() : 0;
+  const int abl = a.ablate;   // developer experiment: skip phases (bit i), results are wrong
 #else
 #define PT3(i) do { } while (0)
+  constexpr int abl = 0;
 #endif
-  for (int c = 0; c < nC; c++) {
-    const int cur = c & 1, nxt = cur ^ 1;
+  for (int c = c0; c < c1; c++) {
+    const int cur = (c - c0) & 1, nxt = cur ^ 1;
     const int tlo = chunk_lo(c);
-    const int cnext = c + 1 < nC ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
+    const int cnext = c + 1 < c1 ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
     PT3(0);
     // ---- (1) O = exp2(cs_l) * (Q . S_in): A = Q fragments (registers), B = S_in[k][u] as [u][k] bf16 rows
     f32x4 acc[4];
 #pragma unroll
     for (int ut = 0; ut < 4; ut++) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!STATE) {   // (the state-only pass is: stage, state update, one barrier)
+      if (!(abl & 1))
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++)
+      for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-      for (int ut = 0; ut < 4; ut++) {
-        const s16x8 fs = as_s16x8(ld16(&sm.S[o_rd[kk] + 16 * 128 * ut]));
-        acc[ut] = mfma16x16x32_bf16(fs, as_s16x8(qf[kk]), acc[ut]);   // O^T[u][l]: 4 consecutive u per lane
-      }
-    {
+        for (int ut = 0; ut < 4; ut++) {
+          const s16x8 fs = as_s16x8(ld16(&sm.S[o_rd[kk] + 16 * 128 * ut]));
+          acc[ut] = mfma16x16x32_bf16(fs, as_s16x8(qf[kk]), acc[ut]);   // O^T[u][l]: 4 consecutive u per lane
+        }
       const float e1 = sm.ecs[cur][16 * w + t16];
 #pragma unroll
       for (int ut = 0; ut < 4; ut++) acc[ut] *= e1;
+      PT3(1);
+      block_sync();   // X: every wave is done with S_in
     }
-    PT3(1);
-    block_sync();   // X: every wave is done with S_in
     PT3(2);
     stlo = chunk_lo(cnext);
     prefetch_k();
     prefetch_u();
     // ---- (2) intra-chunk: G tiles -> M fragments (registers) -> M . U
-    {
+    if (!STATE) {
       const float cs_l = sm.cs[cur][16 * w + t16];
       auto block = [&](int kk, bool second, bool diag0, bool diag1) {
         // tiles ta = 2 kk + j (j = 0, 1) of G^T: lane holds s = 16 ta + 4 g16 + r (r = 0..3) for its own l = 16 w + t16
@@ -309,15 +343,16 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
         }
       };
       // strip w: s blocks kk = 0 .. w >> 1; the diagonal tile is ta = w, tiles ta > w are empty
-      if (w == 0) { block(0, false, true, false); }
+      if (abl & 2) { }
+      else if (w == 0) { block(0, false, true, false); }
       else if (w == 1) { block(0, true, false, true); }
       else if (w == 2) { block(0, true, false, false); block(1, false, true, false); }
       else { block(0, true, false, false); block(1, true, false, true); }
     }
     PT3(3);
-    prefetch_q();
+    if (!STATE) prefetch_q();
     // ---- (3) state update: S^T[k][u] = exp2(cs_end) S^T + sum_l (ws_l K^T[k][l]) U[l][u]
-    {
+    if (!(abl & 4)) {
       const float dec = sm.ecs[cur][QC - 1];
 #pragma unroll
       for (int ut = 0; ut < 2; ut++) accS[ut] *= dec;
@@ -354,14 +389,14 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     }
     PT3(4);
     // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
-    publish_state();
+    if (!STATE && !(abl & 8)) publish_state();
     commit(nxt);
-    if (w == 0) scalars(nxt);
+    if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);
     // ---- epilogue from the MFMA layout: 4 consecutive columns of one row per (lane, ut)
-    {
+    if (!STATE) {
       const int trow = tlo + erow;
-      if (trow < a.L) {
+      if (trow < a.L && !(abl & 16)) {
         const float dts = MODE == GS_DX ? sm.dtl[cur][16 * w + t16] : 1.f;
         uint16_t* oc = ob + (int64_t)tlo * osl;
 #pragma unroll
@@ -393,7 +428,16 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   if (prof && lane == 0)
     for (int i = 0; i < 12; i++) a.prof[w * 12 + i] = pt[i];
 #endif
-  if (a.fin) {
+  if (STATE) {
+    float* sp = a.seg + (bh * a.nseg + seg) * SEG_STATE + segoff;
+#pragma unroll
+    for (int ut = 0; ut < 2; ut++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) sp[(ut * 16 + r) * 64] = accS[ut][r];
+    if (tid == 0) a.seg[(int64_t)a.B * a.H * a.nseg * SEG_STATE + bh * a.nseg + seg] = segdec;
+    return;
+  }
+  if (a.fin && seg == a.nseg - 1) {
     const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
@@ -845,14 +889,22 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (!stride_ok(g.K.sl) || !stride_ok(g.Q.sl) || !stride_ok(g.U.sl) || !stride_ok(g.osl) || (g.Z.p && !stride_ok(g.Z.sl))) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
-  dim3 grid((unsigned)(g.B * g.H)), block(256);   // one head per workgroup, two workgroups per CU
+  // one head (x one segment of the sequence) per workgroup, two workgroups per CU
+  GScan a = g;
+  const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
   const size_t smem = sizeof(SmemA3);
-#define OMK_A3(MODE_, EX_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_>), grid, block, smem, stream, g); } while (0)
-  if (g.mode == GS_Y && (g.Z.p || g.outx)) OMK_A3(GS_Y, true);
-  else if (g.mode == GS_Y) OMK_A3(GS_Y, false);
-  else OMK_A3(GS_DX, false);
+#define OMK_A3(MODE_, EX_, ST_, GRID_) do { \
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_>), GRID_, block, smem, stream, a); } while (0)
+  if (a.nseg > 1) {
+    dim3 sgrid((unsigned)(a.B * a.H * (a.nseg - 1)));
+    OMK_A3(GS_Y, false, true, sgrid);   // the state pass does not depend on the mode (no output)
+  }
+  if (a.mode == GS_Y && (a.Z.p || a.outx)) OMK_A3(GS_Y, true, false, grid);
+  else if (a.mode == GS_Y) OMK_A3(GS_Y, false, false, grid);
+  else OMK_A3(GS_DX, false, false, grid);
 #undef OMK_A3
   return OMK_OK;
 }

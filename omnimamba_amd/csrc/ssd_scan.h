@@ -10,6 +10,7 @@
 // (derivation checked against autograd in tests/test_bwd_derivation.py).  Two implementations consume this
 // descriptor: the shape-generic fp32 VALU kernel (ssd.hip) and the MFMA chunked kernel (ssd_mfma.hip).
 #pragma once
+#include <cstdlib>
 #include "omk_common.h"
 
 namespace omk {
@@ -42,8 +43,38 @@ struct GScan {
   // DC/DB (MFMA): forward-state checkpoints at every chunk end, written by the dC scan in MFMA fragment order
   // (bf16 pairs) and read back by the dB scan, which emits the exact decay-gradient restart values bnd (B, H, nC + 1)
   void* ckpt; float* bnd;
+  // class A (MFMA) sequence split for few (batch, head) pairs: nseg segments of cps chunks in scan order.  A state-only
+  // pass leaves every segment's end state from a zero start in seg[(bh * nseg + s) * SEG_STATE ..] (MFMA accumulator
+  // order) and its total log2 decay in seg[BH * nseg * SEG_STATE + bh * nseg + s]; the scan proper folds them.
+  float* seg; int nseg, cps;
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
+  int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
+
+constexpr int SEG_STATE = 64 * 128;
+struct SegPlan { int nseg, cps; };
+// Few (batch, head) sequences leave CUs idle (B = 1, H = 64: a quarter of the chip).  Cut L so that up to two
+// workgroups per CU exist; the extra state pass re-reads x and B and costs about a third of a scan, so the split
+// only pays from four segments on (measured: B = 1 L = 8192 264 -> 106 us, B = 2 269 -> 190 us, B = 4 loses),
+// and segments stay >= 8 chunks long.
+inline SegPlan ssd_segments(int BH, int L) {
+  const int nC = (L + 63) / 64;
+  SegPlan p = {1, nC};
+  int minc = 8;   // chunks per segment at least (OMK_SSD_SEG_CHUNKS: test hook, lets short sequences split)
+  if (const char* e = getenv("OMK_SSD_SEG_CHUNKS")) minc = atoi(e) > 0 ? atoi(e) : minc;
+  if (BH <= 0 || BH > 128) return p;
+  int n = 512 / BH;
+  if (n > nC / minc) n = nC / minc;
+  if (n > 16) n = 16;
+  if (n < 2 || (n < 4 && minc >= 8)) return p;
+  p.cps = (nC + n - 1) / n;
+  p.nseg = (nC + p.cps - 1) / p.cps;
+  return p;
+}
+inline size_t ssd_seg_bytes(int BH, int L) {
+  const SegPlan p = ssd_segments(BH, L);
+  return p.nseg > 1 ? (((size_t)BH * p.nseg * (SEG_STATE + 1) * 4 + 255) & ~(size_t)255) : 0;
+}
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);
 // returns OMK_EUNSUPPORTED (without touching the error text) when the shape/dtype/layout is outside the MFMA kernel

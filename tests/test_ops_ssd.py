@@ -100,9 +100,56 @@ def test_ssd_mfma_fwd(dev, L, H, G, with_z, with_init, arith):
         assert out_x is not None
 
 
-@pytest.mark.parametrize("L,H,G,with_z,with_init", [(130, 2, 1, False, False), (70, 4, 2, True, True)])
-def test_ssd_mfma_bwd(dev, L, H, G, with_z, with_init):
-    """bf16 MFMA backward (3 scans + finish) vs autograd of the fp32 oracle on identical bf16 inputs."""
+@pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(200, 2, 1, False, False, 1), (330, 2, 2, True, True, 2)])
+def test_ssd_mfma_fwd_split_sequence(dev, monkeypatch, L, H, G, with_z, with_init, minc):
+    """Few (batch, head) pairs: the class A scans cut the sequence into segments (state-only pass + scan proper from the
+    folded segment states, ssd_scan.h).  Same tolerances as the unsplit kernel, and both agree with each other."""
+    monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))   # production: >= 8 chunks per segment
+    torch.manual_seed(21)
+    out, out_x, fin, outg, fing, o0, f0, o32 = _mfma_case(dev, 1, L, H, G, with_z, with_init)
+    monkeypatch.setenv("OMK_SSD_NO_SPLIT", "1")
+    torch.manual_seed(21)
+    out1, _, fin1, _, _, _, _, _ = _mfma_case(dev, 1, L, H, G, with_z, with_init)
+    q = rel(o32.bfloat16().float(), o32)
+    tol = (1.5e-3 ** 2 + q ** 2) ** 0.5
+    assert rel(out.float(), o32) < tol and rel(fin, f0) < 2.5e-3
+    assert rel(out.float(), out1.float().cpu()) < 2e-3 and rel(fin, fin1.cpu()) < 1e-5
+
+
+def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
+    """Slow decay (|A| ~ 0.1): the state entering a segment is dominated by what the earlier segments left, so this
+    pins the fold of the segment states (coefficients = products of the later segments' decays, initial_states
+    included) against the fp32 oracle, and the reverse scan (dx) through the gradient."""
+    import omnimamba_amd.ssd_combined as S
+    monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", "1")
+    L, H, G, P, N = 300, 2, 1, 64, 128
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=3)
+    A = -(torch.rand(H) * 0.1 + 0.05)
+    dtb = torch.randn(H) * 0.3 - 2.0
+    src = [x, dt, A, Bm, Cm, D, dtb, init]
+    lv = [t.clone().to(dev).requires_grad_() for t in src]
+    y, fin = S.mamba_chunk_scan_combined(lv[0], lv[1], lv[2], lv[3], lv[4], 256, D=lv[5], dt_bias=lv[6], initial_states=lv[7],
+                                         dt_softplus=True, return_final_states=True)
+    gy, gf = torch.randn(y.shape).bfloat16(), torch.randn(fin.shape)
+    torch.autograd.backward([y, fin], [gy.to(dev), gf.to(dev)])
+    dl = [t.double().clone().requires_grad_() for t in src]
+    y0, f0 = O.ssd_ref_sequential(dl[0], dl[1], dl[2], dl[3], dl[4], D=dl[5], dt_bias=dl[6], initial_states=dl[7],
+                                  dt_softplus=True, return_final_states=True, compute_dtype=torch.float64)
+    torch.autograd.backward([y0, f0], [gy.double(), gf.double()])
+    q = rel(y0.float().bfloat16().float(), y0.float())
+    assert rel(y.float().cpu(), y0.float()) < (2.5e-3 ** 2 + q ** 2) ** 0.5
+    assert rel(fin.cpu(), f0.float()) < 3e-3
+    assert rel(lv[0].grad.float().cpu(), dl[0].grad.float()) < 6e-3          # dx: reverse scan, split the same way
+    assert rel(lv[7].grad.float().cpu(), dl[7].grad.float()) < 6e-3          # d initial_states: its final state
+
+
+@pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(130, 2, 1, False, False, None), (70, 4, 2, True, True, None),
+                                                                (200, 2, 1, False, True, 1)])
+def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
+    """bf16 MFMA backward (3 scans + finish) vs autograd of the fp32 oracle on identical bf16 inputs.  minc: split the
+    sequence of the y and dx scans into segments of that many chunks (see test_ssd_mfma_fwd_split_sequence)."""
+    if minc:
+        monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
     import omnimamba_amd.ssd_combined as S
     P, N = 64, 128
     x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=5)
