@@ -81,7 +81,9 @@ static_assert(sizeof(SmemA3) <= 80 * 1024, "two workgroups must fit the 160 KB o
 // STATE: the state-only pass of a split sequence (ssd_scan.h, GScan::seg): segments 0 .. nseg - 2, no output, the
 // segment's end state from a zero start and its total decay go to the workspace; the scan proper (STATE = false,
 // nseg workgroups per head) starts every segment from the fold of the earlier segments' states.
-template <int MODE, bool EXTRAS, bool STATE>
+// DFOLD (forward, one D per head): D x_l rides on the diagonal of M (M_ll += D, kept to 16 bits by the hi + lo split)
+// instead of an epilogue that re-reads x and D from LDS.
+template <int MODE, bool EXTRAS, bool STATE, bool DFOLD = false>
 __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA3& sm = *reinterpret_cast<SmemA3*>(smem_raw);
@@ -251,8 +253,9 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   if (w == 0) scalars(0, true);
   if (!STATE) {
     publish_state();
-    if (tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
+    if (!DFOLD && tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
   }
+  const float Dh = (DFOLD && a.D) ? load_rt(a.D, (int64_t)h * a.Dsh, a.D_dt) : 0.f;
   block_sync();
   uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
   uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const bool prof = a.prof != nullptr && blockIdx.x == 0;
 #define PT3(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
   uint64_t tprev = prof ? clock64_() : 0;
+  const uint64_t t_core0 = tprev, t_ref0 = prof ? __builtin_readsteadycounter() : 0;   // core clock vs 100 MHz reference
   const int abl = a.ablate;   // developer experiment: skip phases (bit i), results are wrong
 #else
 #define PT3(i) do { } while (0)
@@ -321,7 +325,10 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             v[r] = gt[r] * exp2_fast(cs_l + lw4[r]);
-            if (j == 0 ? diag0 : diag1) v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+            if (j == 0 ? diag0 : diag1) {
+              if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh : 0.f);
+              else v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+            }
           }
 #pragma unroll
           for (int p2 = 0; p2 < 2; p2++) {   // bf16 hi + lo: the rounding of M dominates the error of y otherwise
@@ -401,9 +408,12 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
         uint16_t* oc = ob + (int64_t)tlo * osl;
 #pragma unroll
         for (int ut = 0; ut < 4; ut++) {
-          const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][o_xu[ut] + 16 * 64 * w]);
-          const f32x4 Du = *reinterpret_cast<const f32x4*>(&sm.Dv[16 * ut + 4 * g16]);   // D of columns 16 ut + 4 g16 + r
-          f32x4 v = acc[ut] * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
+          f32x4 v = acc[ut];
+          if (!DFOLD) {
+            const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][o_xu[ut] + 16 * 64 * w]);
+            const f32x4 Du = *reinterpret_cast<const f32x4*>(&sm.Dv[16 * ut + 4 * g16]);   // D of columns 16 ut + 4 g16 + r
+            v = acc[ut] * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
+          }
           if (MODE == GS_Y) {
             if (EXTRAS && oxb) {
               u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     PT3(7);
   }
 #ifdef OMK_PHASE_PROF
+  if (prof) { pt[10] = clock64_() - t_core0; pt[11] = __builtin_readsteadycounter() - t_ref0; }
   if (prof && lane == 0)
     for (int i = 0; i < 12; i++) a.prof[w * 12 + i] = pt[i];
 #endif
@@ -895,16 +906,17 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   a.nseg = sp.nseg; a.cps = sp.cps;
   dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
   const size_t smem = sizeof(SmemA3);
-#define OMK_A3(MODE_, EX_, ST_, GRID_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_>), GRID_, block, smem, stream, a); } while (0)
+#define OMK_A3(MODE_, EX_, ST_, DF_, GRID_) do { \
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), GRID_, block, smem, stream, a); } while (0)
   if (a.nseg > 1) {
     dim3 sgrid((unsigned)(a.B * a.H * (a.nseg - 1)));
-    OMK_A3(GS_Y, false, true, sgrid);   // the state pass does not depend on the mode (no output)
+    OMK_A3(GS_Y, false, true, false, sgrid);   // the state pass does not depend on the mode (no output)
   }
-  if (a.mode == GS_Y && (a.Z.p || a.outx)) OMK_A3(GS_Y, true, false, grid);
-  else if (a.mode == GS_Y) OMK_A3(GS_Y, false, false, grid);
-  else OMK_A3(GS_DX, false, false, grid);
+  const bool dfold = !a.D || a.Dsp == 0;   // one D per head (or none)
+  if (a.mode == GS_Y && (a.Z.p || a.outx)) { if (dfold) OMK_A3(GS_Y, true, false, true, grid); else OMK_A3(GS_Y, true, false, false, grid); }
+  else if (a.mode == GS_Y) { if (dfold) OMK_A3(GS_Y, false, false, true, grid); else OMK_A3(GS_Y, false, false, false, grid); }
+  else OMK_A3(GS_DX, false, false, false, grid);
 #undef OMK_A3
   return OMK_OK;
 }

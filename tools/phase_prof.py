@@ -1,6 +1,7 @@
 """Developer tool: per-phase cycle breakdown of the forward scan (OMK_PROF=1 makes workgroup 0 dump s_memtime deltas)."""
 import os, sys
 os.environ["OMK_PROF"] = "1"
+os.environ["OMK_SSD_NO_SPLIT"] = "1"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd import _capi as K
@@ -31,3 +32,5 @@ print(f"B={B}: cycles per chunk, per wave (= strip)   " + " ".join(f"{n:>10s}" f
 for w in range(4):
     row = prof[w].double()[:8] / nC
     print(f"wave {w}:                         " + " ".join(f"{v:10.0f}" for v in row.tolist()) + f" {row.sum():10.0f}")
+core, ref = prof[0][10].item(), prof[0][11].item()
+print(f"core clock during the kernel: {core} cycles / {ref} ticks of the 100 MHz reference = {core / max(ref, 1) * 100:.0f} MHz   (kernel {ref / 100:.1f} us)")
