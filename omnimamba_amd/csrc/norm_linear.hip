@@ -193,6 +193,173 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_kernel(NlArgs a) {
 }
 #undef NL_ISSUE
 
+// ---------------------------------------------------------------------------------------------------------
+// The 1.3B decode configurations take this variant: every dtype and the row length are template parameters, so the
+// preamble is ONE batch of unconditional loads (x, residual, gate, norm weight, the LoRA A rows) and the row loop holds
+// nothing but weight loads -- no load or store sits under control flow, where the compiler would have to fall back to
+// s_waitcnt vmcnt(0) (the generic kernel above drains the memory pipeline 500+ times per call that way, 21 us for the
+// 70 MB in_proj against 12.8 us for the bare GEMV).  Results stay in registers (lane s keeps the s-th row of its wave)
+// until the loop is done; the LoRA B term, the bias and the store happen once per wave after it.
+//   TW: weight / activation / norm-weight / LoRA / output type, TR: residual type, In = 1024 NQ, R <= RMAX (0 or 8)
+// element i of a 16-byte weight vector kept raw in registers (converted at the multiply, not at the load: the converted
+// copy of sixteen bf16 loads would be 128 registers)
+template <class TW> __device__ __forceinline__ float raw_elem(const u32x4& v, int i);
+// (the element goes through a scalar first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+template <> __device__ __forceinline__ float raw_elem<float>(const u32x4& v, int i) { const uint32_t e = v[i]; return __builtin_bit_cast(float, e); }
+template <> __device__ __forceinline__ float raw_elem<bf16_t>(const u32x4& v, int i) {
+  const uint32_t e = v[i >> 1], b = (i & 1) ? (e & 0xffff0000u) : (e << 16);
+  return __builtin_bit_cast(float, b);
+}
+
+template <class TW, class TR, int NQ, int RMAX>
+__global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) {
+  constexpr int In = 1024 * NQ;
+  constexpr int VEC = 16 / sizeof(TW);
+  constexpr int LOADS = 16;                                   // 16-byte loads in flight per lane
+  constexpr int STEPS_ROW = In / (64 * VEC);                  // column steps of one row
+  constexpr int UNE = STEPS_ROW < 8 ? STEPS_ROW : 8;          // column steps per sweep
+  constexpr int NSW = STEPS_ROW / UNE;                        // sweeps per row (1 or 2)
+  constexpr int RW = LOADS / UNE;                             // rows per batch
+  static_assert(NSW * UNE == STEPS_ROW && NSW <= 2, "row length");
+  OMK_DYN_SMEM(smem);
+  float* sn = (float*)smem;                       // [In] u
+  float* part = sn + In;                          // [waves][8] LoRA partials
+  __shared__ float red[NL_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TW* W = (const TW*)a.W;
+  const int nwaves = gridDim.x * (NL_THREADS / 64);
+  const int wg = blockIdx.x * (NL_THREADS / 64) + wave;
+  int row0 = wg;
+  u32x4 wr[RW][UNE];
+#define NLF_ISSUE(r0_, sw_) do {                                                                     \
+    _Pragma("unroll") for (int j = 0; j < RW; j++) {                                                   \
+      const int rj_ = (r0_) + j * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                         \
+      const TW* wp_ = W + (int64_t)rc_ * a.Ws + (sw_) * (64 * VEC * UNE) + lane * VEC;                 \
+      _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
+    } } while (0)
+  NLF_ISSUE(row0, 0);
+  // ---- preamble: a thread owns the 4-column groups tid, tid + 256, ...
+  const bool hasres = a.res != nullptr, hasz = a.z != nullptr;
+  const TW* xp = (const TW*)a.x;
+  const TR* rp = hasres ? (const TR*)a.res : (const TR*)a.x;      // absent: any valid 16 bytes, the value is not used
+  const TW* zp = hasz ? (const TW*)a.z : xp;
+  float v[NQ][4], t4[NQ][4], g4[NQ][4], n4[NQ][4];
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int c = 4 * (tid + NL_THREADS * k);
+    load_vec<TW, 4>(xp + c, v[k]);
+    load_vec<TR, 4>(rp + (hasres ? c : 0), t4[k]);
+    load_vec<TW, 4>(zp + c, g4[k]);
+    load_vec<TW, 4>((const TW*)a.nw + c, n4[k]);
+  }
+  float ssq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int c = 4 * (tid + NL_THREADS * k);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[k][i] += hasres ? t4[k][i] : 0.f;
+      t4[k][i] = v[k][i];                                                      // residual_out
+      const float g = hasz ? silu_f(g4[k][i]) : 1.f;
+      const float q = (hasz && !a.nbg) ? v[k][i] * g : v[k][i];                // the quantity that is normalised
+      ssq += q * q;
+      v[k][i] = q * n4[k][i] * ((hasz && a.nbg) ? g : 1.f);
+    }
+    *reinterpret_cast<f32x4*>(&sn[c]) = f32x4{v[k][0], v[k][1], v[k][2], v[k][3]};
+  }
+  if (a.ro && blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NQ; k++) store_vec<TR, 4>((TR*)a.ro + 4 * (tid + NL_THREADS * k), t4[k]);
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  if (RMAX > 0) {
+    const TW* lap = (const TW*)a.la;
+#pragma unroll
+    for (int rb = 0; rb < RMAX; rb += 4) {       // four rows of A at a time: bounds the registers of the batch
+      float a4[4][NQ][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+          load_vec<TW, 4>(lap + (int64_t)(rb + r < a.R ? rb + r : 0) * a.las + 4 * (tid + NL_THREADS * k), a4[r][k]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float hr = 0.f;
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) hr += v[k][i] * a4[r][k][i];
+        hr = wave_sum(hr);
+        if (lane == 0) part[wave * 8 + rb + r] = rb + r < a.R ? hr : 0.f;
+      }
+    }
+  }
+  block_sync();   // u, the sums of squares and the LoRA partials are visible
+  const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)In + a.eps);
+  // this lane's slice of u, kept in registers for every row (<= 64 values)
+  float ur[NSW][UNE][VEC];
+#pragma unroll
+  for (int sw = 0; sw < NSW; sw++)
+#pragma unroll
+    for (int u = 0; u < UNE; u++)
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&sn[(sw * UNE + u) * 64 * VEC + lane * VEC + i]);
+        ur[sw][u][i] = t[0]; ur[sw][u][i + 1] = t[1]; ur[sw][u][i + 2] = t[2]; ur[sw][u][i + 3] = t[3];
+      }
+  // ---- rows: a batch = RW rows x one sweep; the next batch is requested before the current one is reduced
+  float acc[RW], keep = 0.f;
+#pragma unroll
+  for (int j = 0; j < RW; j++) acc[j] = 0.f;
+  int sw = 0, slot = 0;
+  while (row0 < a.Out) {
+#pragma unroll
+    for (int s2 = 0; s2 < NSW; s2++) {
+      if (s2 == sw) {
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+#pragma unroll
+          for (int u = 0; u < UNE; u++)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) acc[j] += raw_elem<TW>(wr[j][u], i) * ur[s2][u][i];
+      }
+    }
+    const bool row_done = sw + 1 == NSW;
+    if (row_done) { sw = 0; row0 += RW * nwaves; } else { sw++; }
+    OMK_SCHED_FENCE();   // keep the next batch's loads below the products: hoisted, they need a second register set
+    if (row0 < a.Out) NLF_ISSUE(row0, sw);
+    if (row_done) {
+#pragma unroll
+      for (int j = 0; j < RW; j++) {
+        const float vv = wave_sum(acc[j]);
+        keep = lane == slot + j ? vv : keep;
+        acc[j] = 0.f;
+      }
+      slot += RW;
+    }
+  }
+#undef NLF_ISSUE
+  // ---- lane s finishes the s-th row of this wave: LoRA B term, norm scale, bias, store
+  const int row = wg + lane * nwaves;
+  if (lane < slot && row < a.Out) {
+    float vv = keep;
+    if (RMAX > 0) {
+      const TW* lbp = (const TW*)a.lb + (int64_t)row * a.lbs;
+      float d = 0.f;
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) {
+        const float h = part[r] + part[8 + r] + part[16 + r] + part[24 + r];     // zero beyond R
+        d += to_f32(lbp[r < a.R ? r : 0]) * h;
+      }
+      vv += a.scale * d;
+    }
+    vv *= rstd;
+    if (a.bias) vv += to_f32(((const TW*)a.bias)[row]);
+    ((TW*)a.out)[row] = from_f32<TW>(vv);
+  }
+}
+
 // compute units of the current device (cached; 256 on the MI355X and under the emulator)
 static int cu_count() {
 #ifdef OMK_EMU
@@ -259,6 +426,43 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
   a.nbg = p->norm_before_gate; a.eps = p->eps; a.scale = p->lora_scale;
   const size_t smem = ((size_t)a.In + (size_t)NL_MAXR * (NL_THREADS / 64)) * 4;
   if (a.G > 8 || (a.G > 1 && a.R > 0)) return fail(OMK_EUNSUPPORTED, "norm_linear: more than 8 norm groups, or grouped norm together with LoRA");
+  // the templated variant: one dtype for x, z, norm weight, weight, LoRA, bias and out; fp32 or that dtype for the residual
+  {
+    const int xdt = p->x.dtype;
+    auto same = [&](const OmkTensor& t) { return !present(t) || t.dtype == wdt; };
+    const int nq = a.In / 1024;
+    const bool resok = (!present(p->residual) || p->residual.dtype == OMK_F32 || p->residual.dtype == wdt) &&
+                       (!present(p->residual_out) || !present(p->residual) || p->residual_out.dtype == p->residual.dtype);
+    const int trdt = present(p->residual) ? p->residual.dtype : (present(p->residual_out) ? p->residual_out.dtype : wdt);
+    const bool fast = (wdt == OMK_F32 || wdt == OMK_BF16) && xdt == wdt && same(p->z) && same(p->norm_weight) && same(p->lora_a) &&
+                      same(p->bias) && p->out.dtype == wdt && present(p->norm_weight) && a.G == 1 && a.R <= 8 && resok &&
+                      (trdt == OMK_F32 || trdt == wdt) && a.In == 1024 * nq && (nq == 1 || nq == 2 || nq == 4) &&
+                      (!present(p->lora_b) || p->lora_b.stride[1] == 1) && !getenv("OMK_NORM_LINEAR_GENERIC");
+    if (fast) {
+      const int vecw = wdt == OMK_F32 ? 4 : 8;
+      const int steps_row = a.In / (64 * vecw), une = steps_row < 8 ? steps_row : 8, rw = 16 / une;
+      // waves: every wave takes k full batches of rw rows (k as small as two workgroups per CU allow)
+      const int maxw = 2 * cu_count() * (NL_THREADS / 64);
+      const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
+      const int nw_ = (a.Out + rw * k - 1) / (rw * k);
+      if (k * rw <= 64) {
+        dim3 fgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), fblock(NL_THREADS);
+        const size_t fsmem = ((size_t)a.In + 8 * (NL_THREADS / 64)) * 4;
+#define NLF_GO(TW_, TR_, NQ_, RM_) do { \
+          if (OMK_SET_MAX_DYN_SMEM((norm_linear_fast_kernel<TW_, TR_, NQ_, RM_>), fsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", fsmem); \
+          OMK_LAUNCH((norm_linear_fast_kernel<TW_, TR_, NQ_, RM_>), fgrid, fblock, fsmem, stream, a); } while (0)
+#define NLF_R(TW_, TR_, NQ_) do { if (a.R > 0) NLF_GO(TW_, TR_, NQ_, 8); else NLF_GO(TW_, TR_, NQ_, 0); } while (0)
+#define NLF_Q(TW_, TR_) do { if (nq == 1) NLF_R(TW_, TR_, 1); else if (nq == 2) NLF_R(TW_, TR_, 2); else NLF_R(TW_, TR_, 4); } while (0)
+        if (wdt == OMK_F32) NLF_Q(float, float);
+        else if (trdt == OMK_F32) NLF_Q(bf16_t, float);
+        else NLF_Q(bf16_t, bf16_t);
+#undef NLF_Q
+#undef NLF_R
+#undef NLF_GO
+        return finish_launch("norm_linear");
+      }
+    }
+  }
   // two workgroups per CU; small matrices get one wave per row pair
   const int ncu = 2 * cu_count();
   const int want = (a.Out + 7) / 8;   // workgroups if every wave took exactly one row pair

@@ -40,6 +40,42 @@ def test_gated_norm_linear(dev, B, In, Out, G, nbg):
     assert rel(out, n0.double() @ W.double().t()) < 2e-5
 
 
+@pytest.mark.parametrize("In,Out,dtype,rdtype,with_lora,with_z", [
+    (2048, 333, torch.float32, torch.float32, True, False), (4096, 77, torch.float32, torch.float32, False, True),
+    (2048, 517, torch.bfloat16, torch.float32, True, False), (2048, 64, torch.bfloat16, torch.bfloat16, True, False),
+    (4096, 130, torch.bfloat16, torch.float32, False, True), (1024, 1000, torch.bfloat16, torch.float32, True, True)])
+def test_uniform_dtype_variant(dev, monkeypatch, In, Out, dtype, rdtype, with_lora, with_z):
+    """The templated kernel the 1.3B decode takes (one dtype for activations, weights, norm weight and LoRA; fp32 or that
+    dtype for the residual): against the fp64 composition, and against the generic kernel on the same inputs."""
+    from omnimamba_amd.norm_linear import norm_linear
+    x, res, z = torch.randn(1, In).to(dtype), torch.randn(1, In).to(rdtype), torch.randn(1, In).to(dtype)
+    nw, W, bias = (torch.rand(In) + 0.5).to(dtype), (torch.randn(Out, In) * 0.05).to(dtype), torch.randn(Out).to(dtype)
+    la, lb = (torch.randn(8, In) * 0.05).to(dtype), (torch.randn(Out, 8) * 0.05).to(dtype)
+    kw = dict(norm_weight=nw.to(dev), eps=1e-5)
+    if with_z:
+        kw.update(z=z.to(dev))
+    else:
+        kw.update(residual=res.to(dev), residual_out_dtype=rdtype)
+    if with_lora:
+        kw.update(lora_a=la.to(dev), lora_b=lb.to(dev), lora_scale=4.0)
+    r = norm_linear(x.to(dev), W.to(dev), bias.to(dev), **kw)
+    monkeypatch.setenv("OMK_NORM_LINEAR_GENERIC", "1")
+    g = norm_linear(x.to(dev), W.to(dev), bias.to(dev), **kw)
+    out, outg = (r, g) if with_z else (r[0], g[0])
+    xd = x.double()
+    if with_z:
+        q = xd * F.silu(z.double())
+    else:
+        q = xd + res.double()
+        assert torch.equal(r[1].cpu(), g[1].cpu()) and rel(r[1], q) < (1e-6 if rdtype == torch.float32 else 5e-3)
+    n0 = q * torch.rsqrt((q * q).mean() + 1e-5) * nw.double()
+    y0 = n0 @ W.double().t() + bias.double()
+    if with_lora:
+        y0 = y0 + 4.0 * (n0 @ la.double().t()) @ lb.double().t()
+    tol = 2e-5 if dtype == torch.float32 else 5e-3      # bf16: one output rounding
+    assert out.dtype == dtype and rel(out, y0) < tol and rel(out, outg.double()) < tol
+
+
 def test_residual_out_without_incoming_residual(dev):
     """First block of a stack: no residual yet, residual_out must still be x (in the requested dtype)."""
     from omnimamba_amd.norm_linear import norm_linear
