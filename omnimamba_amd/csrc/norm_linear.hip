@@ -26,6 +26,7 @@ struct NlArgs {
   void* ro; void* out;
   int64_t xs, rs, zs, ros, os, Ws, las, lbs;     // row strides (elements)
   int B, In, Out, R, G, xdt, rdt, rodt, nwdt, bdt, odt, ldt, nbg;   // G = norm groups, nbg = norm_before_gate
+  int nbatch;                                                        // templated variant: row batches per wave
   float eps, scale;
 };
 
@@ -217,10 +218,9 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
   constexpr int VEC = 16 / sizeof(TW);
   constexpr int LOADS = 16;                                   // 16-byte loads in flight per lane
   constexpr int STEPS_ROW = In / (64 * VEC);                  // column steps of one row
-  constexpr int UNE = STEPS_ROW < 8 ? STEPS_ROW : 8;          // column steps per sweep
-  constexpr int NSW = STEPS_ROW / UNE;                        // sweeps per row (1 or 2)
+  constexpr int UNE = STEPS_ROW;                              // a lane holds a whole row slice: one request per row
   constexpr int RW = LOADS / UNE;                             // rows per batch
-  static_assert(NSW * UNE == STEPS_ROW && NSW <= 2, "row length");
+  static_assert(UNE <= LOADS && RW * UNE == LOADS, "row length");
   OMK_DYN_SMEM(smem);
   float* sn = (float*)smem;                       // [In] u
   float* part = sn + In;                          // [waves][8] LoRA partials
@@ -231,13 +231,14 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
   const int wg = blockIdx.x * (NL_THREADS / 64) + wave;
   int row0 = wg;
   u32x4 wr[RW][UNE];
-#define NLF_ISSUE(r0_, sw_) do {                                                                     \
-    _Pragma("unroll") for (int j = 0; j < RW; j++) {                                                   \
-      const int rj_ = (r0_) + j * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                         \
-      const TW* wp_ = W + (int64_t)rc_ * a.Ws + (sw_) * (64 * VEC * UNE) + lane * VEC;                 \
-      _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
-    } } while (0)
-  NLF_ISSUE(row0, 0);
+  // row j of the batch that starts at row r0_ (rows past the end re-read the last row: unconditional, never used)
+#define NLF_ISSUE_ROW(r0_, j_) do {                                                                  \
+    const int rj_ = (r0_) + (j_) * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                        \
+    const TW* wp_ = W + (int64_t)rc_ * a.Ws + lane * VEC;                                              \
+    _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j_][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
+  } while (0)
+#pragma unroll
+  for (int j = 0; j < RW; j++) NLF_ISSUE_ROW(row0, j);
   // ---- preamble: a thread owns the 4-column groups tid, tid + 256, ...
   const bool hasres = a.res != nullptr, hasz = a.z != nullptr;
   const TW* xp = (const TW*)a.x;
@@ -298,48 +299,37 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
   block_sync();   // u, the sums of squares and the LoRA partials are visible
   const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)In + a.eps);
   // this lane's slice of u, kept in registers for every row (<= 64 values)
-  float ur[NSW][UNE][VEC];
+  float ur[UNE][VEC];
 #pragma unroll
-  for (int sw = 0; sw < NSW; sw++)
+  for (int u = 0; u < UNE; u++)
 #pragma unroll
-    for (int u = 0; u < UNE; u++)
-#pragma unroll
-      for (int i = 0; i < VEC; i += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(&sn[(sw * UNE + u) * 64 * VEC + lane * VEC + i]);
-        ur[sw][u][i] = t[0]; ur[sw][u][i + 1] = t[1]; ur[sw][u][i + 2] = t[2]; ur[sw][u][i + 3] = t[3];
-      }
-  // ---- rows: a batch = RW rows x one sweep; the next batch is requested before the current one is reduced
-  float acc[RW], keep = 0.f;
-#pragma unroll
-  for (int j = 0; j < RW; j++) acc[j] = 0.f;
-  int sw = 0, slot = 0;
-  while (row0 < a.Out) {
-#pragma unroll
-    for (int s2 = 0; s2 < NSW; s2++) {
-      if (s2 == sw) {
-#pragma unroll
-        for (int j = 0; j < RW; j++)
-#pragma unroll
-          for (int u = 0; u < UNE; u++)
-#pragma unroll
-            for (int i = 0; i < VEC; i++) acc[j] += raw_elem<TW>(wr[j][u], i) * ur[s2][u][i];
-      }
+    for (int i = 0; i < VEC; i += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&sn[u * 64 * VEC + lane * VEC + i]);
+      ur[u][i] = t[0]; ur[u][i + 1] = t[1]; ur[u][i + 2] = t[2]; ur[u][i + 3] = t[3];
     }
-    const bool row_done = sw + 1 == NSW;
-    if (row_done) { sw = 0; row0 += RW * nwaves; } else { sw++; }
-    OMK_SCHED_FENCE();   // keep the next batch's loads below the products: hoisted, they need a second register set
-    if (row0 < a.Out) NLF_ISSUE(row0, sw);
-    if (row_done) {
+  // ---- rows: a batch = RW rows; as soon as a row's products are done its registers take the same row of the next
+  // batch, so (RW - 1) / RW of the requests stay in flight through the reductions.  The trip count is uniform (the
+  // host sizes the grid for nbatch full batches per wave) and the loads are unconditional: the compiler counts them.
+  float keep = 0.f;
+  for (int b = 0; b < a.nbatch; b++) {
+    const int rnext = row0 + RW * nwaves;
 #pragma unroll
-      for (int j = 0; j < RW; j++) {
-        const float vv = wave_sum(acc[j]);
-        keep = lane == slot + j ? vv : keep;
-        acc[j] = 0.f;
-      }
-      slot += RW;
+    for (int j = 0; j < RW; j++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < UNE; u++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc += raw_elem<TW>(wr[j][u], i) * ur[u][i];
+      OMK_SCHED_FENCE();   // the refill stays below the products (hoisted, it would need a second register set)
+      NLF_ISSUE_ROW(rnext, j);
+      OMK_SCHED_FENCE();
+      const float vv = wave_sum(acc);
+      keep = lane == b * RW + j ? vv : keep;
     }
+    row0 = rnext;
   }
-#undef NLF_ISSUE
+  const int slot = a.nbatch * RW;
+#undef NLF_ISSUE_ROW
   // ---- lane s finishes the s-th row of this wave: LoRA B term, norm scale, bias, store
   const int row = wg + lane * nwaves;
   if (lane < slot && row < a.Out) {
@@ -440,11 +430,12 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
                       (!present(p->lora_b) || p->lora_b.stride[1] == 1) && !getenv("OMK_NORM_LINEAR_GENERIC");
     if (fast) {
       const int vecw = wdt == OMK_F32 ? 4 : 8;
-      const int steps_row = a.In / (64 * vecw), une = steps_row < 8 ? steps_row : 8, rw = 16 / une;
+      const int steps_row = a.In / (64 * vecw), rw = 16 / steps_row;   // rows per batch (16 loads of 16 bytes per lane)
       // waves: every wave takes k full batches of rw rows (k as small as two workgroups per CU allow)
       const int maxw = 2 * cu_count() * (NL_THREADS / 64);
       const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
       const int nw_ = (a.Out + rw * k - 1) / (rw * k);
+      a.nbatch = k;
       if (k * rw <= 64) {
         dim3 fgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), fblock(NL_THREADS);
         const size_t fsmem = ((size_t)a.In + 8 * (NL_THREADS / 64)) * 4;

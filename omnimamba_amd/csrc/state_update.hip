@@ -29,21 +29,35 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
   const bool live = p < a.P;
   const int pp = live ? p : a.P - 1;                 // keep every lane in the shuffles
   const int g = h / (a.H / a.G);
+  // every independent load first: the scalars of the row and (vector path, N <= LPR * VEC: one step) its state / B / C
   float dt = load_rt(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh + (int64_t)pp * a.dsp, a.dtdt);
-  if (a.dtb) dt += load_rt(a.dtb, (int64_t)h * a.tsh + (int64_t)pp * a.tsp, a.tbdt);
-  if (a.softplus) dt = softplus_f(dt);
+  const float dtbv = load_rt(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh + (int64_t)pp * a.tsp : 0, a.dtb ? a.tbdt : a.dtdt);
   const float xv = load_rt(a.x, (int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)pp * a.xsp, a.xdt);
-  const float xdt = xv * dt;
   const bool tied = a.asn == 0;
-  const float dA_t = tied ? expf(dt * load_rt(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt)) : 0.f;
+  const float Av = load_rt(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt);
   TS* s = (TS*)a.state + (int64_t)b * a.ssb + (int64_t)h * a.ssh + (int64_t)pp * a.ssp;
   const TX* Bp = (const TX*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
   const TX* Cp = (const TX*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
+  float sv0[VEC], bv0[VEC], cv0[VEC];
+  const bool one_step = VEC > 1 && a.N <= LPR * VEC;
+  if constexpr (VEC > 1) {
+    const int n0c = lr * VEC < a.N ? lr * VEC : 0;   // clamped: lanes past N re-read the row start and are not stored
+    load_vec<TS, VEC>(s + n0c, sv0); load_vec<TX, VEC>(Bp + n0c, bv0); load_vec<TX, VEC>(Cp + n0c, cv0);
+  }
+  if (a.dtb) dt += dtbv;
+  if (a.softplus) dt = softplus_f(dt);
+  const float xdt = xv * dt;
+  const float dA_t = tied ? expf(dt * Av) : 0.f;
   float acc = 0.f;
   for (int n0 = lr * VEC; n0 < a.N; n0 += LPR * VEC) {
     float sv[VEC], bv[VEC], cv[VEC];
     if constexpr (VEC > 1) {             // unit stride on n checked on the host
-      load_vec<TS, VEC>(s + n0, sv); load_vec<TX, VEC>(Bp + n0, bv); load_vec<TX, VEC>(Cp + n0, cv);
+      if (n0 == lr * VEC) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { sv[i] = sv0[i]; bv[i] = bv0[i]; cv[i] = cv0[i]; }
+      } else {
+        load_vec<TS, VEC>(s + n0, sv); load_vec<TX, VEC>(Bp + n0, bv); load_vec<TX, VEC>(Cp + n0, cv);
+      }
     } else {
       bv[0] = to_f32(Bp[(int64_t)n0 * a.bsn]); cv[0] = to_f32(Cp[(int64_t)n0 * a.csn]); sv[0] = to_f32(s[(int64_t)n0 * a.ssn]);
     }
@@ -58,6 +72,7 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
       else s[(int64_t)n0 * a.ssn] = from_f32<TS>(sv[0]);
     }
   }
+  (void)one_step;
 #pragma unroll
   for (int m = LPR / 2; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
   if (live && lr == 0) {
