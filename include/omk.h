@@ -211,10 +211,19 @@ typedef struct {
   OmkTensor lora_b;        /* optional (out, r) */
   OmkTensor residual_out;  /* optional out (B, in): x + residual */
   OmkTensor out;           /* out (B, out) */
+  /* optional tail for the in_proj call of Mamba2.step: output rows [conv_offset, conv_offset + C) are the new xBC inputs;
+   * they are pushed through causal_conv1d_update (+ SiLU) right where they are produced -- out holds the convolved
+   * values, conv_state (B, C, S) is rolled in place -- so the step needs no separate convolution launch.  Only taken by
+   * the uniform-dtype kernel (all of x / weight / conv tensors one dtype); otherwise OMK_EUNSUPPORTED. */
+  OmkTensor conv_state;    /* optional (B, C, S), S = W-1 .. 4, in place */
+  OmkTensor conv_weight;   /* (C, W), W = 2 .. 4 */
+  OmkTensor conv_bias;     /* optional (C) */
   int64_t group_size;      /* norm group size (0 = in) */
+  int64_t conv_offset;
   float eps;
   float lora_scale;
   int32_t norm_before_gate;
+  int32_t conv_silu;
 } OmkNormLinear;
 int omk_norm_linear(const OmkNormLinear* p, omk_stream stream);
 

@@ -67,8 +67,9 @@ SelScanBwd = _S("OmkSelScanBwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm
                                                     "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")] + _ws
                 + [("delta_softplus", _i)])
 NormLinear = _S("OmkNormLinear", [(n, _t) for n in ("x", "residual", "z", "norm_weight", "weight", "bias", "lora_a", "lora_b",
-                                                    "residual_out", "out")]
-                + [("group_size", C.c_int64), ("eps", _f), ("lora_scale", _f), ("norm_before_gate", _i)])
+                                                    "residual_out", "out", "conv_state", "conv_weight", "conv_bias")]
+                + [("group_size", C.c_int64), ("conv_offset", C.c_int64), ("eps", _f), ("lora_scale", _f),
+                   ("norm_before_gate", _i), ("conv_silu", _i)])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])

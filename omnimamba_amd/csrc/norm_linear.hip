@@ -27,6 +27,7 @@ struct NlArgs {
   int64_t xs, rs, zs, ros, os, Ws, las, lbs;     // row strides (elements)
   int B, In, Out, R, G, xdt, rdt, rodt, nwdt, bdt, odt, ldt, nbg;   // G = norm groups, nbg = norm_before_gate
   int nbatch;                                                        // templated variant: row batches per wave
+  void* cst; const void* ccw; const void* ccb; int64_t csc, csl, ccws; int cc0, cc1, cS, cW, csilu;   // conv tail (see omk.h)
   float eps, scale;
 };
 
@@ -346,6 +347,25 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
     }
     vv *= rstd;
     if (a.bias) vv += to_f32(((const TW*)a.bias)[row]);
+    if (a.cst && row >= a.cc0 && row < a.cc1) {
+      // this row is a new xBC input: causal_conv1d_update for its channel, right here (no other lane touches it)
+      const int ch = row - a.cc0;
+      TW* cs = (TW*)a.cst + (int64_t)ch * a.csc;
+      const TW* wr_ = (const TW*)a.ccw + (int64_t)ch * a.ccws;
+      float hist[3], wt[4];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; hist[k] = to_f32(cs[(int64_t)(sl >= 0 ? sl : 0) * a.csl]); }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); wt[k] = col >= 0 ? to_f32(wr_[col >= 0 ? col : 0]) : 0.f; }
+      const float xin = to_f32(from_f32<TW>(vv));            // the value upstream would have stored in zxbcdt
+      float cv = (a.ccb ? to_f32(((const TW*)a.ccb)[ch]) : 0.f) + wt[0] * hist[0] + wt[1] * hist[1] + wt[2] * hist[2] + wt[3] * xin;
+      for (int sl = 0; sl + 1 < a.cS; sl++) {                 // roll: slot sl <- slot sl + 1 = hist[sl + 1 - (S - 3)]
+        const int k = sl + 1 - (a.cS - 3);
+        cs[(int64_t)sl * a.csl] = from_f32<TW>(k == 0 ? hist[0] : (k == 1 ? hist[1] : hist[2]));
+      }
+      cs[(int64_t)(a.cS - 1) * a.csl] = from_f32<TW>(xin);
+      vv = a.csilu ? silu_f(cv) : cv;
+    }
     ((TW*)a.out)[row] = from_f32<TW>(vv);
   }
 }
@@ -428,6 +448,18 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
                       same(p->bias) && p->out.dtype == wdt && present(p->norm_weight) && a.G == 1 && a.R <= 8 && resok &&
                       (trdt == OMK_F32 || trdt == wdt) && a.In == 1024 * nq && (nq == 1 || nq == 2 || nq == 4) &&
                       (!present(p->lora_b) || p->lora_b.stride[1] == 1) && !getenv("OMK_NORM_LINEAR_GENERIC");
+    if (present(p->conv_state)) {
+      OMK_REQUIRE(present(p->conv_weight) && p->conv_state.ndim == 3 && p->conv_weight.ndim == 2, "norm_linear: conv_state (B, C, S) needs conv_weight (C, W)");
+      const int64_t Cc = p->conv_state.shape[1];
+      a.cS = (int)p->conv_state.shape[2]; a.cW = (int)p->conv_weight.shape[1];
+      OMK_REQUIRE(p->conv_weight.shape[0] == Cc && p->conv_offset >= 0 && p->conv_offset + Cc <= a.Out, "norm_linear: conv channels must be rows [conv_offset, conv_offset + C) of the output");
+      const bool cok = fast && a.cW >= 2 && a.cW <= 4 && a.cS >= a.cW - 1 && a.cS <= 4 && p->conv_state.dtype == wdt && p->conv_weight.dtype == wdt &&
+                       p->conv_weight.stride[1] == 1 && (!present(p->conv_bias) || (p->conv_bias.dtype == wdt && is_contig_last(p->conv_bias) && numel(p->conv_bias) == Cc));
+      if (!cok) return fail(OMK_EUNSUPPORTED, "norm_linear: the conv tail needs the uniform-dtype kernel (W 2..4, state length W-1..4)");
+      a.cst = p->conv_state.data; a.ccw = p->conv_weight.data; a.ccb = p->conv_bias.data;
+      a.csc = p->conv_state.stride[1]; a.csl = p->conv_state.stride[2]; a.ccws = p->conv_weight.stride[0];
+      a.cc0 = (int)p->conv_offset; a.cc1 = (int)(p->conv_offset + Cc); a.csilu = p->conv_silu;
+    }
     if (fast) {
       const int vecw = wdt == OMK_F32 ? 4 : 8;
       const int steps_row = a.In / (64 * vecw), rw = 16 / steps_row;   // rows per batch (16 loads of 16 bytes per lane)
@@ -454,6 +486,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       }
     }
   }
+  if (present(p->conv_state)) return fail(OMK_EUNSUPPORTED, "norm_linear: the conv tail needs the uniform-dtype kernel");
   // two workgroups per CU; small matrices get one wave per row pair
   const int ncu = 2 * cu_count();
   const int want = (a.Out + 7) / 8;   // workgroups if every wave took exactly one row pair

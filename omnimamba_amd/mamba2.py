@@ -174,13 +174,15 @@ class Mamba2(nn.Module):
         zxbcdt = self.in_proj(hidden_states.squeeze(1))
         return self.step_from_zxbcdt(zxbcdt, conv_state, ssm_state).unsqueeze(1), conv_state, ssm_state
 
-    def step_from_zxbcdt(self, zxbcdt, conv_state, ssm_state):
+    def step_from_zxbcdt(self, zxbcdt, conv_state, ssm_state, conv_done=False):
         """The decode step after in_proj: zxbcdt (batch, d_in_proj) -> out (batch, d_model).  Split out so that callers
-        which fuse the block's pre-norm into the in_proj GEMV (stack.ResidualBlock) can enter here."""
+        which fuse the block's pre-norm into the in_proj GEMV (stack.ResidualBlock) can enter here; conv_done: the xBC
+        columns already went through the convolution update (norm_linear's conv tail)."""
         d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * self.ngroups * self.d_state - self.nheads) // 2
         z0, x0, z, xBC, dt = torch.split(
             zxbcdt, [d_mlp, d_mlp, self.d_ssm, self.d_ssm + 2 * self.ngroups * self.d_state, self.nheads], dim=-1)
-        xBC = causal_conv1d_update(xBC, conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        if not conv_done:
+            xBC = causal_conv1d_update(xBC, conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
         x, B, C = torch.split(xBC, [self.d_ssm, self.ngroups * self.d_state, self.ngroups * self.d_state], dim=-1)
         A = self._A_inference()
         H, P, N = self.nheads, self.headdim, self.d_state

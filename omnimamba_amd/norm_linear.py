@@ -26,12 +26,26 @@ def applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and weight.stride(0) % vec == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
+def conv_tail_applies(x, weight, norm_weight, conv_state, conv_weight, conv_bias, lora_a=None, bias=None, residual=None) -> bool:
+    """Whether `norm_linear(..., conv_state=...)` is served (the uniform-dtype kernel: fp32 or bf16 everywhere)."""
+    dt = weight.dtype
+    same = lambda t: t is None or t.dtype == dt
+    W, S = conv_weight.shape[-1], conv_state.shape[-1]
+    return (dt in (torch.float32, torch.bfloat16) and x.dtype == dt and norm_weight is not None and same(norm_weight) and same(lora_a)
+            and same(bias) and same(conv_bias) and conv_state.dtype == dt and conv_weight.dtype == dt
+            and (residual is None or residual.dtype in (torch.float32, dt)) and weight.shape[1] in (1024, 2048, 4096)
+            and 2 <= W <= 4 and W - 1 <= S <= 4 and (lora_a is None or lora_a.shape[0] <= 8))
+
+
 def norm_linear(x, weight, bias=None, *, norm_weight=None, eps=1e-5, residual=None, residual_out_dtype=None, z=None,
-                group_size=None, norm_before_gate=False, lora_a=None, lora_b=None, lora_scale=0.0, out_dtype=None):
+                group_size=None, norm_before_gate=False, lora_a=None, lora_b=None, lora_scale=0.0, out_dtype=None,
+                conv_state=None, conv_weight=None, conv_bias=None, conv_offset=0, conv_silu=True):
     """out = norm(x [+ residual] | gated by z) @ weight^T [+ bias] [+ lora_scale * (n @ lora_a^T) @ lora_b^T].
-    x: (B, in).  Returns out, or (out, residual_out) when `residual_out_dtype` is given (residual_out = x + residual)."""
+    x: (B, in).  Returns out, or (out, residual_out) when `residual_out_dtype` is given (residual_out = x + residual).
+    conv_state (B, C, S) + conv_weight (C, W): output columns [conv_offset, conv_offset + C) additionally go through
+    causal_conv1d_update (+ SiLU): out holds the convolved values and conv_state is rolled in place."""
     lib = get_lib()
-    require_device(lib, x, weight, bias, norm_weight, residual, z, lora_a, lora_b)
+    require_device(lib, x, weight, bias, norm_weight, residual, z, lora_a, lora_b, conv_state, conv_weight, conv_bias)
     if x.stride(-1) != 1:
         x = x.contiguous()
     if z is not None and (z.dtype != x.dtype or z.stride(-1) != 1):
@@ -41,7 +55,8 @@ def norm_linear(x, weight, bias=None, *, norm_weight=None, eps=1e-5, residual=No
     ro = None if residual_out_dtype is None else torch.empty(B, x.shape[1], dtype=residual_out_dtype, device=x.device)
     p = K.NormLinear(x=K.T(x), residual=K.T(residual), z=K.T(z), norm_weight=K.T(norm_weight), weight=K.T(weight), bias=K.T(bias),
                      lora_a=K.T(lora_a), lora_b=K.T(lora_b), residual_out=K.T(ro), out=K.T(out),
-                     group_size=0 if group_size is None else int(group_size), eps=float(eps), lora_scale=float(lora_scale),
-                     norm_before_gate=int(bool(norm_before_gate)))
+                     conv_state=K.T(conv_state), conv_weight=K.T(conv_weight), conv_bias=K.T(conv_bias),
+                     group_size=0 if group_size is None else int(group_size), conv_offset=int(conv_offset), eps=float(eps),
+                     lora_scale=float(lora_scale), norm_before_gate=int(bool(norm_before_gate)), conv_silu=int(bool(conv_silu)))
     K.run(lib, "omk_norm_linear", p, x)
     return out if ro is None else (out, ro)

@@ -9,6 +9,7 @@ State-dict keys of the mixer/norm parts match the reference (`backbone.layers.{i
 """
 from __future__ import annotations
 
+import os
 import math
 from collections import namedtuple
 from dataclasses import dataclass, field
@@ -125,10 +126,18 @@ class ResidualBlock(nn.Module):
         elif type(ip) is not nn.Linear:
             return None
         ro_dtype = torch.float32 if (self.residual_in_fp32 or (residual is not None and residual.dtype == torch.float32)) else x2.dtype
-        zxbcdt, new_res = NL.norm_linear(x2, ip.weight, ip.bias, norm_weight=self.norm.weight, eps=self.norm.eps,
-                                         residual=None if residual is None else residual.squeeze(1), residual_out_dtype=ro_dtype, **lora)
         conv_state, ssm_state = self.mixer._get_states_from_cache(inference_params, x2.shape[0])
-        out = self.mixer.step_from_zxbcdt(zxbcdt, conv_state, ssm_state)
+        res2 = None if residual is None else residual.squeeze(1)
+        m, conv = self.mixer, {}
+        cw = m.conv1d.weight.squeeze(1)
+        d_mlp = (ip.weight.shape[0] - 2 * m.d_ssm - 2 * m.ngroups * m.d_state - m.nheads) // 2
+        if (m.activation in ("silu", "swish") and os.environ.get("OMK_DECODE_CONV_SEPARATE") != "1"
+                and NL.conv_tail_applies(x2, ip.weight, self.norm.weight, conv_state, cw, m.conv1d.bias, lora.get("lora_a"), ip.bias, res2)):
+            # the convolution of the new xBC inputs rides on the in_proj launch (one launch less per layer-step)
+            conv = dict(conv_state=conv_state, conv_weight=cw, conv_bias=m.conv1d.bias, conv_offset=2 * d_mlp + m.d_ssm)
+        zxbcdt, new_res = NL.norm_linear(x2, ip.weight, ip.bias, norm_weight=self.norm.weight, eps=self.norm.eps,
+                                         residual=res2, residual_out_dtype=ro_dtype, **lora, **conv)
+        out = self.mixer.step_from_zxbcdt(zxbcdt, conv_state, ssm_state, conv_done=bool(conv))
         return out.unsqueeze(1), new_res.unsqueeze(1)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):

@@ -76,6 +76,31 @@ def test_uniform_dtype_variant(dev, monkeypatch, In, Out, dtype, rdtype, with_lo
     assert out.dtype == dtype and rel(out, y0) < tol and rel(out, outg.double()) < tol
 
 
+@pytest.mark.parametrize("dtype,W,S", [(torch.float32, 4, 4), (torch.bfloat16, 4, 4), (torch.float32, 3, 3), (torch.float32, 2, 1), (torch.bfloat16, 4, 3)])
+def test_conv_tail(dev, dtype, W, S):
+    """in_proj of Mamba2.step with the convolution update riding on it: output columns [off, off + C) = silu(conv) of the
+    projected values, conv_state rolled in place -- three consecutive steps against projection + causal_conv1d_update_ref."""
+    from omnimamba_amd.norm_linear import norm_linear, conv_tail_applies
+    In, Out, C, off = 1024, 200, 120, 48
+    nw, Wt = (torch.rand(In) + 0.5).to(dtype), (torch.randn(Out, In) * 0.05).to(dtype)
+    cw, cb = (torch.randn(C, W) * 0.5).to(dtype), (torch.randn(C) * 0.2).to(dtype)
+    cst = torch.randn(1, S, C).to(dtype).transpose(1, 2)             # channel-contiguous like the module's cache
+    cst_d = cst.transpose(1, 2).contiguous().to(dev).transpose(1, 2)
+    cst0 = cst.clone()
+    for step in range(3):
+        x, res = torch.randn(1, In).to(dtype), torch.randn(1, In)
+        assert conv_tail_applies(x, Wt, nw, cst_d, cw, cb, residual=res)
+        out, ro = norm_linear(x.to(dev), Wt.to(dev), None, norm_weight=nw.to(dev), eps=1e-5, residual=res.to(dev), residual_out_dtype=torch.float32,
+                              conv_state=cst_d, conv_weight=cw.to(dev), conv_bias=cb.to(dev), conv_offset=off)
+        q = x.double() + res.double()
+        y0 = ((q * torch.rsqrt((q * q).mean() + 1e-5) * nw.double()) @ Wt.double().t()).to(dtype)     # zxbcdt as upstream stores it
+        y0c = y0.clone()
+        y0c[:, off:off + C] = O.causal_conv1d_update_ref(y0[:, off:off + C], cst0, cw, cb, activation="silu")
+        tol = 3e-5 if dtype == torch.float32 else 1e-2
+        assert rel(out, y0c.double()) < tol, step
+        assert rel(cst_d, cst0.double()) < (1e-6 if dtype == torch.float32 else 6e-3), step   # bf16: the stored input may round differently by an ulp
+
+
 def test_residual_out_without_incoming_residual(dev):
     """First block of a stack: no residual yet, residual_out must still be x (in the requested dtype)."""
     from omnimamba_amd.norm_linear import norm_linear
