@@ -27,7 +27,7 @@ struct NlArgs {
   int64_t xs, rs, zs, ros, os, Ws, las, lbs;     // row strides (elements)
   int B, In, Out, R, G, xdt, rdt, rodt, nwdt, bdt, odt, ldt, nbg;   // G = norm groups, nbg = norm_before_gate
   int nbatch;                                                        // templated variant: row batches per wave
-  void* cst; const void* ccw; const void* ccb; int64_t csc, csl, ccws; int cc0, cc1, cS, cW, csilu;   // conv tail (see omk.h)
+  void* cst; const void* ccw; const void* ccb; int64_t csb, csc, csl, ccws; int cc0, cc1, cS, cW, csilu;   // conv tail (see omk.h)
   float eps, scale;
 };
 
@@ -370,6 +370,210 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two to eight sequences per step: the same stream of W, every 16-byte weight vector multiplied against the NB
+// activation rows while it sits in registers (the separate ops re-stream W per GEMM and per LoRA factor and spend 11
+// launches: 4.6 ms per step at batch 8 against 1.8 ms at batch 1).  Differences to the batch-1 kernel: u lives in LDS
+// ([NB][In], fp32 for fp32 weights, bf16 -- upstream's own rounding point -- for bf16 weights) and is re-read per batch
+// of rows; the preamble walks the sequences in groups that fit the registers; NB accumulators per row.
+template <class TW> struct lds_u { using type = float; };
+template <> struct lds_u<bf16_t> { using type = bf16_t; };
+
+template <class TW, class TR, int NQ, int RMAX, int NB>
+__global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs a) {
+  using TU = typename lds_u<TW>::type;
+  constexpr int In = 1024 * NQ;
+  constexpr int VEC = 16 / sizeof(TW);
+  constexpr int LOADS = 16;
+  constexpr int UNE = In / (64 * VEC);
+  constexpr int RW = LOADS / UNE;
+  constexpr int CB = (8 / NQ) < NB ? (8 / NQ) : NB;           // sequences per preamble group
+  static_assert(UNE <= LOADS && RW * UNE == LOADS && NB % CB == 0, "row length");
+  OMK_DYN_SMEM(smem);
+  TU* sn = (TU*)smem;                                         // [NB][In] u
+  float* part = (float*)(smem + (size_t)NB * In * sizeof(TU));   // [waves][NB][8] LoRA partials
+  float* red = part + (NL_THREADS / 64) * NB * 8;             // [waves][NB] sums of squares
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TW* W = (const TW*)a.W;
+  const int nwaves = gridDim.x * (NL_THREADS / 64);
+  const int wg = blockIdx.x * (NL_THREADS / 64) + wave;
+  int row0 = wg;
+  u32x4 wr[RW][UNE];
+#define NLB_ISSUE(r0_) do {                                                                          \
+    _Pragma("unroll") for (int j = 0; j < RW; j++) {                                                   \
+      const int rj_ = (r0_) + j * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                         \
+      const TW* wp_ = W + (int64_t)rc_ * a.Ws + lane * VEC;                                            \
+      _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
+    } } while (0)
+  NLB_ISSUE(row0);
+  // ---- preamble, CB sequences at a time (sequences past B repeat the last one; nothing of theirs is stored)
+  const bool hasres = a.res != nullptr, hasz = a.z != nullptr;
+  float n4[NQ][4];
+#pragma unroll
+  for (int k = 0; k < NQ; k++) load_vec<TW, 4>((const TW*)a.nw + 4 * (tid + NL_THREADS * k), n4[k]);
+#pragma unroll
+  for (int b0 = 0; b0 < NB; b0 += CB) {
+    float v[CB][NQ][4], t4[CB][NQ][4], g4[CB][NQ][4];
+#pragma unroll
+    for (int bb = 0; bb < CB; bb++) {
+      const int b = b0 + bb < a.B ? b0 + bb : a.B - 1;
+      const TW* xp = (const TW*)a.x + (int64_t)b * a.xs;
+      const TR* rp = hasres ? (const TR*)a.res + (int64_t)b * a.rs : (const TR*)xp;
+      const TW* zp = hasz ? (const TW*)a.z + (int64_t)b * a.zs : xp;
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int c = 4 * (tid + NL_THREADS * k);
+        load_vec<TW, 4>(xp + c, v[bb][k]);
+        load_vec<TR, 4>(rp + (hasres ? c : 0), t4[bb][k]);
+        load_vec<TW, 4>(zp + c, g4[bb][k]);
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < CB; bb++) {
+      float ssq = 0.f;
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int c = 4 * (tid + NL_THREADS * k);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          v[bb][k][i] += hasres ? t4[bb][k][i] : 0.f;
+          t4[bb][k][i] = v[bb][k][i];
+          const float g = hasz ? silu_f(g4[bb][k][i]) : 1.f;
+          const float q = (hasz && !a.nbg) ? v[bb][k][i] * g : v[bb][k][i];
+          ssq += q * q;
+          v[bb][k][i] = q * n4[k][i] * ((hasz && a.nbg) ? g : 1.f);
+        }
+        store_vec<TU, 4>(sn + (size_t)(b0 + bb) * In + c, v[bb][k]);
+        if (sizeof(TU) == 2) {   // the LoRA input is the same rounded u the rows multiply
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[bb][k][i] = to_f32(from_f32<TU>(v[bb][k][i]));
+        }
+      }
+      if (a.ro && blockIdx.x == 0 && b0 + bb < a.B) {
+#pragma unroll
+        for (int k = 0; k < NQ; k++) store_vec<TR, 4>((TR*)a.ro + (int64_t)(b0 + bb) * a.ros + 4 * (tid + NL_THREADS * k), t4[bb][k]);
+      }
+      ssq = wave_sum(ssq);
+      if (lane == 0) red[wave * NB + b0 + bb] = ssq;
+    }
+    if constexpr (RMAX > 0) {
+      const TW* lap = (const TW*)a.la;
+#pragma unroll
+      for (int rb = 0; rb < RMAX; rb += 4) {
+        float a4[4][NQ][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int k = 0; k < NQ; k++)
+            load_vec<TW, 4>(lap + (int64_t)(rb + r < a.R ? rb + r : 0) * a.las + 4 * (tid + NL_THREADS * k), a4[r][k]);
+#pragma unroll
+        for (int bb = 0; bb < CB; bb++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float hr = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; k++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) hr += v[bb][k][i] * a4[r][k][i];
+            hr = wave_sum(hr);
+            if (lane == 0) part[(wave * NB + b0 + bb) * 8 + rb + r] = rb + r < a.R ? hr : 0.f;
+          }
+      }
+    }
+  }
+  block_sync();
+  // ---- rows: every weight vector meets the NB activation rows while it is in registers
+  float keep[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) keep[b] = 0.f;
+  for (int bi = 0; bi < a.nbatch; bi++) {
+    float acc[RW][NB];
+#pragma unroll
+    for (int j = 0; j < RW; j++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) acc[j][b] = 0.f;
+#pragma unroll
+    for (int u = 0; u < UNE; u++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        float uv[VEC];
+        load_vec<TU, VEC>(sn + (size_t)b * In + u * 64 * VEC + lane * VEC, uv);
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+#pragma unroll
+          for (int i = 0; i < VEC; i++) acc[j][b] += raw_elem<TW>(wr[j][u], i) * uv[i];
+      }
+    row0 += RW * nwaves;
+    OMK_SCHED_FENCE();
+    NLB_ISSUE(row0);
+    OMK_SCHED_FENCE();
+#pragma unroll
+    for (int j = 0; j < RW; j++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const float vv = wave_sum(acc[j][b]);
+        keep[b] = lane == bi * RW + j ? vv : keep[b];
+      }
+  }
+#undef NLB_ISSUE
+  const int slot = a.nbatch * RW;
+  const int row = wg + lane * nwaves;
+  if (lane < slot && row < a.Out) {
+    float lbv[RMAX > 0 ? RMAX : 1];
+    if (RMAX > 0) {
+      const TW* lbp = (const TW*)a.lb + (int64_t)row * a.lbs;
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) lbv[r] = to_f32(lbp[r < a.R ? r : 0]);
+    }
+    const float bias = a.bias ? to_f32(((const TW*)a.bias)[row]) : 0.f;
+    const bool isconv = a.cst && row >= a.cc0 && row < a.cc1;
+    float wt[4] = {0.f, 0.f, 0.f, 0.f}, cbias = 0.f;
+    const int ch = row - a.cc0;
+    if (isconv) {
+      const TW* wr_ = (const TW*)a.ccw + (int64_t)ch * a.ccws;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); wt[k] = col >= 0 ? to_f32(wr_[col >= 0 ? col : 0]) : 0.f; }
+      cbias = a.ccb ? to_f32(((const TW*)a.ccb)[ch]) : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b < a.B) {
+        float vv = keep[b];
+        if (RMAX > 0) {
+          float d = 0.f;
+#pragma unroll
+          for (int r = 0; r < RMAX; r++) {
+            float h = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NL_THREADS / 64; w2++) h += part[(w2 * NB + b) * 8 + r];
+            d += lbv[r] * h;
+          }
+          vv += a.scale * d;
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NL_THREADS / 64; w2++) ss += red[w2 * NB + b];
+        vv = vv * rsqrtf(ss / (float)In + a.eps) + bias;
+        if (isconv) {
+          TW* cs = (TW*)a.cst + (int64_t)b * a.csb + (int64_t)ch * a.csc;
+          float hist[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; hist[k] = to_f32(cs[(int64_t)(sl >= 0 ? sl : 0) * a.csl]); }
+          const float xin = to_f32(from_f32<TW>(vv));
+          const float cv = cbias + wt[0] * hist[0] + wt[1] * hist[1] + wt[2] * hist[2] + wt[3] * xin;
+          for (int sl = 0; sl + 1 < a.cS; sl++) {
+            const int k = sl + 1 - (a.cS - 3);
+            cs[(int64_t)sl * a.csl] = from_f32<TW>(k == 0 ? hist[0] : (k == 1 ? hist[1] : hist[2]));
+          }
+          cs[(int64_t)(a.cS - 1) * a.csl] = from_f32<TW>(xin);
+          vv = a.csilu ? silu_f(cv) : cv;
+        }
+        ((TW*)a.out)[(int64_t)b * a.os + row] = from_f32<TW>(vv);
+      }
+    }
+  }
+}
+
 // compute units of the current device (cached; 256 on the MI355X and under the emulator)
 static int cu_count() {
 #ifdef OMK_EMU
@@ -399,7 +603,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
   if (a.B == 0 || a.Out == 0) return OMK_OK;
   // one sequence per call: with more, the per-batch preamble state and the double register set of the pipelined row loop
   // no longer fit (the kernel template takes NB, the launcher only instantiates 1); callers use the separate ops instead
-  if (a.B > 1) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d > 1 is served by the unfused ops", a.B);
+  if (a.B > 8) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d > 8 is served by the unfused ops", a.B);
   const int wdt = p->weight.dtype;
   const int vec = wdt == OMK_F32 ? 4 : 8;
   if (a.In % 1024 != 0 || a.In > 8192 || !aligned16(p->weight) || p->weight.stride[0] % vec != 0)
@@ -452,14 +656,44 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       OMK_REQUIRE(present(p->conv_weight) && p->conv_state.ndim == 3 && p->conv_weight.ndim == 2, "norm_linear: conv_state (B, C, S) needs conv_weight (C, W)");
       const int64_t Cc = p->conv_state.shape[1];
       a.cS = (int)p->conv_state.shape[2]; a.cW = (int)p->conv_weight.shape[1];
+      OMK_REQUIRE(p->conv_state.shape[0] == a.B, "norm_linear: conv_state batch");
       OMK_REQUIRE(p->conv_weight.shape[0] == Cc && p->conv_offset >= 0 && p->conv_offset + Cc <= a.Out, "norm_linear: conv channels must be rows [conv_offset, conv_offset + C) of the output");
       const bool cok = fast && a.cW >= 2 && a.cW <= 4 && a.cS >= a.cW - 1 && a.cS <= 4 && p->conv_state.dtype == wdt && p->conv_weight.dtype == wdt &&
                        p->conv_weight.stride[1] == 1 && (!present(p->conv_bias) || (p->conv_bias.dtype == wdt && is_contig_last(p->conv_bias) && numel(p->conv_bias) == Cc));
       if (!cok) return fail(OMK_EUNSUPPORTED, "norm_linear: the conv tail needs the uniform-dtype kernel (W 2..4, state length W-1..4)");
       a.cst = p->conv_state.data; a.ccw = p->conv_weight.data; a.ccb = p->conv_bias.data;
-      a.csc = p->conv_state.stride[1]; a.csl = p->conv_state.stride[2]; a.ccws = p->conv_weight.stride[0];
+      a.csb = p->conv_state.stride[0]; a.csc = p->conv_state.stride[1]; a.csl = p->conv_state.stride[2]; a.ccws = p->conv_weight.stride[0];
       a.cc0 = (int)p->conv_offset; a.cc1 = (int)(p->conv_offset + Cc); a.csilu = p->conv_silu;
     }
+    if (fast && a.B > 1) {
+      // two to eight sequences: u for all of them in LDS; one workgroup per CU when that takes more than half of it
+      const int nb = a.B <= 2 ? 2 : (a.B <= 4 ? 4 : 8);
+      const int vecw = wdt == OMK_F32 ? 4 : 8, steps_row = a.In / (64 * vecw), rw = 16 / steps_row;
+      const size_t bsmem = (size_t)nb * a.In * (wdt == OMK_F32 ? 4 : 2) + (size_t)(NL_THREADS / 64) * nb * 9 * 4;
+      if (bsmem > 150 * 1024) return fail(OMK_EUNSUPPORTED, "norm_linear: %d sequences x %d features do not fit the LDS", a.B, a.In);
+      const int wg_per_cu = bsmem <= 76 * 1024 ? 2 : 1;
+      const int maxw = wg_per_cu * cu_count() * (NL_THREADS / 64);
+      const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
+      const int nw_ = (a.Out + rw * k - 1) / (rw * k);
+      a.nbatch = k;
+      if (k * rw > 64) return fail(OMK_EUNSUPPORTED, "norm_linear: %d output rows are too many for the batched kernel", a.Out);
+      dim3 bgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), bblock(NL_THREADS);
+#define NLB_GO(TW_, TR_, NQ_, RM_, NB_) do { \
+        if (OMK_SET_MAX_DYN_SMEM((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_>), bsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", bsmem); \
+        OMK_LAUNCH((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_>), bgrid, bblock, bsmem, stream, a); } while (0)
+#define NLB_B(TW_, TR_, NQ_, RM_) do { if (nb == 2) NLB_GO(TW_, TR_, NQ_, RM_, 2); else if (nb == 4) NLB_GO(TW_, TR_, NQ_, RM_, 4); else NLB_GO(TW_, TR_, NQ_, RM_, 8); } while (0)
+#define NLB_R(TW_, TR_, NQ_) do { if (a.R > 0) NLB_B(TW_, TR_, NQ_, 8); else NLB_B(TW_, TR_, NQ_, 0); } while (0)
+#define NLB_Q(TW_, TR_) do { if (nq == 1) NLB_R(TW_, TR_, 1); else if (nq == 2) NLB_R(TW_, TR_, 2); else NLB_R(TW_, TR_, 4); } while (0)
+      if (wdt == OMK_F32) NLB_Q(float, float);
+      else if (trdt == OMK_F32) NLB_Q(bf16_t, float);
+      else NLB_Q(bf16_t, bf16_t);
+#undef NLB_Q
+#undef NLB_R
+#undef NLB_B
+#undef NLB_GO
+      return finish_launch("norm_linear");
+    }
+    if (a.B > 1) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d needs the uniform-dtype kernel (one dtype, in_features 1024 / 2048 / 4096)", a.B);
     if (fast) {
       const int vecw = wdt == OMK_F32 ? 4 : 8;
       const int steps_row = a.In / (64 * vecw), rw = 16 / steps_row;   // rows per batch (16 loads of 16 bytes per lane)

@@ -197,7 +197,7 @@ class Mamba2(nn.Module):
                                    dt_bias=dt_bias_e, dt_softplus=True)
         y = y.reshape(batch, H * P)
         if (self.rmsnorm and d_mlp == 0 and type(self.out_proj) is nn.Linear and self.norm.bias is None
-                and NL.applies(y, self.out_proj.weight)):
+                and NL.applies(y, self.out_proj.weight, self.norm.weight, z, self.out_proj.bias)):
             # gated RMSNorm + out_proj in one launch (weights streamed once)
             return NL.norm_linear(y, self.out_proj.weight, self.out_proj.bias, norm_weight=self.norm.weight, eps=self.norm.eps,
                                   z=z, group_size=self.norm.group_size, norm_before_gate=self.norm.norm_before_gate)

@@ -12,18 +12,30 @@ import torch
 from . import _capi as K
 from ._lib import get_lib, require_device
 
-MAX_BATCH = 1     # one sequence per call; larger decode batches take the separate ops
+MAX_BATCH = 8     # sequences per call; larger decode batches take the separate ops
 
 
-def applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Fused path preconditions (shape / dtype / no autograd)."""
+def _uniform(weight, *others) -> bool:
+    """The templated kernels' dtype rule: fp32 or bf16 weights, every other tensor of the same dtype."""
+    return weight.dtype in (torch.float32, torch.bfloat16) and all(t is None or t.dtype == weight.dtype for t in others)
+
+
+def applies(x: torch.Tensor, weight: torch.Tensor, norm_weight=None, *same_dtype) -> bool:
+    """Fused path preconditions (shape / dtype / no autograd).  One sequence: any supported dtype mix.  Two to eight
+    sequences: the uniform-dtype kernel only -- pass the norm weight and every tensor that must share the weight's dtype
+    (gate, LoRA factors, bias)."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         return False
-    if x.dim() != 2 or x.shape[0] > MAX_BATCH or x.shape[0] * x.shape[1] * 4 > 96 * 1024:
+    if x.dim() != 2 or x.shape[0] > MAX_BATCH or x.shape[0] == 0:
         return False
     vec = 4 if weight.dtype == torch.float32 else 8
-    return (weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 1024 == 0 and weight.shape[1] <= 8192
-            and weight.stride(0) % vec == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+    ok = (weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 1024 == 0 and weight.shape[1] <= 8192
+          and weight.stride(0) % vec == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+    if x.shape[0] == 1:
+        return ok and x.shape[1] * 4 <= 96 * 1024
+    nb = 2 if x.shape[0] <= 2 else (4 if x.shape[0] <= 4 else 8)
+    return (ok and norm_weight is not None and _uniform(weight, x, norm_weight, *same_dtype) and weight.shape[1] in (1024, 2048, 4096)
+            and nb * weight.shape[1] * weight.element_size() <= 144 * 1024 and weight.shape[0] <= 64 * 1024)
 
 
 def conv_tail_applies(x, weight, norm_weight, conv_state, conv_weight, conv_bias, lora_a=None, bias=None, residual=None) -> bool:

@@ -114,7 +114,7 @@ class ResidualBlock(nn.Module):
         rest of Mamba2.step.  Returns None when the fused kernel does not apply (training, large batch, odd shapes)."""
         ip = self.mixer.in_proj
         x2 = hidden_states.squeeze(1)
-        if self.norm.bias is not None or not isinstance(ip, nn.Linear) or not NL.applies(x2, ip.weight):
+        if self.norm.bias is not None or not isinstance(ip, nn.Linear):
             return None
         lora = {}
         if isinstance(ip, TaskLoRALinear):
@@ -124,6 +124,12 @@ class ResidualBlock(nn.Module):
                 lora = dict(lora_a=getattr(ip, f"{ip.task_types}_lora_A0").weight, lora_b=getattr(ip, f"{ip.task_types}_lora_B0").weight,
                             lora_scale=ip.scaling)
         elif type(ip) is not nn.Linear:
+            return None
+        if lora and (lora["lora_a"].shape[0] > 8 and x2.shape[0] > 1):
+            return None
+        if not NL.applies(x2, ip.weight, self.norm.weight, lora.get("lora_a"), lora.get("lora_b"), ip.bias):
+            return None
+        if x2.shape[0] > 1 and residual is not None and residual.dtype not in (torch.float32, x2.dtype):
             return None
         ro_dtype = torch.float32 if (self.residual_in_fp32 or (residual is not None and residual.dtype == torch.float32)) else x2.dtype
         conv_state, ssm_state = self.mixer._get_states_from_cache(inference_params, x2.shape[0])

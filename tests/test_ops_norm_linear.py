@@ -101,6 +101,52 @@ def test_conv_tail(dev, dtype, W, S):
         assert rel(cst_d, cst0.double()) < (1e-6 if dtype == torch.float32 else 6e-3), step   # bf16: the stored input may round differently by an ulp
 
 
+@pytest.mark.parametrize("B,In,Out,dtype,rdtype,mode", [
+    (2, 2048, 333, torch.float32, torch.float32, "lora"), (3, 2048, 200, torch.bfloat16, torch.float32, "lora+conv"),
+    (8, 2048, 517, torch.float32, torch.float32, "lora+conv"), (8, 4096, 130, torch.bfloat16, torch.bfloat16, "gate"),
+    (4, 4096, 77, torch.float32, torch.float32, "gate"), (5, 1024, 90, torch.bfloat16, torch.float32, "lora")])
+def test_batched_variant(dev, B, In, Out, dtype, rdtype, mode):
+    """Two to eight sequences per call (decode batches): every weight vector is used for all sequences while it is in
+    registers.  Against the fp64 composition per sequence; with the conv tail, two consecutive steps."""
+    from omnimamba_amd.norm_linear import norm_linear, applies
+    C, off, W, S = 64, 16, 4, 4
+    nw, Wt, bias = (torch.rand(In) + 0.5).to(dtype), (torch.randn(Out, In) * 0.05).to(dtype), torch.randn(Out).to(dtype)
+    la, lb = (torch.randn(8, In) * 0.05).to(dtype), (torch.randn(Out, 8) * 0.05).to(dtype)
+    cw, cb = (torch.randn(C, W) * 0.5).to(dtype), (torch.randn(C) * 0.2).to(dtype)
+    cst = torch.randn(B, S, C).to(dtype).transpose(1, 2)
+    cst_d, cst0 = cst.transpose(1, 2).contiguous().to(dev).transpose(1, 2), cst.clone()
+    for step in range(2 if "conv" in mode else 1):
+        x, res, z = torch.randn(B, In).to(dtype), torch.randn(B, In).to(rdtype), torch.randn(B, In).to(dtype)
+        kw = dict(norm_weight=nw.to(dev), eps=1e-5)
+        if mode == "gate":
+            kw.update(z=z.to(dev))
+            q = x.double() * F.silu(z.double())
+        else:
+            kw.update(residual=res.to(dev), residual_out_dtype=rdtype)
+            q = x.double() + res.double()
+        if "lora" in mode:
+            kw.update(lora_a=la.to(dev), lora_b=lb.to(dev), lora_scale=4.0)
+        if "conv" in mode:
+            kw.update(conv_state=cst_d, conv_weight=cw.to(dev), conv_bias=cb.to(dev), conv_offset=off)
+        assert applies(x.to(dev), Wt.to(dev), nw.to(dev), la.to(dev) if "lora" in mode else None, bias.to(dev))
+        r = norm_linear(x.to(dev), Wt.to(dev), bias.to(dev), **kw)
+        out = r if mode == "gate" else r[0]
+        n0 = q * torch.rsqrt((q * q).mean(-1, keepdim=True) + 1e-5) * nw.double()
+        if dtype == torch.bfloat16:
+            n0 = n0.to(dtype).double()                      # the batched kernel keeps u in bf16 (upstream's rounding point)
+        y0 = n0 @ Wt.double().t() + bias.double()
+        if "lora" in mode:
+            y0 = y0 + 4.0 * (n0 @ la.double().t()) @ lb.double().t()
+        if mode != "gate":
+            assert rel(r[1], q) < (1e-6 if rdtype == torch.float32 else 5e-3)
+        if "conv" in mode:
+            y0 = y0.to(dtype)
+            y0[:, off:off + C] = O.causal_conv1d_update_ref(y0[:, off:off + C].clone(), cst0, cw, cb, activation="silu")
+            assert rel(cst_d, cst0.double()) < (1e-6 if dtype == torch.float32 else 6e-3), step
+        tol = 3e-5 if dtype == torch.float32 else 1e-2
+        assert out.shape == (B, Out) and out.dtype == dtype and rel(out, y0.double()) < tol, step
+
+
 def test_residual_out_without_incoming_residual(dev):
     """First block of a stack: no residual yet, residual_out must still be x (in the requested dtype)."""
     from omnimamba_amd.norm_linear import norm_linear
@@ -116,5 +162,6 @@ def test_plain_linear_and_limits(dev):
     x, W = torch.randn(1, 1024), torch.randn(10, 1024)
     out = NL.norm_linear(x.to(dev), W.to(dev))
     assert rel(out, F.linear(x, W)) < 2e-5
-    assert NL.applies(x, W) and not NL.applies(torch.randn(2, 1024), W) and not NL.applies(torch.randn(1, 256), torch.randn(10, 256))
+    assert NL.applies(x, W) and not NL.applies(torch.randn(9, 1024), W) and not NL.applies(torch.randn(1, 256), torch.randn(10, 256))
+    assert not NL.applies(torch.randn(2, 1024), W) and NL.applies(torch.randn(2, 1024), W, torch.ones(1024))     # batches need the norm weight
     assert not NL.applies(x, W.requires_grad_())

@@ -84,8 +84,8 @@ def test_greedy_decode_trace_and_tokens(dev):
     assert torch.equal(full[:, Pn - 1:].argmax(-1).cpu(), toks.cpu())
 
 
-@pytest.mark.parametrize("task", ["t2i", "mmu"])
-def test_fused_decode_step_equals_unfused(dev, task, monkeypatch):
+@pytest.mark.parametrize("task,Bsz", [("t2i", 1), ("mmu", 1), ("t2i", 3)])
+def test_fused_decode_step_equals_unfused(dev, task, Bsz, monkeypatch):
     """The one-launch add + norm + in_proj + LoRA and gated-norm + out_proj of the decode step (omk_norm_linear) against the
     same step through the separate ops, on a stack wide enough for the fused kernel to apply (d_model 1024)."""
     from omnimamba_amd import norm_linear as NL
@@ -99,7 +99,7 @@ def test_fused_decode_step_equals_unfused(dev, task, monkeypatch):
         for blk in model.backbone.layers:       # non-trivial adapters
             for t in ("t2i", "mmu"):
                 getattr(blk.mixer.in_proj, f"{t}_lora_B0").weight.normal_(std=0.05)
-    emb = torch.randn(1, 6, cfg.d_model).to(dev)
+    emb = torch.randn(Bsz, 6, cfg.d_model).to(dev)
     calls = {"n": 0}
     real = NL.norm_linear
 
@@ -110,14 +110,14 @@ def test_fused_decode_step_equals_unfused(dev, task, monkeypatch):
     outs = []
     for fused in (True, False):
         if not fused:
-            monkeypatch.setattr(NL, "applies", lambda x, w: False)
+            monkeypatch.setattr(NL, "applies", lambda *a, **k: False)
         monkeypatch.setattr(NL, "norm_linear", counting)
-        ip = InferenceParams(max_seqlen=32, max_batch_size=1)
+        ip = InferenceParams(max_seqlen=32, max_batch_size=Bsz)
         with torch.no_grad():
             model(None, emb, task=task, inference_params=ip, num_last_tokens=1)
             ip.seqlen_offset = 6
-            ids = torch.tensor([[3]]).to(dev)
-            pos = torch.full((1, 1), 6, dtype=torch.long).to(dev)
+            ids = torch.full((Bsz, 1), 3).to(dev)
+            pos = torch.full((Bsz, 1), 6, dtype=torch.long).to(dev)
             logits = []
             for step in range(2):
                 o = model(ids, None, position_ids=pos + step, task=task, inference_params=ip, num_last_tokens=1)
