@@ -48,11 +48,18 @@ template <> __device__ __forceinline__ float from_f32<float>(float f) { return f
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return bf16_t{f32_to_bf16(f)}; }
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return f16_t{(_Float16)f}; }
 
-// runtime-dtype scalar access (parameters: a handful of loads per thread, never in the streaming loop).  The load is
-// branch-free on purpose -- one aligned dword read, the element picked with selects: a load under control flow makes
-// the compiler drain the memory pipeline (s_waitcnt vmcnt(0)) at every use, which serialises the round trips of the
-// scalar-heavy decode kernels.  (16-bit element: the aligned dword that contains it, always inside the allocation.)
+// runtime-dtype scalar access (parameters: a handful of loads per thread, never in the streaming loop)
 __device__ __forceinline__ float load_rt(const void* p, int64_t i, int dt) {
+  if (dt == OMK_F32) return ((const float*)p)[i];
+  if (dt == OMK_BF16) return bf16_to_f32(((const uint16_t*)p)[i]);
+  return (float)((const _Float16*)p)[i];
+}
+// The same without control flow -- one aligned dword read, the element picked with selects -- for kernels that are
+// nothing but a chain of such loads (the decode-step state update): a load under a branch makes the compiler drain the
+// memory pipeline at every use, which serialises the round trips.  Costs address arithmetic and registers, so the
+// streaming kernels (conv1d forward: +13 % with this variant) keep the compact one.  (16-bit element: the aligned dword
+// that contains it, always inside the allocation.)
+__device__ __forceinline__ float load_rt_flat(const void* p, int64_t i, int dt) {
   const uintptr_t addr = (uintptr_t)p + ((uintptr_t)i << (dt == OMK_F32 ? 2 : 1));
   const uint32_t w = *reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
   const uint32_t h = (addr & 2) ? (w >> 16) : (w & 0xffffu);

@@ -30,11 +30,11 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
   const int pp = live ? p : a.P - 1;                 // keep every lane in the shuffles
   const int g = h / (a.H / a.G);
   // every independent load first: the scalars of the row and (vector path, N <= LPR * VEC: one step) its state / B / C
-  float dt = load_rt(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh + (int64_t)pp * a.dsp, a.dtdt);
-  const float dtbv = load_rt(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh + (int64_t)pp * a.tsp : 0, a.dtb ? a.tbdt : a.dtdt);
-  const float xv = load_rt(a.x, (int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)pp * a.xsp, a.xdt);
+  float dt = load_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh + (int64_t)pp * a.dsp, a.dtdt);
+  const float dtbv = load_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh + (int64_t)pp * a.tsp : 0, a.dtb ? a.tbdt : a.dtdt);
+  const float xv = load_rt_flat(a.x, (int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)pp * a.xsp, a.xdt);
   const bool tied = a.asn == 0;
-  const float Av = load_rt(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt);
+  const float Av = load_rt_flat(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt);
   TS* s = (TS*)a.state + (int64_t)b * a.ssb + (int64_t)h * a.ssh + (int64_t)pp * a.ssp;
   const TX* Bp = (const TX*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
   const TX* Cp = (const TX*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
