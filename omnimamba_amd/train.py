@@ -74,7 +74,10 @@ class Stage2Step:
         self.model, self.cfg = model, cfg
         self.net = ddp_model if ddp_model is not None else model
         params = [p for p in model.parameters() if p.requires_grad]
-        self.opt = torch.optim.AdamW(params, lr=cfg.lr, betas=cfg.betas, weight_decay=cfg.weight_decay)
+        # one fused kernel per parameter chunk on the GPU: the foreach form makes ~15 passes over the 1.39 B fp32 parameters
+        # and their two moments (33 ms of a 480 ms step), the fused one a single read-modify-write
+        fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("OMK_FUSED_ADAMW", "1") != "0"
+        self.opt = torch.optim.AdamW(params, lr=cfg.lr, betas=cfg.betas, weight_decay=cfg.weight_decay, fused=fused)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: cosine_with_min_lr(s, cfg))
         self.last = {}
 
