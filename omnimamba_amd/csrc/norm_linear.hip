@@ -14,6 +14,7 @@
 // 8 (16-bit) consecutive columns per step, 16 loads of 16 bytes in flight per lane, the next pair requested before the
 // current one is reduced.  HBM-bound on W: out * in * sizeof(W) bytes per call; measured 23.6 us (in_proj + norm + LoRA,
 // 70 MB) and 12.5 us (gated norm + out_proj, 33.5 MB) per layer-step of the 1.3B model, 12.8 us for the bare in_proj GEMV.
+#include <type_traits>
 #include "omk_common.h"
 
 namespace omk {
@@ -492,17 +493,28 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
     for (int j = 0; j < RW; j++)
 #pragma unroll
       for (int b = 0; b < NB; b++) acc[j][b] = 0.f;
+    // all NB reads of a column step are issued before the first multiply: one LDS round trip per step, not one per
+    // sequence (a single wave per SIMD cannot hide them: 128 serialised reads were most of the out_proj call)
 #pragma unroll
-    for (int u = 0; u < UNE; u++)
+    for (int u = 0; u < UNE; u++) {
+      using URaw = typename std::conditional<sizeof(TU) == 4, f32x4, u32x4>::type;   // 16 bytes: VEC elements of TU
+      URaw uraw[NB];
 #pragma unroll
-      for (int b = 0; b < NB; b++) {
-        float uv[VEC];
-        load_vec<TU, VEC>(sn + (size_t)b * In + u * 64 * VEC + lane * VEC, uv);
+      for (int b = 0; b < NB; b++)
+        uraw[b] = *reinterpret_cast<const URaw*>(sn + (size_t)b * In + u * 64 * VEC + lane * VEC);
+      OMK_SCHED_FENCE();
+#pragma unroll
+      for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int j = 0; j < RW; j++)
 #pragma unroll
-          for (int i = 0; i < VEC; i++) acc[j][b] += raw_elem<TW>(wr[j][u], i) * uv[i];
-      }
+          for (int i = 0; i < VEC; i++) {
+            float uvi;
+            if constexpr (sizeof(TU) == 4) uvi = uraw[b][i];
+            else uvi = raw_elem<bf16_t>(uraw[b], i);
+            acc[j][b] += raw_elem<TW>(wr[j][u], i) * uvi;
+          }
+    }
     row0 += RW * nwaves;
     OMK_SCHED_FENCE();
     NLB_ISSUE(row0);

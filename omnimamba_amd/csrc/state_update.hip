@@ -83,6 +83,60 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
   }
 }
 
+// Mamba-2's configuration (A, dt, dt_bias tied over (p, n); one vector step per row: N == 4 LPR; unit strides), RPT rows
+// per lane group: the per-head scalars and B / C are loaded once, the RPT state vectors fly together.  With one row per
+// lane group (kernel above) a batch-8 step is 16 k waves of ten dependent-ish loads each: 17.4 us for 33.5 MB.
+template <class TS, class TX, int LPR, int RPT>
+__global__ __launch_bounds__(256) void state_update_tied_kernel(SuArgs a) {
+  constexpr int VEC = 4, RPW = 64 / LPR, RPB = RPW * 4;         // rows per workgroup and pass
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane % LPR, rw = lane / LPR;
+  const int pblocks = a.P / (RPB * RPT);                       // host: P % (RPB * RPT) == 0
+  const int pb = blockIdx.x % pblocks, h = (blockIdx.x / pblocks) % a.H, b = blockIdx.x / (pblocks * a.H);
+  const int g = h / (a.H / a.G);
+  const int p0 = pb * RPB * RPT + wave * RPW + rw, n0 = lr * VEC;
+  TS* s = (TS*)a.state + (int64_t)b * a.ssb + (int64_t)h * a.ssh + n0;
+  float sv[RPT][VEC], xv[RPT], bv[VEC], cv[VEC];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) load_vec<TS, VEC>(s + (int64_t)(p0 + k * RPB) * a.ssp, sv[k]);
+  load_vec<TX, VEC>((const TX*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + n0, bv);
+  load_vec<TX, VEC>((const TX*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + n0, cv);
+#pragma unroll
+  for (int k = 0; k < RPT; k++) xv[k] = to_f32(((const TX*)a.x)[(int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)(p0 + k * RPB) * a.xsp]);
+  float dt = load_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh, a.dtdt);
+  const float dtbv = load_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh : 0, a.dtb ? a.tbdt : a.dtdt);
+  const float Av = load_rt_flat(a.A, (int64_t)h * a.ash, a.adt);
+  if (a.dtb) dt += dtbv;
+  if (a.softplus) dt = softplus_f(dt);
+  const float dA = expf(dt * Av);
+  float acc[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    acc[k] = 0.f;
+    const float xdt = xv[k] * dt;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      sv[k][i] = sv[k][i] * dA + xdt * bv[i];
+      acc[k] += sv[k][i] * cv[i];
+    }
+    store_vec<TS, VEC>(s + (int64_t)(p0 + k * RPB) * a.ssp, sv[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; k++)
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) acc[k] += shfl_xor(acc[k], m);
+  if (lr == 0) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int p = p0 + k * RPB;
+      float y = acc[k];
+      if (a.D) y += xv[k] * load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)p * a.Dsp, a.ddt);
+      if (a.z) y *= silu_f(to_f32(((const TX*)a.z)[(int64_t)b * a.zsb + (int64_t)h * a.zsh + (int64_t)p * a.zsp]));
+      ((TX*)a.out)[(int64_t)b * a.osb + (int64_t)h * a.osh + (int64_t)p * a.osp] = from_f32<TX>(y);
+    }
+  }
+}
+
 }  // namespace omk
 
 using namespace omk;
@@ -119,6 +173,21 @@ extern "C" int omk_selective_state_update(const OmkStateUpdate* p, omk_stream st
              ((uintptr_t)p->state.data % (4 * sb)) == 0 && ((uintptr_t)p->Bm.data % (4 * xb)) == 0 && ((uintptr_t)p->Cm.data % (4 * xb)) == 0 &&
              a.ssb % 4 == 0 && a.ssh % 4 == 0 && a.ssp % 4 == 0 && a.bsb % 4 == 0 && a.bsg % 4 == 0 && a.csb % 4 == 0 && a.csg % 4 == 0;
   dim3 block(256);
+  // Mamba-2 decode with several sequences: tied scalars, one vector step per row, four rows per lane group
+  {
+    const int lpr = a.N / 4;
+    const bool tied = vec && a.asn == 0 && a.asp == 0 && a.dsp == 0 && (!present(p->dt_bias) || a.tsp == 0) && (lpr == 32 || lpr == 16) && a.N % 4 == 0 &&
+                      p->z.dtype == p->x.dtype && p->out.dtype == p->x.dtype && (int64_t)a.B * a.H * a.P * a.N >= ((int64_t)1 << 21);
+    const int rpb = tied ? (64 / lpr) * 4 : 1;
+    if (tied && a.P % (rpb * 4) == 0 && !getenv("OMK_STATE_UPDATE_GENERIC")) {
+      dim3 grid((unsigned)((int64_t)a.B * a.H * (a.P / (rpb * 4))));
+#define SU_TIED(TS, TX) do { if (lpr == 32) OMK_LAUNCH((state_update_tied_kernel<TS, TX, 32, 4>), grid, block, 0, stream, a); \
+                             else OMK_LAUNCH((state_update_tied_kernel<TS, TX, 16, 4>), grid, block, 0, stream, a); } while (0)
+      OMK_DISPATCH_DTYPE(p->state.dtype, TS, OMK_DISPATCH_DTYPE(p->x.dtype, TX, SU_TIED(TS, TX)));
+#undef SU_TIED
+      return finish_launch("selective_state_update");
+    }
+  }
 #define SU_LAUNCH(TS, TX, VEC, LPR) do { \
     int rpb = (64 / LPR) * 4; int pblocks = (a.P + rpb - 1) / rpb; \
     dim3 grid((unsigned)((int64_t)a.B * a.H * pblocks)); \

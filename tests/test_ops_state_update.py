@@ -35,6 +35,26 @@ def test_state_update(dev, sdt, xdt, H, P, N, G, tied):
     assert rel(y, y0) < tol and rel(s1, s0) < stol
 
 
+@pytest.mark.parametrize("sdt,xdt,N", [(torch.float32, torch.float32, 128), (torch.bfloat16, torch.bfloat16, 128), (torch.float32, torch.bfloat16, 64)])
+def test_state_update_tied_rows_kernel(dev, sdt, xdt, N):
+    """Several sequences of the 1.3B block shape: the tied-scalar kernel with four rows per lane group (>= 2^21 state
+    elements).  Same oracle, same tolerances."""
+    from omnimamba_amd.selective_state_update import selective_state_update
+    torch.manual_seed(3)
+    Bsz, H, P, G = (4 if N == 128 else 8), 64, 64, 1
+    st = torch.randn(Bsz, H, P, N).to(sdt)
+    x, z = torch.randn(Bsz, H, P).to(xdt), torch.randn(Bsz, H, P).to(xdt)
+    Bm, Cm = torch.randn(Bsz, G, N).to(xdt), torch.randn(Bsz, G, N).to(xdt)
+    dt_, A_, D_, dtb_ = torch.randn(Bsz, H).to(xdt), -(torch.rand(H) * 15 + 1), torch.randn(H), torch.randn(H)
+    ex = lambda t, d: (t.to(d)[..., None].expand(*t.shape, P))
+    s1, s0 = st.clone().to(dev), st.clone()
+    y = selective_state_update(s1, x.to(dev), ex(dt_, dev), A_.to(dev)[:, None, None].expand(H, P, N), Bm.to(dev), Cm.to(dev), D=ex(D_, dev),
+                               z=z.to(dev), dt_bias=ex(dtb_, dev), dt_softplus=True)
+    y0 = O.selective_state_update_ref(s0, x, ex(dt_, "cpu"), A_[:, None, None].expand(H, P, N), Bm, Cm, D=ex(D_, "cpu"), z=z,
+                                      dt_bias=ex(dtb_, "cpu"), dt_softplus=True)
+    assert rel(y, y0) < (2e-5 if xdt == torch.float32 else 6e-3) and rel(s1, s0) < (2e-5 if sdt == torch.float32 else 6e-3)
+
+
 def test_state_update_no_heads(dev):
     from omnimamba_amd.selective_state_update import selective_state_update
     torch.manual_seed(1)
