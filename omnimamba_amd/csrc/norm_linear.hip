@@ -380,7 +380,8 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
 template <class TW> struct lds_u { using type = float; };
 template <> struct lds_u<bf16_t> { using type = bf16_t; };
 
-template <class TW, class TR, int NQ, int RMAX, int NB>
+// GATE: the second input is the gate z (dtype TW) instead of a residual (dtype TR) -- never both in this kernel.
+template <class TW, class TR, int NQ, int RMAX, int NB, bool GATE>
 __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs a) {
   using TU = typename lds_u<TW>::type;
   constexpr int In = 1024 * NQ;
@@ -407,28 +408,45 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
       _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
     } } while (0)
   NLB_ISSUE(row0);
-  // ---- preamble, CB sequences at a time (sequences past B repeat the last one; nothing of theirs is stored)
-  const bool hasres = a.res != nullptr, hasz = a.z != nullptr;
+  // ---- preamble, CB sequences at a time (sequences past B repeat the last one; nothing of theirs is stored).  Every
+  // wait on a load costs a round trip (and the first one also waits for the weight rows above, in-order counter), so the
+  // LoRA A rows are requested once, up front, and the next group's activations before the current group is reduced.
+  using TA = typename std::conditional<GATE, TW, TR>::type;       // second input: gate or residual
+  const bool hasaux = GATE ? true : a.res != nullptr;
   float n4[NQ][4];
 #pragma unroll
   for (int k = 0; k < NQ; k++) load_vec<TW, 4>((const TW*)a.nw + 4 * (tid + NL_THREADS * k), n4[k]);
+  constexpr bool A_UP = RMAX > 0 && RMAX * NQ <= 16;             // 64 registers at most
+  float aup[A_UP ? RMAX : 1][NQ][4];
+  if constexpr (A_UP) {
 #pragma unroll
-  for (int b0 = 0; b0 < NB; b0 += CB) {
-    float v[CB][NQ][4], t4[CB][NQ][4], g4[CB][NQ][4];
+    for (int r = 0; r < RMAX; r++)
+#pragma unroll
+      for (int k = 0; k < NQ; k++)
+        load_vec<TW, 4>((const TW*)a.la + (int64_t)(r < a.R ? r : 0) * a.las + 4 * (tid + NL_THREADS * k), aup[r][k]);
+  }
+  constexpr int NG = NB / CB;
+  constexpr bool PF = RMAX == 0 && NG > 1;                        // prefetch the next group (registers allow it without LoRA)
+  float v[PF ? 2 : 1][CB][NQ][4], t4[PF ? 2 : 1][CB][NQ][4];
+  auto issue = [&](int gi, int buf) {
 #pragma unroll
     for (int bb = 0; bb < CB; bb++) {
-      const int b = b0 + bb < a.B ? b0 + bb : a.B - 1;
+      const int b = gi * CB + bb < a.B ? gi * CB + bb : a.B - 1;
       const TW* xp = (const TW*)a.x + (int64_t)b * a.xs;
-      const TR* rp = hasres ? (const TR*)a.res + (int64_t)b * a.rs : (const TR*)xp;
-      const TW* zp = hasz ? (const TW*)a.z + (int64_t)b * a.zs : xp;
+      const TA* ap = GATE ? (const TA*)a.z + (int64_t)b * a.zs : (hasaux ? (const TA*)a.res + (int64_t)b * a.rs : (const TA*)xp);
 #pragma unroll
       for (int k = 0; k < NQ; k++) {
         const int c = 4 * (tid + NL_THREADS * k);
-        load_vec<TW, 4>(xp + c, v[bb][k]);
-        load_vec<TR, 4>(rp + (hasres ? c : 0), t4[bb][k]);
-        load_vec<TW, 4>(zp + c, g4[bb][k]);
+        load_vec<TW, 4>(xp + c, v[buf][bb][k]);
+        load_vec<TA, 4>(ap + (hasaux ? c : 0), t4[buf][bb][k]);
       }
     }
+  };
+  issue(0, 0);
+#pragma unroll
+  for (int gi = 0; gi < NG; gi++) {
+    const int cur = PF ? (gi & 1) : 0, b0 = gi * CB;
+    if constexpr (PF) { if (gi + 1 < NG) issue(gi + 1, cur ^ 1); }
 #pragma unroll
     for (int bb = 0; bb < CB; bb++) {
       float ssq = 0.f;
@@ -437,36 +455,39 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
         const int c = 4 * (tid + NL_THREADS * k);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          v[bb][k][i] += hasres ? t4[bb][k][i] : 0.f;
-          t4[bb][k][i] = v[bb][k][i];
-          const float g = hasz ? silu_f(g4[bb][k][i]) : 1.f;
-          const float q = (hasz && !a.nbg) ? v[bb][k][i] * g : v[bb][k][i];
+          float x_ = v[cur][bb][k][i], g = 1.f;
+          if constexpr (GATE) g = silu_fast(t4[cur][bb][k][i]);
+          else { x_ += hasaux ? t4[cur][bb][k][i] : 0.f; t4[cur][bb][k][i] = x_; }   // t4 becomes residual_out
+          const float q = (GATE && !a.nbg) ? x_ * g : x_;
           ssq += q * q;
-          v[bb][k][i] = q * n4[k][i] * ((hasz && a.nbg) ? g : 1.f);
+          v[cur][bb][k][i] = q * n4[k][i] * ((GATE && a.nbg) ? g : 1.f);
         }
-        store_vec<TU, 4>(sn + (size_t)(b0 + bb) * In + c, v[bb][k]);
+        store_vec<TU, 4>(sn + (size_t)(b0 + bb) * In + c, v[cur][bb][k]);
         if (sizeof(TU) == 2) {   // the LoRA input is the same rounded u the rows multiply
 #pragma unroll
-          for (int i = 0; i < 4; i++) v[bb][k][i] = to_f32(from_f32<TU>(v[bb][k][i]));
+          for (int i = 0; i < 4; i++) v[cur][bb][k][i] = to_f32(from_f32<TU>(v[cur][bb][k][i]));
         }
       }
-      if (a.ro && blockIdx.x == 0 && b0 + bb < a.B) {
+      if constexpr (!GATE) {
+        if (a.ro && blockIdx.x == 0 && b0 + bb < a.B) {
 #pragma unroll
-        for (int k = 0; k < NQ; k++) store_vec<TR, 4>((TR*)a.ro + (int64_t)(b0 + bb) * a.ros + 4 * (tid + NL_THREADS * k), t4[bb][k]);
+          for (int k = 0; k < NQ; k++) store_vec<TR, 4>((TR*)a.ro + (int64_t)(b0 + bb) * a.ros + 4 * (tid + NL_THREADS * k), t4[cur][bb][k]);
+        }
       }
       ssq = wave_sum(ssq);
       if (lane == 0) red[wave * NB + b0 + bb] = ssq;
     }
     if constexpr (RMAX > 0) {
-      const TW* lap = (const TW*)a.la;
 #pragma unroll
       for (int rb = 0; rb < RMAX; rb += 4) {
-        float a4[4][NQ][4];
+        float a4[A_UP ? 1 : 4][NQ][4];
+        if constexpr (!A_UP) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+          for (int r = 0; r < 4; r++)
 #pragma unroll
-          for (int k = 0; k < NQ; k++)
-            load_vec<TW, 4>(lap + (int64_t)(rb + r < a.R ? rb + r : 0) * a.las + 4 * (tid + NL_THREADS * k), a4[r][k]);
+            for (int k = 0; k < NQ; k++)
+              load_vec<TW, 4>((const TW*)a.la + (int64_t)(rb + r < a.R ? rb + r : 0) * a.las + 4 * (tid + NL_THREADS * k), a4[r][k]);
+        }
 #pragma unroll
         for (int bb = 0; bb < CB; bb++)
 #pragma unroll
@@ -475,12 +496,13 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
 #pragma unroll
             for (int k = 0; k < NQ; k++)
 #pragma unroll
-              for (int i = 0; i < 4; i++) hr += v[bb][k][i] * a4[r][k][i];
+              for (int i = 0; i < 4; i++) hr += v[cur][bb][k][i] * (A_UP ? aup[A_UP ? rb + r : 0][k][i] : a4[A_UP ? 0 : r][k][i]);
             hr = wave_sum(hr);
             if (lane == 0) part[(wave * NB + b0 + bb) * 8 + rb + r] = rb + r < a.R ? hr : 0.f;
           }
       }
     }
+    if constexpr (!PF) { if (gi + 1 < NG) issue(gi + 1, 0); }
   }
   block_sync();
   // ---- rows: every weight vector meets the NB activation rows while it is in registers
@@ -690,9 +712,12 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       a.nbatch = k;
       if (k * rw > 64) return fail(OMK_EUNSUPPORTED, "norm_linear: %d output rows are too many for the batched kernel", a.Out);
       dim3 bgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), bblock(NL_THREADS);
-#define NLB_GO(TW_, TR_, NQ_, RM_, NB_) do { \
-        if (OMK_SET_MAX_DYN_SMEM((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_>), bsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", bsmem); \
-        OMK_LAUNCH((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_>), bgrid, bblock, bsmem, stream, a); } while (0)
+      const bool gate = present(p->z);
+      if (gate && present(p->residual)) return fail(OMK_EUNSUPPORTED, "norm_linear: residual and gate together are served by the batch-1 kernel only");
+#define NLB_G(TW_, TR_, NQ_, RM_, NB_, G_) do { \
+        if (OMK_SET_MAX_DYN_SMEM((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", bsmem); \
+        OMK_LAUNCH((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bgrid, bblock, bsmem, stream, a); } while (0)
+#define NLB_GO(TW_, TR_, NQ_, RM_, NB_) do { if (gate) NLB_G(TW_, TR_, NQ_, RM_, NB_, true); else NLB_G(TW_, TR_, NQ_, RM_, NB_, false); } while (0)
 #define NLB_B(TW_, TR_, NQ_, RM_) do { if (nb == 2) NLB_GO(TW_, TR_, NQ_, RM_, 2); else if (nb == 4) NLB_GO(TW_, TR_, NQ_, RM_, 4); else NLB_GO(TW_, TR_, NQ_, RM_, 8); } while (0)
 #define NLB_R(TW_, TR_, NQ_) do { if (a.R > 0) NLB_B(TW_, TR_, NQ_, 8); else NLB_B(TW_, TR_, NQ_, 0); } while (0)
 #define NLB_Q(TW_, TR_) do { if (nq == 1) NLB_R(TW_, TR_, 1); else if (nq == 2) NLB_R(TW_, TR_, 2); else NLB_R(TW_, TR_, 4); } while (0)
@@ -703,6 +728,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
 #undef NLB_R
 #undef NLB_B
 #undef NLB_GO
+#undef NLB_G
       return finish_launch("norm_linear");
     }
     if (a.B > 1) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d needs the uniform-dtype kernel (one dtype, in_features 1024 / 2048 / 4096)", a.B);
