@@ -581,40 +581,54 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
       for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); wt[k] = col >= 0 ? to_f32(wr_[col >= 0 ? col : 0]) : 0.f; }
       cbias = a.ccb ? to_f32(((const TW*)a.ccb)[ch]) : 0.f;
     }
+    // every load of the tail first (sequences past B clamp to the last one), then the arithmetic, stores last: with the
+    // loads inside a per-sequence branch each sequence costs its own round trip
+    float hist[NB][3], vout[NB], xin[NB];
+    if (isconv) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const TW* cs = (const TW*)a.cst + (int64_t)(b < a.B ? b : a.B - 1) * a.csb + (int64_t)ch * a.csc;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; hist[b][k] = to_f32(cs[(int64_t)(sl >= 0 ? sl : 0) * a.csl]); }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      float vv = keep[b];
+      if (RMAX > 0) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+          float h = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < NL_THREADS / 64; w2++) h += part[(w2 * NB + b) * 8 + r];
+          d += lbv[r] * h;
+        }
+        vv += a.scale * d;
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NL_THREADS / 64; w2++) ss += red[w2 * NB + b];
+      vv = vv * rsqrtf(ss / (float)In + a.eps) + bias;
+      xin[b] = to_f32(from_f32<TW>(vv));
+      if (isconv) {
+        const float cv = cbias + wt[0] * hist[b][0] + wt[1] * hist[b][1] + wt[2] * hist[b][2] + wt[3] * xin[b];
+        vv = a.csilu ? silu_f(cv) : cv;
+      }
+      vout[b] = vv;
+    }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
       if (b < a.B) {
-        float vv = keep[b];
-        if (RMAX > 0) {
-          float d = 0.f;
-#pragma unroll
-          for (int r = 0; r < RMAX; r++) {
-            float h = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < NL_THREADS / 64; w2++) h += part[(w2 * NB + b) * 8 + r];
-            d += lbv[r] * h;
-          }
-          vv += a.scale * d;
-        }
-        float ss = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < NL_THREADS / 64; w2++) ss += red[w2 * NB + b];
-        vv = vv * rsqrtf(ss / (float)In + a.eps) + bias;
         if (isconv) {
           TW* cs = (TW*)a.cst + (int64_t)b * a.csb + (int64_t)ch * a.csc;
-          float hist[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; hist[k] = to_f32(cs[(int64_t)(sl >= 0 ? sl : 0) * a.csl]); }
-          const float xin = to_f32(from_f32<TW>(vv));
-          const float cv = cbias + wt[0] * hist[0] + wt[1] * hist[1] + wt[2] * hist[2] + wt[3] * xin;
           for (int sl = 0; sl + 1 < a.cS; sl++) {
             const int k = sl + 1 - (a.cS - 3);
-            cs[(int64_t)sl * a.csl] = from_f32<TW>(k == 0 ? hist[0] : (k == 1 ? hist[1] : hist[2]));
+            cs[(int64_t)sl * a.csl] = from_f32<TW>(k == 0 ? hist[b][0] : (k == 1 ? hist[b][1] : hist[b][2]));
           }
-          cs[(int64_t)(a.cS - 1) * a.csl] = from_f32<TW>(xin);
-          vv = a.csilu ? silu_f(cv) : cv;
+          cs[(int64_t)(a.cS - 1) * a.csl] = from_f32<TW>(xin[b]);
         }
-        ((TW*)a.out)[(int64_t)b * a.os + row] = from_f32<TW>(vv);
+        ((TW*)a.out)[(int64_t)b * a.os + row] = from_f32<TW>(vout[b]);
       }
     }
   }
