@@ -409,7 +409,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   return finish_launch("ssd_scan_fwd");
 }
 
-struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg; size_t total; };
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg, *segf; size_t total; };
 static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, bool need_part) {
   BwdWs w; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
@@ -420,7 +420,9 @@ static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N,
   const size_t nC = (size_t)(L + 63) / 64;
   w.ckpt = need_part ? take((size_t)B * (H / 2) * nC * (8 * 2 * 8 * 64) * 4) : nullptr;
   w.bnd = need_part ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
-  w.seg = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;   // dx scan, split sequence
+  // split sequences: start states of the segments -- adjoint state (dx and dB scans) and forward state (dC scan)
+  w.seg = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
+  w.segf = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
   w.total = off;
   return w;
 }
@@ -521,6 +523,23 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   const float* A = (const float*)p->A.data;
   GScan gdc, gdx, gdb;
   bwd_scans(p, d, w, mfma, &gdc, &gdx, &gdb);
+  if (mfma && gdx.seg && ssd_segments(d.B * d.H, d.L).nseg > 1) {
+    // few (batch, head) pairs: every scan cuts the sequence into the same segments.  Their start states come from two
+    // state-only passes + folds: the forward state (x, B; shared by the dC scan) and the adjoint state (dy, C; dx and dB)
+    GScan gf = {};
+    gf.mode = GS_Y; gf.dtp = w.dtp; gf.A = A; gf.B = d.B; gf.H = d.H; gf.G = d.G; gf.L = d.L; gf.DU = d.P; gf.DK = d.N;
+    gf.U = make_src(p->x, false); gf.K = make_src(p->Bm, true); gf.Q = make_src(p->Cm, true); gf.reverse = 0; gf.w_is_dt = 1;
+    if (present(p->initial_states)) {
+      gf.init = p->initial_states.data; gf.init_dt = p->initial_states.dtype;
+      gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
+    }
+    gf.seg = w.segf;
+    if ((rc = ssd_mfma_prepare_segments(gf, stream))) return rc;
+    if ((rc = ssd_mfma_prepare_segments(gdx, stream))) return rc;
+    gdc.seg = w.segf; gdc.seg_ready = 1;
+    gdx.seg_ready = 1;
+    gdb.seg = w.seg; gdb.seg_ready = 1;
+  }
   if (mfma) {
     if ((rc = ssd_mfma_launch(gdc, stream))) return rc;   // forward in time: e_t, state checkpoints, dC partials
     ssd_reduce_partials(w.part, p->dC.data, p->dC.stride[0], p->dC.stride[1], p->dC.stride[2], p->dC.dtype, d.B, d.L, d.G, d.H, stream);

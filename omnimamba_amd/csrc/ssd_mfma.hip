@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   }
   // ---- running state: S^T[32 w + ..][32 ut + ..], ut = 0, 1
   f32x16 accS[2];
-  float init_scale = 1.f;   // decay of the caller's initial state down to this segment's start
 #pragma unroll
   for (int ut = 0; ut < 2; ut++)
 #pragma unroll
@@ -210,27 +209,20 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const int64_t bh = (int64_t)b * a.H + h;
   // accumulator order of the segment states: element (w, ut, r, lane) at ((2 w + ut) * 16 + r) * 64 + lane
   const int segoff = (2 * w * 16) * 64 + lane;
-  if (!STATE && seg > 0) {
-    const float* sdec = a.seg + (int64_t)a.B * a.H * a.nseg * SEG_STATE + bh * a.nseg;
-    float run = 0.f;   // log2 decay from the end of segment i to the start of this one
-    for (int i = seg - 1; i >= 0; i--) {
-      const float cf = exp2_fast(run);
-      const float* sp = a.seg + (bh * a.nseg + i) * SEG_STATE + segoff;
+  if (!STATE && seg > 0) {   // folded by ssd_seg_fold_kernel: slot seg - 1 = state at the start of this segment
+    const float* sp = a.seg + (bh * a.nseg + seg - 1) * SEG_STATE + segoff;
 #pragma unroll
-      for (int ut = 0; ut < 2; ut++)
+    for (int ut = 0; ut < 2; ut++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) accS[ut][r] += cf * sp[(ut * 16 + r) * 64];
-      run += sdec[i];
-    }
-    init_scale = exp2_fast(run);
+      for (int r = 0; r < 16; r++) accS[ut][r] = sp[(ut * 16 + r) * 64];
   }
-  if (a.init && !STATE) {
+  if (a.init && !STATE && seg == 0) {
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h32, u = 32 * ut + l31;
-        accS[ut][r] += init_scale * load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+        accS[ut][r] = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
       }
   }
   auto publish_state = [&]() {
@@ -460,6 +452,27 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   }
 }
 
+// Segment states -> start states, in place: slot j (end state of segment j from a zero start, accumulator order) becomes
+// the state at the START of segment j + 1: run = exp2(dec_j) run + slot_j, run_0 = the caller's initial state.
+// One thread = one state element of one (b, h); nseg - 1 sequential steps.
+__global__ void ssd_seg_fold_kernel(GScan a) {
+  const int64_t bh = blockIdx.x / (SEG_STATE / 256);
+  const int e = (blockIdx.x % (SEG_STATE / 256)) * 256 + threadIdx.x;
+  const int b = (int)(bh / a.H), h = (int)(bh % a.H);
+  float run = 0.f;
+  if (a.init) {   // element e = ((2 w + ut) * 16 + r) * 64 + lane of the class A accumulators
+    const int lane = e & 63, r = (e >> 6) & 15, ut = (e >> 10) & 1, w = e >> 11;
+    const int k = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), u = 32 * ut + (lane & 31);
+    run = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
+  }
+  const float* sdec = a.seg + (int64_t)a.B * a.H * a.nseg * SEG_STATE + bh * a.nseg;
+  float* sp = a.seg + bh * a.nseg * SEG_STATE + e;
+  for (int j = 0; j + 1 < a.nseg; j++) {
+    run = exp2_fast(sdec[j]) * run + sp[(int64_t)j * SEG_STATE];
+    sp[(int64_t)j * SEG_STATE] = run;
+  }
+}
+
 // =========================================================================================================
 // class B: the row-strip design of ssd_mfma_a3_kernel for the dC / dB scans.  One 512-thread workgroup owns
 // a head PAIR (the unit of the fp32 partial tiles): waves 0-3 are the strips of head 0, waves 4-7 of head 1; the group
@@ -494,10 +507,12 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
   const int pairs = a.H / 2;
   int vid = blockIdx.x;
   if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous (batch, pair)
-  const int b = vid / pairs, hp = vid % pairs;
+  // workgroup order (b, segment, pair): the pairs of one (batch, segment) share the group rows and an XCD
+  const int hp = vid % pairs, seg = (vid / pairs) % a.nseg, b = vid / (pairs * a.nseg);
   const int h0 = hp * 2, hcur = h0 + hh;
   const int g = h0 / (a.H / a.G);
   const int nC = (a.L + QC - 1) / QC;
+  const int c0 = seg * a.cps, c1 = (c0 + a.cps < nC) ? c0 + a.cps : nC;   // chunks of this workgroup, scan order
   const bool rev = a.reverse != 0;
   auto chunk_lo = [&](int c) -> int { return (rev ? nC - 1 - c : c) * QC; };
   auto rowtok = [&](int i) -> int { return rev ? QC - 1 - i : i; };
@@ -590,8 +605,14 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float v = 0.f;
-      if (a.init) {
-        const int k = 16 * w + 4 * g16 + r, u = 16 * ut + t16;
+      const int k = 16 * w + 4 * g16 + r, u = 16 * ut + t16;   // this kernel's state is [n = u][p = k]
+      if (seg > 0) {
+        // start state of the segment, folded in the class A accumulator order of the transposed state [p][n]:
+        // element ((2 (n >> 5) + (p >> 5)) * 16 + 4 ((n >> 3) & 3) + (n & 3)) * 64 + 32 ((n >> 2) & 1) + (p & 31)
+        const int n = u, pp = k;
+        const int e = ((2 * (n >> 5) + (pp >> 5)) * 16 + 4 * ((n >> 3) & 3) + (n & 3)) * 64 + 32 * ((n >> 2) & 1) + (pp & 31);
+        v = a.seg[(((int64_t)b * a.H + hcur) * a.nseg + seg - 1) * SEG_STATE + e];
+      } else if (a.init) {
         v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)hcur * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
       }
       accS[ut][r] = v;
@@ -604,7 +625,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     }
   };
 
-  stlo = chunk_lo(0);
+  stlo = chunk_lo(c0);
   prefetch_tiles();
   prefetch_q();
   commit();
@@ -630,11 +651,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) ckv[i] = ld16(cp + 256 * i);
   };
-  if (want_bnd) load_ckpt(0);
+  if (want_bnd) load_ckpt(c0);
 
-  for (int c = 0; c < nC; c++) {
+  for (int c = c0; c < c1; c++) {
     const int tlo = chunk_lo(c);
-    const int cnext = c + 1 < nC ? c + 1 : c;
+    const int cnext = c + 1 < c1 ? c + 1 : c;
     OMK_OPAQUE(o_mu); OMK_OPAQUE(o_su); OMK_OPAQUE(o_x4); OMK_OPAQUE(o_ps); OMK_OPAQUE(o_tk);
     if (want_bnd) {
       // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
@@ -826,7 +847,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       atomic_add_f32(a.dD + (int64_t)(h0 + r) * a.dDsh + (int64_t)col * a.dDsp, v);
     }
   }
-  if (a.fin) {
+  if (a.fin && seg == a.nseg - 1) {
     const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
 #pragma unroll
     for (int ut = 0; ut < 8; ut++)
@@ -877,16 +898,35 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
   if (!stride_ok(g.U.sl) || !stride_ok(g.K.sl) || !stride_ok(g.Q.sl) || !stride_ok(g.X4.sl) || !stride_ok(g.K.sh)) return OMK_EUNSUPPORTED;
   if (!g.tokscal && !dry) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
-  dim3 grid((unsigned)(g.B * (g.H / 2))), block(512);
+  // one head pair (x one segment of a split sequence, start states prepared by ssd_mfma_prepare_segments) per workgroup
+  GScan a = g;
+  const SegPlan sp = (a.seg && a.seg_ready) ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
   const size_t smem = sizeof(SmemB3);
 #define OMK_B3(MODE_, DM_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_b3_kernel<MODE_, DM_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_mfma_b3_kernel<MODE_, DM_>), grid, block, smem, stream, g); } while (0)
-  if (g.mode == GS_DC) OMK_B3(GS_DC, 0);
-  else if (!g.dD) OMK_B3(GS_DB, 0);
-  else if (g.dDsp == 0) OMK_B3(GS_DB, 1);
+    OMK_LAUNCH((ssd_mfma_b3_kernel<MODE_, DM_>), grid, block, smem, stream, a); } while (0)
+  if (a.mode == GS_DC) OMK_B3(GS_DC, 0);
+  else if (!a.dD) OMK_B3(GS_DB, 0);
+  else if (a.dDsp == 0) OMK_B3(GS_DB, 1);
   else OMK_B3(GS_DB, 2);
 #undef OMK_B3
+  return OMK_OK;
+}
+
+int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream) {
+  GScan a = g;
+  const SegPlan sp = ssd_segments(a.B * a.H, a.L);
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  if (!a.seg || a.nseg < 2) return OMK_OK;
+  dim3 block(256), sgrid((unsigned)(a.B * a.H * (a.nseg - 1)));
+  const size_t smem = sizeof(SmemA3);
+  // the state pass does not depend on the mode (no output); it reads U, K, dt' and the scan direction only
+  if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+  OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), sgrid, block, smem, stream, a);
+  dim3 fgrid((unsigned)((int64_t)a.B * a.H * (SEG_STATE / 256)));
+  OMK_LAUNCH(ssd_seg_fold_kernel, fgrid, block, 0, stream, a);
   return OMK_OK;
 }
 
@@ -909,9 +949,9 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
 #define OMK_A3(MODE_, EX_, ST_, DF_, GRID_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), GRID_, block, smem, stream, a); } while (0)
-  if (a.nseg > 1) {
-    dim3 sgrid((unsigned)(a.B * a.H * (a.nseg - 1)));
-    OMK_A3(GS_Y, false, true, false, sgrid);   // the state pass does not depend on the mode (no output)
+  if (a.nseg > 1 && !a.seg_ready) {
+    int rc = ssd_mfma_prepare_segments(g, stream);
+    if (rc) return rc;
   }
   const bool dfold = !a.D || a.Dsp == 0;   // one D per head (or none)
   if (a.mode == GS_Y && (a.Z.p || a.outx)) { if (dfold) OMK_A3(GS_Y, true, false, true, grid); else OMK_A3(GS_Y, true, false, false, grid); }

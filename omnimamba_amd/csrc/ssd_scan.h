@@ -47,6 +47,7 @@ struct GScan {
   // pass leaves every segment's end state from a zero start in seg[(bh * nseg + s) * SEG_STATE ..] (MFMA accumulator
   // order) and its total log2 decay in seg[BH * nseg * SEG_STATE + bh * nseg + s]; the scan proper folds them.
   float* seg; int nseg, cps;
+  int seg_ready;                                                 // seg already holds the folded START states (slot j - 1 = segment j)
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
@@ -79,6 +80,9 @@ inline size_t ssd_seg_bytes(int BH, int L) {
 int ssd_generic_launch(const GScan& g, omk_stream stream);
 // returns OMK_EUNSUPPORTED (without touching the error text) when the shape/dtype/layout is outside the MFMA kernel
 int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 1: only answer whether it applies
+// split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the
+// state at the START of segment j (initial state included).  Shared by the scans whose state this is (y and dC; dx and dB).
+int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream);
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
 }  // namespace omk

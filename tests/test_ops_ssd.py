@@ -141,6 +141,10 @@ def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
     assert rel(fin.cpu(), f0.float()) < 3e-3
     assert rel(lv[0].grad.float().cpu(), dl[0].grad.float()) < 6e-3          # dx: reverse scan, split the same way
     assert rel(lv[7].grad.float().cpu(), dl[7].grad.float()) < 6e-3          # d initial_states: its final state
+    # the dC / dB scans cut the sequence the same way (their start states: the folded forward / adjoint segment states)
+    assert rel(lv[3].grad.float().cpu(), dl[3].grad.float()) < 6e-3 and rel(lv[4].grad.float().cpu(), dl[4].grad.float()) < 6e-3
+    assert rel(lv[1].grad.float().cpu(), dl[1].grad.float()) < 8e-3          # d(dt): token scalars + boundary restarts
+    assert rel(lv[2].grad.float().cpu(), dl[2].grad.float()) < 3e-2          # dA: a signed sum of d(dt) over 300 tokens
 
 
 @pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(130, 2, 1, False, False, None), (70, 4, 2, True, True, None),
