@@ -394,7 +394,7 @@ template <> struct lds_u<bf16_t> { using type = bf16_t; };
 
 // GATE: the second input is the gate z (dtype TW) instead of a residual (dtype TR) -- never both in this kernel.
 template <class TW, class TR, int NQ, int RMAX, int NB, bool GATE>
-__global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs a) {
+__global__ __launch_bounds__(NL_THREADS, 2) void norm_linear_batched_kernel(NlArgs a) {   // two waves per SIMD: <= 256 VGPRs
   using TU = typename lds_u<TW>::type;
   constexpr int In = 1024 * NQ;
   constexpr int VEC = 16 / sizeof(TW);
@@ -407,6 +407,7 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
   TU* sn = (TU*)smem;                                         // [NB][In] u
   float* part = (float*)(smem + (size_t)NB * In * sizeof(TU));   // [waves][NB][8] LoRA partials
   float* red = part + (NL_THREADS / 64) * NB * 8;             // [waves][NB] sums of squares
+  float* res = red + (NL_THREADS / 64) * NB;                  // [waves][64 row slots][NB] row results
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const TW* W = (const TW*)a.W;
   const int nwaves = gridDim.x * (NL_THREADS / 64);
@@ -500,27 +501,29 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
             for (int k = 0; k < NQ; k++)
               load_vec<TW, 4>((const TW*)a.la + (int64_t)(rb + r < a.R ? rb + r : 0) * a.las + 4 * (tid + NL_THREADS * k), a4[r][k]);
         }
+        float hr[CB * 4];                                       // index bb * 4 + r: one butterfly instead of 4 CB wave sums
 #pragma unroll
         for (int bb = 0; bb < CB; bb++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            float hr = 0.f;
+            float h = 0.f;
 #pragma unroll
             for (int k = 0; k < NQ; k++)
 #pragma unroll
-              for (int i = 0; i < 4; i++) hr += v[cur][bb][k][i] * (A_UP ? aup[A_UP ? rb + r : 0][k][i] : a4[A_UP ? 0 : r][k][i]);
-            hr = wave_sum(hr);
-            if (lane == 0) part[(wave * NB + b0 + bb) * 8 + rb + r] = rb + r < a.R ? hr : 0.f;
+              for (int i = 0; i < 4; i++) h += v[cur][bb][k][i] * (A_UP ? aup[A_UP ? rb + r : 0][k][i] : a4[A_UP ? 0 : r][k][i]);
+            hr[bb * 4 + r] = rb + r < a.R ? h : 0.f;
           }
+        wave_multi_sum<CB * 4>(hr);                             // lane L: value index L >> (6 - log2(4 CB))
+        if ((lane & (64 / (CB * 4) - 1)) == 0) {
+          const int idx = lane / (64 / (CB * 4));
+          part[(wave * NB + b0 + idx / 4) * 8 + rb + idx % 4] = hr[0];
+        }
       }
     }
     if constexpr (!PF) { if (gi + 1 < NG) issue(gi + 1, 0); }
   }
   block_sync();
   // ---- rows: every weight vector meets the NB activation rows while it is in registers
-  float keep[NB];
-#pragma unroll
-  for (int b = 0; b < NB; b++) keep[b] = 0.f;
   for (int bi = 0; bi < a.nbatch; bi++) {
     float acc[RW][NB];
 #pragma unroll
@@ -553,15 +556,21 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
     OMK_SCHED_FENCE();
     NLB_ISSUE(row0);
     OMK_SCHED_FENCE();
+    // RW * NB totals with one butterfly (15 + 2 shuffles for 16 values instead of 16 DPP scans and their wait states);
+    // lane L ends up with the value of index L >> (6 - log2(RW NB)) = j * NB + b and parks it in LDS for the row's lane
+    float tot[RW * NB];
 #pragma unroll
     for (int j = 0; j < RW; j++)
 #pragma unroll
-      for (int b = 0; b < NB; b++) {
-        const float vv = wave_sum(acc[j][b]);
-        keep[b] = lane == bi * RW + j ? vv : keep[b];
-      }
+      for (int b = 0; b < NB; b++) tot[j * NB + b] = acc[j][b];
+    wave_multi_sum<RW * NB>(tot);
+    if ((lane & (64 / (RW * NB) - 1)) == 0) {
+      const int idx = lane / (64 / (RW * NB));
+      res[(wave * 64 + bi * RW + idx / NB) * NB + idx % NB] = tot[0];
+    }
   }
 #undef NLB_ISSUE
+  block_sync();   // the row results were parked by other lanes
   const int slot = a.nbatch * RW;
   const int row = wg + lane * nwaves;
   if (lane < slot && row < a.Out) {
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_batched_kernel(NlArgs 
     }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      float vv = keep[b];
+      float vv = res[(wave * 64 + lane) * NB + b];
       if (RMAX > 0) {
         float d = 0.f;
 #pragma unroll
@@ -729,7 +738,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       // two to eight sequences: u for all of them in LDS; one workgroup per CU when that takes more than half of it
       const int nb = a.B <= 2 ? 2 : (a.B <= 4 ? 4 : 8);
       const int vecw = wdt == OMK_F32 ? 4 : 8, steps_row = a.In / (64 * vecw), rw = 16 / steps_row;
-      const size_t bsmem = (size_t)nb * a.In * (wdt == OMK_F32 ? 4 : 2) + (size_t)(NL_THREADS / 64) * nb * 9 * 4;
+      const size_t bsmem = (size_t)nb * a.In * (wdt == OMK_F32 ? 4 : 2) + (size_t)(NL_THREADS / 64) * nb * (9 + 64) * 4;
       if (bsmem > 150 * 1024) return fail(OMK_EUNSUPPORTED, "norm_linear: %d sequences x %d features do not fit the LDS", a.B, a.In);
       const int wg_per_cu = bsmem <= 76 * 1024 ? 2 : 1;
       const int maxw = wg_per_cu * cu_count() * (NL_THREADS / 64);

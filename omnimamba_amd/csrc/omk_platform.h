@@ -218,6 +218,35 @@ __device__ __forceinline__ uint64_t clock64_() { return __builtin_readcyclecount
 #endif
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float sigmoid_fast(float x) { return rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
+// Wave totals of N per-lane values (N a power of two <= 64) with N - 1 + log2(64 / N) shuffles instead of the 6 N
+// DPP steps (plus their wait states) of N wave_sum calls: each halving step hands half of the values to the partner
+// lane.  On return v[0] of lane L is the total of the value with index L >> (6 - log2 N).
+// (compile-time recursion: a run-time halving loop is not unrolled and turns v[] into scratch memory)
+template <int N, int S> struct WaveMultiSum {
+  template <int M> static __device__ __forceinline__ void run(float (&v)[M], int lane) {
+    const bool up = (lane & S) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+      const float keep = up ? v[i + N / 2] : v[i], send = up ? v[i] : v[i + N / 2];
+      v[i] = keep + shfl_xor(send, S);
+    }
+    WaveMultiSum<N / 2, S / 2>::run(v, lane);
+  }
+};
+template <int S> struct WaveMultiSum<1, S> {
+  template <int M> static __device__ __forceinline__ void run(float (&v)[M], int) {
+    v[0] += shfl_xor(v[0], S);
+    WaveMultiSum<1, S / 2>::run(v, 0);
+  }
+};
+template <> struct WaveMultiSum<1, 0> {
+  template <int M> static __device__ __forceinline__ void run(float (&)[M], int) {}
+};
+template <int N> __device__ __forceinline__ void wave_multi_sum(float (&v)[N]) {
+  static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "power of two");
+  WaveMultiSum<N, 32>::run(v, lane_id());
+}
+
 __device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
