@@ -199,7 +199,9 @@ int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* d_st
 
 /* ---- decode-step projection fused with the normalisation in front of it ----------------------------------
  * one launch for: reference block.py:86-95 (fused add + RMSNorm) -> lora.py:185-279 (base + task LoRA) at one token
- * per sequence, and for Mamba2.step's gated RMSNorm -> out_proj (upstream mamba2.py step()).  Batch 1 (larger batches: separate ops).           */
+ * per sequence, and for Mamba2.step's gated RMSNorm -> out_proj (upstream mamba2.py step()).  One sequence: any dtype mix.  Two to eight
+ * sequences: one dtype for activations / weights / norm weight / LoRA (fp32 or bf16), in_features 1024 / 2048 / 4096.
+ * Anything else returns OMK_EUNSUPPORTED: use the separate ops.                                                     */
 typedef struct {
   OmkTensor x;             /* (B, in) */
   OmkTensor residual;      /* optional (B, in): added before the norm */

@@ -670,8 +670,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
   OMK_REQUIRE(p->weight.shape[1] == a.In && p->out.shape[0] == a.B && p->out.shape[1] == a.Out, "norm_linear: shape mismatch");
   OMK_REQUIRE(p->x.stride[1] == 1 && p->out.stride[1] == 1 && p->weight.stride[1] == 1, "norm_linear: last dims must be contiguous");
   if (a.B == 0 || a.Out == 0) return OMK_OK;
-  // one sequence per call: with more, the per-batch preamble state and the double register set of the pipelined row loop
-  // no longer fit (the kernel template takes NB, the launcher only instantiates 1); callers use the separate ops instead
+  // up to eight sequences per call (norm_linear_batched_kernel); more than that goes to the separate ops
   if (a.B > 8) return fail(OMK_EUNSUPPORTED, "norm_linear: batch %d > 8 is served by the unfused ops", a.B);
   const int wdt = p->weight.dtype;
   const int vec = wdt == OMK_F32 ? 4 : 8;

@@ -3,7 +3,7 @@
 At one token per sequence the reference runs `layer_norm_fn` (block.py:86-95), the task LoRA `Linear` (lora.py:185-279:
 base GEMV, A GEMV, B GEMV, scale, add) and later `RMSNormGated` + `out_proj` (upstream Mamba2.step) as separate launches
 of a few microseconds each; here each group is ONE kernel that streams the weight matrix once.  Inference only (no
-autograd); batch 1.  Callers fall back to the unfused ops when `applies()` says no.
+autograd); one to eight sequences per call.  Callers fall back to the unfused ops when `applies()` says no.
 """
 from __future__ import annotations
 
