@@ -139,10 +139,11 @@ def main():
         ach = fwd_bytes / (ms_f * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of the same kernel at this shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot be read inside this process
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "ssd_fwd_traffic.json")) as fh:
-                traffic = int(json.load(fh)["traffic_bytes_per_launch"])
+                tj = json.load(fh)
+                traffic, traffic_src = int(tj["traffic_bytes_per_launch"]), tj.get("source")
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -155,7 +156,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
             "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_ssd_fwd_v3.txt" if traffic else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4),
                          "launches_timed": n_f},
             "scan_bwd": {"launch_ms": round(ms_b, 4), "algorithmic_bytes_per_launch": tok * SCAN_BWD_BYTES_PER_TOK,
