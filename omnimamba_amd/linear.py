@@ -65,38 +65,64 @@ def weight_grad(dy2d: torch.Tensor, x2d: torch.Tensor, out_dtype: torch.dtype) -
     return (dy2d.t() @ x2d).to(out_dtype)
 
 
-class _LinearFn(torch.autograd.Function):
+class _XGradFn(torch.autograd.Function):
+    """y = F.linear(x, W, b); its backward only forms dx."""
+
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
-        ctx.wdtype, ctx.bdtype = weight.dtype, None if bias is None else bias.dtype
         if torch.is_autocast_enabled():
             adt = torch.get_autocast_dtype("cuda")
             x, weight = x.to(adt), weight.to(adt)
             bias = None if bias is None else bias.to(adt)
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(weight)
         return F.linear(x, weight, bias)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = dy @ weight.to(dy.dtype)
+        (weight,) = ctx.saved_tensors
+        return (dy @ weight.to(dy.dtype)) if ctx.needs_input_grad[0] else None, None, None
+
+
+class _WGradFn(torch.autograd.Function):
+    """Identity on y that owns the weight / bias gradients.  It sits BEHIND the GEMM node in the graph, so backward reaches
+    it first: dW is formed, the weight's AccumulateGrad (highest priority in the autograd engine) runs, and under DDP the
+    bucket's all-reduce is in flight while the dx GEMM of `_XGradFn` computes.  For the first layer of a stack -- or the
+    single block of bench.py -- this is the only overlap the last (largest) weight gradient can get."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, y, x, weight, bias):
+        ctx.wdtype, ctx.bdtype = weight.dtype, None if bias is None else bias.dtype
+        if torch.is_autocast_enabled():
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        ctx.save_for_backward(x)
+        return y.view_as(y)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1])
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             dy2c = dy2 if dy2.is_contiguous() else dy2.contiguous()
             x2 = x.reshape(-1, x.shape[-1])
             dw = weight_grad(dy2c, x2 if x2.is_contiguous() else x2.contiguous(), ctx.wdtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.bdtype is not None and ctx.needs_input_grad[3]:
             db = dy2.sum(0).to(ctx.bdtype)
-        return dx, dw, db
+        return dy, None, dw, db
 
 
 def linear(x, weight, bias=None):
-    """F.linear whose weight gradient is formed with `weight_grad` (same forward arithmetic)."""
+    """F.linear whose weight gradient is formed with `weight_grad` (same forward arithmetic), as two autograd nodes so that
+    the weight gradient is ready -- and its all-reduce started -- before the input gradient is computed."""
     if not x.is_cuda:
         return F.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias)
+    # the GEMM node sees detached parameters: an edge from it to the weight would make the weight's AccumulateGrad wait
+    # for the dx GEMM as well
+    y = _XGradFn.apply(x, weight.detach(), None if bias is None else bias.detach())
+    if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)):
+        y = _WGradFn.apply(y, x.detach(), weight, bias)
+    return y

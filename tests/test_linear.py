@@ -48,3 +48,29 @@ def test_gradients_match_autograd(tokens, out_f, in_f):
     assert rel(res[0][2]) <= rel(res[1][2]) * 1.05 + 1e-6          # fp32 partial sums: at least as accurate as one bf16-output GEMM
     assert rel(res[0][2]) < 3e-3
     assert ((res[0][3] - res[1][3]).norm() / res[1][3].norm()).item() < 1e-2
+
+
+@pytest.mark.gpu
+def test_weight_gradient_is_ready_before_the_input_gradient():
+    """Two autograd nodes: the weight's AccumulateGrad (where DDP starts the bucket's all-reduce) runs before the dx GEMM,
+    so the last weight gradient of backward still overlaps something."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(4, 512, 256, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    w = (torch.randn(384, 256, device=dev) * 0.02).requires_grad_()
+    order = []
+    w.register_post_accumulate_grad_hook(lambda p: order.append("w"))
+    x.register_hook(lambda g: order.append("x"))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = L.linear(x, w)
+    y.float().sum().backward()
+    assert order == ["w", "x"], order
+    # frozen weight (LoRA base in stage 1): no second node, plain dgrad
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = L.linear(x, w.detach())
+        assert y2.grad_fn is not None and "XGrad" in type(y2.grad_fn).__name__
+        # input without gradient (first layer on fixed embeddings): the weight still gets its gradient
+        w3 = w.detach().clone().requires_grad_()
+        y3 = L.linear(x.detach(), w3)
+    y3.float().sum().backward()
+    assert w3.grad is not None and w3.grad.shape == w3.shape
