@@ -93,7 +93,10 @@ def main():
     model = block
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
-        model = DDP(block, device_ids=[local_rank], gradient_as_bucket_view=True, bucket_cap_mb=64)
+        # 32 MB buckets: out_proj.weight (33.5 MB, ready at the very start of backward) gets a bucket of its own and its
+        # all-reduce overlaps the whole backward; with 64 MB it would wait for the small parameters whose gradients come
+        # out of the scan / conv backward.  in_proj.weight (70 MB) is last either way: it overlaps the dx GEMM (linear.py).
+        model = DDP(block, device_ids=[local_rank], gradient_as_bucket_view=True, bucket_cap_mb=32)
     torch.manual_seed(1234 + rank)             # per-rank synthetic batch (weak scaling: B_LOCAL per GPU)
     u = torch.randn(B_LOCAL, SEQ, D_MODEL, device=dev, dtype=torch.bfloat16)
     dy = torch.randn(B_LOCAL, SEQ, D_MODEL, device=dev, dtype=torch.bfloat16)
