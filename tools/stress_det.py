@@ -8,7 +8,8 @@ from omnimamba_amd.ssd_combined import ssd_scan_fwd, ssd_scan_bwd  # noqa: E402
 dev = torch.device("cuda:0")
 H, P, N, G = 64, 64, 128, 1
 bad = 0
-for (B, L, iters) in [(2, 130, 300), (1, 64, 300), (8, 1024, 100), (8, 4096, 30), (3, 1000, 100)]:
+for (B, L, iters) in [(2, 130, 300), (1, 64, 300), (8, 1024, 100), (8, 4096, 30), (3, 1000, 100),
+                      (1, 2048, 100), (1, 8192, 60), (2, 4096, 60)]:      # the last three: split sequences (state passes + folds)
     torch.manual_seed(B * 1000 + L)
     xBC = torch.randn(B, L, H * P + 2 * G * N, device=dev).bfloat16()
     x = xBC[..., :H * P].view(B, L, H, P)
@@ -36,13 +37,16 @@ for (B, L, iters) in [(2, 130, 300), (1, 64, 300), (8, 1024, 100), (8, 4096, 30)
     refb = None
     for i in range(max(iters // 3, 10)):
         g = ssd_scan_bwd(dout, x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True)
-        dx = g["dx"].clone()
+        cur = (g["dx"].clone(), g["dB"].clone(), g["dC"].clone())
         if refb is None:
-            refb = dx
-        elif not torch.equal(refb, dx):
-            nbad += 1
-            d = (refb.float() - dx.float()).abs()
-            print(f"  dx mismatch B={B} L={L} iter {i}: max {d.max().item():.3e} nnz {(d > 0).sum().item()}", flush=True)
+            refb = cur
+        else:
+            for name, a_, b_ in zip(("dx", "dB", "dC"), refb, cur):
+                if not torch.equal(a_, b_):
+                    nbad += 1
+                    d = (a_.float() - b_.float()).abs()
+                    print(f"  {name} mismatch B={B} L={L} iter {i}: max {d.max().item():.3e} nnz {(d > 0).sum().item()}", flush=True)
+                    break
     print(f"B={B} L={L}: {iters} fwd runs, mismatching runs: {nbad}", flush=True)
     bad += nbad
 print("TOTAL mismatches", bad)
