@@ -148,7 +148,7 @@ def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(130, 2, 1, False, False, None), (70, 4, 2, True, True, None),
-                                                                (200, 2, 1, False, True, 1)])
+                                                                (200, 2, 1, False, True, 1), (330, 4, 2, False, True, 2)])
 def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
     """bf16 MFMA backward (3 scans + finish) vs autograd of the fp32 oracle on identical bf16 inputs.  minc: split the
     sequence of the y and dx scans into segments of that many chunks (see test_ssd_mfma_fwd_split_sequence)."""
