@@ -229,6 +229,17 @@ typedef struct {
 } OmkNormLinear;
 int omk_norm_linear(const OmkNormLinear* p, omk_stream stream);
 
+/* ---- task LoRA of a projection: out += scale * h lora_b^T, in place ------------------------------------------
+ * reference models/stage2/lora.py:263-279 (result += lora_B(lora_A(dropout(x))) * scaling) at training / prefill token counts.
+ * Rank 8 or 16, 16-byte aligned rows; otherwise OMK_EUNSUPPORTED (callers use a GEMM).                              */
+typedef struct {
+  OmkTensor out;     /* (T, N) in place */
+  OmkTensor h;       /* (T, r) = lora_A(dropout(x)), dtype of out */
+  OmkTensor lora_b;  /* (N, r) */
+  float scale;
+} OmkLoraAdd;
+int omk_lora_add(const OmkLoraAdd* p, omk_stream stream);
+
 /* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------
  * upstream mamba_ssm.ops.triton.ssd_combined.mamba_chunk_scan_combined (+ the scan stage of
  * mamba_split_conv1d_scan_combined); reference reach: models/stage2/block.py:117 -> Mamba2.forward              */

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import lora_add as LA
 from . import norm_linear as NL
 from .layer_norm import RMSNorm, layer_norm_fn
 from .linear import linear
@@ -87,7 +88,11 @@ class TaskLoRALinear(nn.Linear):
         out_f = result.shape[-1]
         # (an in-place addmm_ on the base GEMM's output would save the 279 MB copy the out-of-place form starts with, but
         # the library then picks a much slower GEMM: 461 -> 509 ms per 1.3B training step)
-        fused = torch.addmm(result.reshape(-1, out_f), h.reshape(-1, h.shape[-1]), B.weight.t().to(h.dtype), alpha=self.scaling)
+        r2, h2 = result.reshape(-1, out_f), h.reshape(-1, h.shape[-1])
+        if os.environ.get("OMK_LORA_ADDMM") != "1" and r2.data_ptr() == result.data_ptr() and LA.applies(r2, h2, B.weight):
+            # one streaming pass over the result (read once, write once) instead of the library's copy + K = 8 GEMM
+            return LA.lora_add(r2, h2, B.weight, self.scaling).view(result.shape)
+        fused = torch.addmm(r2, h2, B.weight.t().to(h.dtype), alpha=self.scaling)
         return fused.view(result.shape)
 
 

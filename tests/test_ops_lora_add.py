@@ -1,0 +1,34 @@
+"""omk_lora_add (result += scaling * h @ lora_B^T, in place) vs the plain composition, forward and gradients."""
+import pytest
+import torch
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("T,N,R,dtype", [(300, 8512, 8, torch.bfloat16), (70, 264, 16, torch.bfloat16), (33, 96, 8, torch.float32)])
+def test_lora_add(dev, T, N, R, dtype):
+    from omnimamba_amd import lora_add as LA
+    torch.manual_seed(0)
+    res, h = torch.randn(T, N).to(dtype), torch.randn(T, R).to(dtype)
+    Bw = torch.randn(N, R) * 0.1
+    resd = res.clone().to(dev).requires_grad_()
+    hd, Bd = h.clone().to(dev).requires_grad_(), Bw.clone().to(dev).requires_grad_()
+    work = resd * 1.0                                    # a non-leaf buffer the op may overwrite
+    assert LA.applies(work, hd, Bd)
+    out = LA.lora_add(work, hd, Bd, 4.0)
+    ref = res.double() + 4.0 * h.double() @ Bw.double().t()
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert out.dtype == dtype and rel(out, ref) < tol
+    g = torch.randn(T, N).to(dtype)
+    out.backward(g.to(dev))
+    assert rel(resd.grad, g.double()) < 1e-6
+    assert rel(hd.grad, 4.0 * g.double() @ Bw.double()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel(Bd.grad, 4.0 * g.double().t() @ h.double()) < (1e-5 if dtype == torch.float32 else 1e-2) and Bd.grad.dtype == torch.float32
+
+
+def test_lora_add_limits(dev):
+    from omnimamba_amd import lora_add as LA
+    assert not LA.applies(torch.randn(4, 96), torch.randn(4, 4), torch.randn(96, 4))       # rank 4: addmm
+    assert not LA.applies(torch.randn(4, 98).bfloat16(), torch.randn(4, 8).bfloat16(), torch.randn(98, 8))
