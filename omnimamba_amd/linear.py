@@ -44,8 +44,10 @@ def split_factor(m: int, n: int, k: int, device) -> int:
     if eff(1) >= 0.75:
         return 1
     best = 1
-    for s in (2, 4, 8):
-        if k % s or k // s < 2048:
+    # a handful of tiles (the rank-8 LoRA factors: 8 tiles for A) may be cut much finer: slices down to 512 tokens
+    cands, kmin = ((2, 4, 8, 16, 32), 512) if tiles <= 16 else ((2, 4, 8), 2048)
+    for s in cands:
+        if k % s or k // s < kmin:
             break
         best = s
         if eff(s) >= 0.8:

@@ -82,7 +82,7 @@ class TaskLoRALinear(nn.Linear):
             return result
         A = getattr(self, f"{self.task_types}_lora_A0")
         B = getattr(self, f"{self.task_types}_lora_B0")
-        h = A(self.lora_dropout(x))
+        h = linear(self.lora_dropout(x), A.weight) if os.environ.get("OMK_LORA_A_PLAIN") != "1" else A(self.lora_dropout(x))   # token-split dA
         # result + scaling * B(h) as ONE GEMM with a beta = 1 epilogue: the separate scale and add passes over the
         # (tokens, 8512) tensor cost two extra HBM round trips per call (8.7 % of the 1.3B training step)
         out_f = result.shape[-1]
