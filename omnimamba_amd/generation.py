@@ -49,12 +49,18 @@ def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
         _top_p_filter_(vals, top_p)
         pick = torch.multinomial(torch.softmax(vals, dim=-1), num_samples=1).squeeze(-1)
         return idx[torch.arange(idx.shape[0], device=idx.device), pick]
-    work = logits / temperature if temperature != 1.0 else logits.clone()
     if min_p > 0.0:
-        probs = torch.softmax(work, dim=-1)
-        work.masked_fill_(probs < probs.max(dim=-1, keepdim=True)[0] * min_p, float("-inf"))
-    else:
-        _top_p_filter_(work, top_p)
+        # reference generation.py:107-113: the threshold max_prob * min_p (a PROBABILITY at temperature 1) is compared with
+        # the raw LOGITS, the filter is skipped unless 0 < threshold < 1 everywhere, and temperature is applied afterwards
+        work = logits.clone()
+        thr = torch.softmax(work, dim=-1).max(dim=-1, keepdim=True)[0] * min_p
+        if not ((thr <= 0.0).any() or (thr >= 1.0).any()):
+            work.masked_fill_(work < thr, float("-inf"))
+        if temperature != 1.0:
+            work /= temperature
+        return torch.multinomial(torch.softmax(work, dim=-1), num_samples=1).squeeze(-1)
+    work = logits / temperature if temperature != 1.0 else logits.clone()
+    _top_p_filter_(work, top_p)
     return torch.multinomial(torch.softmax(work, dim=-1), num_samples=1).squeeze(-1)
 
 

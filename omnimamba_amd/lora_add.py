@@ -30,14 +30,14 @@ class _LoraAdd(torch.autograd.Function):
     def forward(ctx, result2d, h2d, lora_b, scale):
         lib = get_lib()
         require_device(lib, result2d, h2d, lora_b)
-        # in place on the storage of `result2d`: nothing keeps the base projection's output for backward (its gradient only
-        # needs dy, x and W), so overwriting it is safe; autograd sees an ordinary out-of-place node returning an alias
-        out = result2d.detach()
-        p = K.LoraAdd(out=K.T(out), h=K.T(h2d), lora_b=K.T(lora_b), scale=float(scale))
-        K.run(lib, "omk_lora_add", p, out)
+        # in place on `result2d`, declared to autograd (mark_dirty bumps the version counter): a producer or hook that
+        # saved the base projection's output for its own backward now raises instead of silently reading the sum
+        p = K.LoraAdd(out=K.T(result2d), h=K.T(h2d), lora_b=K.T(lora_b), scale=float(scale))
+        K.run(lib, "omk_lora_add", p, result2d)
+        ctx.mark_dirty(result2d)
         ctx.save_for_backward(h2d, lora_b)
         ctx.scale = float(scale)
-        return out
+        return result2d
 
     @staticmethod
     def backward(ctx, dy):

@@ -110,6 +110,8 @@ class Mamba2(nn.Module):
             if inference_params.seqlen_offset > 0:
                 out, _, _ = self.step(u, conv_state, ssm_state)
                 return out
+            if not torch.is_grad_enabled():
+                self._A_inference()   # prefill: bring the step's persistent -exp(A_log) buffer up to date (graph replays read it)
 
         # a plain nn.Linear in_proj goes through omnimamba_amd.linear (same forward GEMM, token-split weight gradient);
         # any replacement module (the reference's LoRA wrapper) is simply called
@@ -158,15 +160,26 @@ class Mamba2(nn.Module):
         return self.out_proj(y)
 
     def _A_inference(self):
-        """-exp(A_log), cached between optimizer updates when autograd is off (two tiny launches per layer-step otherwise)."""
+        """-exp(A_log) for the decode step.  ONE persistent buffer per module, refreshed IN PLACE when A_log's version
+        moved: a captured hipGraph of the step bakes the buffer's address, so an in-place refresh (every prefill passes
+        through here, see forward) keeps replays valid after optimizer steps / load_state_dict into the same model --
+        the reference recomputes A inside the graph (generation.py:372-434 captures the whole step).  While a capture is
+        in progress nothing is allocated or refreshed: a missing or stale buffer is replaced by an in-graph recompute."""
         if torch.is_grad_enabled() and self.A_log.requires_grad:
             return -torch.exp(self.A_log.float())
-        c = getattr(self, "_A_cache", None)
-        if c is None or c[0] != self.A_log._version or c[1].device != self.A_log.device:
-            with torch.no_grad():
-                c = (self.A_log._version, -torch.exp(self.A_log.float()))
-            self._A_cache = c
-        return c[1]
+        buf, ver = getattr(self, "_A_buf", None), getattr(self, "_A_ver", None)
+        fresh = buf is not None and ver == self.A_log._version and buf.device == self.A_log.device
+        if fresh:
+            return buf
+        if self.A_log.is_cuda and torch.cuda.is_current_stream_capturing():
+            return -torch.exp(self.A_log.float())
+        with torch.no_grad():
+            if buf is None or buf.device != self.A_log.device or buf.shape != self.A_log.shape:
+                with torch.inference_mode(False):   # a normal tensor: later refreshes may come from outside inference_mode
+                    self._A_buf = buf = torch.empty(self.A_log.shape, dtype=torch.float32, device=self.A_log.device)
+            buf.copy_(-torch.exp(self.A_log.float()))
+        self._A_ver = self.A_log._version
+        return buf
 
     def step(self, hidden_states, conv_state, ssm_state):
         """hidden_states: (batch, 1, d_model); both states updated in place. -> (out (batch, 1, d_model), conv, ssm)"""

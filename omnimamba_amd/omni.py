@@ -1,0 +1,137 @@
+"""The callers either side of the path: sequence construction and losses of the top-level model, restated for the
+synthetic BASELINE configs 4 / 5 and for checkpoint compatibility (reference
+/root/reference/models/omnimamba.py:49-337, models/mamba_vlm.py:88-108).
+
+Only what drives the Mamba-2 path is here: projector MLP, embedding of the two task sequences, position tables, shifted
+cross-entropy, greedy T2I generation.  The frozen vision towers and the VQ-VAE are inputs / outputs of the path and are
+replaced by synthetic tensors: ``images_feat`` (B, 729, 2176) stands for ``vision_backbone(pixel_values)`` and the 256
+sampled codes are returned instead of ``vqvae.decode_code`` (out of scope).
+
+State-dict keys: ``llm_backbone.mamba.*`` and ``projector.projector.{0,2,4}.*`` exactly as ``OmniMamba.state_dict()``
+writes them; ``load_reference_state_dict`` drops the ``vision_backbone.`` / ``llm_backbone.vqvae.`` entries of a full
+checkpoint (omnimamba.py:88-103) and loads everything else strictly.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .generation import decode
+from .stack import FusedMLPProjector, OmniMambaLM, StackConfig
+
+IGNORE_ID = -100     # UniversalPrompting(ignore_id=-100), mamba_vlm.py:33-38
+# ids the gpt-neox-20b tokenizer (50277 entries) hands out when [PAD] and the nine special tokens are appended in the
+# order of mamba_vlm.py:33-37 / prompting_utils.py:24-27 -- they land inside the 50288 padded rows
+SPECIAL_IDS = {"[PAD]": 50277, "<|soi|>": 50278, "<|eoi|>": 50279, "<|sot|>": 50280, "<|eot|>": 50281, "<|t2i|>": 50282,
+               "<|mmu|>": 50283, "<|soc|>": 50284, "<|eoc|>": 50285, "<|lvg|>": 50286}
+
+
+class _LLMBackbone(nn.Module):
+    """Holder that gives the stack the reference's attribute path ``llm_backbone.mamba`` (models/mamba_vlm.py:14-24)."""
+
+    def __init__(self, cfg: StackConfig, device=None, dtype=None):
+        super().__init__()
+        self.mamba = OmniMambaLM(cfg, device=device, dtype=dtype)
+        self.d_model, self.num_tokens = cfg.d_model, cfg.num_tokens
+
+    def embed_input_ids(self, input_ids):
+        return self.mamba.get_input_embeddings()(input_ids)
+
+
+def shifted_ce(hidden, head_weight, labels, loss_impl=None):
+    """mamba_vlm.py:88-102 + omnimamba.py:276-279,305-306: logits[..., :-1, :] against labels[..., 1:], mean over the
+    labels that are not -100.  ``loss_impl(hidden2d, weight, labels1d)`` may replace the materialised-logits form."""
+    h = hidden[:, :-1].reshape(-1, hidden.shape[-1])
+    t = labels[:, 1:].reshape(-1)
+    if loss_impl is not None:
+        return loss_impl(h, head_weight, t)
+    return F.cross_entropy(F.linear(h, head_weight.to(h.dtype)).float(), t, ignore_index=IGNORE_ID)
+
+
+class OmniMambaPath(nn.Module):
+    def __init__(self, cfg: StackConfig, stage: str = "finetune", special_ids=None, device=None, dtype=None, loss_impl=None):
+        super().__init__()
+        self.cfg = cfg
+        self.llm_backbone = _LLMBackbone(cfg, device=device, dtype=dtype)
+        if cfg.mmu_task:
+            self.projector = FusedMLPProjector(cfg.fused_vision_dim, cfg.d_model, device=device, dtype=dtype)
+        self.special_ids = dict(SPECIAL_IDS if special_ids is None else special_ids)
+        self.loss_impl = loss_impl
+        self.set_stage(stage)
+
+    # ---- which parameters train (omnimamba.py:119-188)
+    def set_stage(self, stage):
+        if stage == "inference":
+            self.eval()
+            self.requires_grad_(False)
+            return
+        self.train()
+        self.llm_backbone.mamba.set_stage(stage)
+        if self.cfg.mmu_task:
+            self.projector.requires_grad_(True)       # trained in both 'align' and 'finetune'
+        if stage == "align":
+            self.llm_backbone.mamba.eval()            # llm_backbone.eval(): dropouts off ...
+            for n, m in self.llm_backbone.mamba.named_modules():
+                if "lora" in n.lower() or (self.cfg.t2i_task and ("img_embeddings" in n or "caption_embed" in n or n == "img_head")):
+                    m.train()                         # ... except the modules the stage trains (:137-151)
+
+    @property
+    def backbone(self):
+        return self.llm_backbone.mamba.backbone
+
+    def load_reference_state_dict(self, state_dict, strict=True):
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith("vision_backbone.") or k.startswith("llm_backbone.vqvae."))}
+        return self.load_state_dict(sd, strict=strict)
+
+    # ---- sequence construction (omnimamba.py:190-218,253-307)
+    def _sp(self, name, like):
+        return torch.full((like.shape[0], 1), self.special_ids[name], dtype=torch.long, device=like.device)
+
+    def t2i_sequence(self, image_ids, caption_ids):
+        bb = self.backbone
+        img = bb.img_embeddings(image_ids)
+        txt = bb.caption_embed(self.llm_backbone.embed_input_ids(caption_ids), train=True)
+        emb = torch.cat((txt[:, :-1], img, txt[:, -1:]), dim=1)
+        ign = lambda n: torch.full((image_ids.shape[0], n), IGNORE_ID, dtype=torch.long, device=image_ids.device)
+        labels = torch.cat([ign(caption_ids.shape[1] - 1), image_ids, ign(1)], dim=1)
+        return emb + bb.pos_embed[:, : emb.shape[1]], labels
+
+    def mmu_sequence(self, images_feat, input_ids, labels):
+        """images_feat None = a text-only batch: zero image embeddings of img_sq_len positions (omnimamba.py:222-250)."""
+        ids = torch.cat([self._sp("<|mmu|>", input_ids), self._sp("<|soi|>", input_ids), self._sp("<|eoi|>", input_ids),
+                         self._sp("<|sot|>", input_ids), input_ids], dim=1)
+        txt = self.llm_backbone.embed_input_ids(ids)
+        if images_feat is not None:
+            img = self.projector(images_feat)
+        else:
+            img = torch.zeros(ids.shape[0], self.backbone.img_sq_len, txt.shape[-1], device=txt.device, dtype=txt.dtype)
+        emb = torch.cat((txt[:, :2], img.to(txt.dtype), txt[:, 2:]), dim=1)
+        ign = lambda n: torch.full((ids.shape[0], n), IGNORE_ID, dtype=torch.long, device=ids.device)
+        return emb, torch.cat([ign(2), ign(img.shape[1]), ign(2), labels.to(ids.device)], dim=1)
+
+    def forward(self, inputs, task="t2i"):
+        """inputs: {'t2i_flow': {'inputs': image ids (B, n_img), 'caption_ids': (B, Lc)},
+                    'mmu_flow': {'images_feat': (B, 729, 2176) | None, 'input_ids': (B, T), 'labels': (B, T)}} -> loss."""
+        lm = self.llm_backbone.mamba
+        if task == "t2i":
+            f = inputs["t2i_flow"]
+            emb, labels = self.t2i_sequence(f["inputs"], f["caption_ids"])
+            hidden = lm.backbone(None, emb, None, "t2i")
+            return shifted_ce(hidden, lm.img_head.weight, labels, self.loss_impl)
+        f = inputs["mmu_flow"]
+        emb, labels = self.mmu_sequence(f.get("images_feat"), f["input_ids"], f["labels"])
+        hidden = lm.backbone(None, emb, None, "mmu")
+        return shifted_ce(hidden, lm.lm_head.weight, labels, self.loss_impl)
+
+    # ---- T2I generation (omnimamba.py:311-337 minus the VQ decode tail)
+    @torch.no_grad()
+    def t2i_generate(self, text_ids, temperature=1.0, top_k=0, top_p=1.0, fast=True):
+        bb = self.backbone
+        emb = bb.caption_embed(self.llm_backbone.embed_input_ids(text_ids), train=False)
+        emb = emb + bb.pos_embed[:, : emb.shape[1]]
+        max_length = self.llm_backbone.num_tokens + emb.shape[1]
+        x = decode(text_ids, emb, self.llm_backbone.mamba, max_length, top_k=top_k, top_p=top_p, temperature=temperature,
+                   cg=fast, task="t2i")
+        self.llm_backbone.mamba._decoding_cache = None
+        return x[: text_ids.shape[0], emb.shape[1]:]

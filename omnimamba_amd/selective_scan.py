@@ -29,8 +29,9 @@ class SelectiveScanFn(torch.autograd.Function):
         out = torch.empty_like(u)
         Bsz, Dm, L = u.shape
         last = torch.empty(Bsz, Dm, A.shape[1], dtype=torch.float32, device=u.device) if return_last_state else None
+        Af = A.float() if A.dtype != torch.float32 else A     # bound to a local: the kernel reads it after this line
         if u.numel() > 0:
-            p = K.SelScanFwd(u=K.T(u), delta=K.T(delta), A=K.T(A.float() if A.dtype != torch.float32 else A), Bm=K.T(B4),
+            p = K.SelScanFwd(u=K.T(u), delta=K.T(delta), A=K.T(Af), Bm=K.T(B4),
                              Cm=K.T(C4), D=K.T(D), z=K.T(z), delta_bias=K.T(delta_bias), out=K.T(out),
                              last_state=K.T(last), delta_softplus=int(delta_softplus))
             K.run(lib, "omk_selective_scan_fwd", p, u)

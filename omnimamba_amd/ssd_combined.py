@@ -224,7 +224,7 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         dev, adt = zxbcdt.device, zxbcdt.dtype
         use_norm = norm_w is not None
         z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
-        dzxbcdt = torch.empty_like(zxbcdt)
+        dzxbcdt = torch.empty(zxbcdt.shape, dtype=adt, device=dev)   # always batch-major dense (empty_like would keep a permuted layout)
         dz, dxBC, ddt_v = torch.split(dzxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
         # ---- out_proj: its wgrad needs the norm output (kept, or recomputed when OMK_RECOMPUTE=1)
         dout = dout.to(adt)

@@ -4,8 +4,12 @@ a1, a3; reference: /root/reference/models/stage2/{block.py, lora.py, mixer_seq_s
 Not a port of OmniMamba: only what drives the Mamba-2 path -- token / image-token embeddings, N x [fused add+RMSNorm ->
 Mamba2 (in_proj wrapped by the task-switched LoRA)], final fused norm, the two tied heads.  Vision towers, VQ-VAE,
 tokenizer and captions are inputs of the path and are replaced by synthetic tensors.
-State-dict keys of the mixer/norm parts match the reference (`backbone.layers.{i}.mixer.*`, `backbone.layers.{i}.norm.weight`,
-`backbone.norm_f.weight`) so real checkpoints can replace the random init later (section 8f-4).
+State-dict keys match the reference's MambaLMHeadModel KEY FOR KEY (`backbone.{embedding, img_embeddings.word_embeddings,
+img_embeddings.project_in.projector.{0,2,4}, pos_embed, caption_embed.cap_proj.{fc1,fc2}, mmu_pos_embed, layers.{i}.norm,
+layers.{i}.mixer.*, norm_f}`, `lm_head`, `img_head`; mixer_seq_simple.py:296-304,353,484-502) so that
+`OmniMamba-1.3b.pth` / `mamba2-1.3b` checkpoints load with strict=True (section 8f-4; tests/test_reference_fixtures.py
+loads a state dict written by the reference's own classes).  `omnimamba_amd.omni.OmniMambaPath` adds the projector and the
+`llm_backbone.mamba.` prefix of the top-level checkpoint (models/omnimamba.py:88-103).
 """
 from __future__ import annotations
 
@@ -45,6 +49,9 @@ class StackConfig:
     lora_dropout: float = 0.05
     t2i_task: bool = True
     mmu_task: bool = True
+    token_drop: float = 0.0                # GPT2Embeddings token dropout (config_mamba.py:34)
+    img_sq_len: int = 729                  # SigLIP + DINOv2 patch tokens (mixer_seq_simple.py:305)
+    fused_vision_dim: int = 2176           # DINOv2-L 1024 + SigLIP-so400m 1152 (dinosiglip_vit.py:37-160)
 
     @staticmethod
     def omnimamba_1_3b(**kw):
@@ -54,6 +61,58 @@ class StackConfig:
     def padded_vocab(self):
         m = self.pad_vocab_size_multiple
         return self.vocab_size + (-self.vocab_size) % m
+
+
+class FusedMLPProjector(nn.Module):
+    """Linear(in, 4 in) -> GELU -> Linear(4 in, out) -> GELU -> Linear(out, out), all with bias
+    (reference models/cobra/nn_utils.py:38-54; parameter names `projector.{0,2,4}.{weight,bias}`)."""
+
+    def __init__(self, fused_vision_dim, llm_dim, device=None, dtype=None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.initial_projection_dim = fused_vision_dim * 4
+        self.projector = nn.Sequential(nn.Linear(fused_vision_dim, self.initial_projection_dim, bias=True, **fk), nn.GELU(),
+                                       nn.Linear(self.initial_projection_dim, llm_dim, bias=True, **fk), nn.GELU(),
+                                       nn.Linear(llm_dim, llm_dim, bias=True, **fk))
+
+    def forward(self, fused_img_patches):
+        return self.projector(fused_img_patches)
+
+
+class ImageTokenEmbeddings(nn.Module):
+    """VQ image-token embedding = table lookup + FusedMLPProjector(d, d) (reference GPT2Embeddings built with
+    max_position_embeddings = -1 and word_embed_proj_dim = d_model, mixer_seq_simple.py:36-89,297)."""
+
+    def __init__(self, d_model, vocab_size, token_drop=0.0, device=None, dtype=None):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab_size, d_model, device=device, dtype=dtype)
+        self.project_in = FusedMLPProjector(d_model, d_model, device=device, dtype=dtype)
+        self.token_dropout = nn.Dropout(token_drop)
+
+    def forward(self, input_ids, position_ids=None):
+        return self.project_in(self.token_dropout(self.word_embeddings(input_ids)))
+
+
+class CaptionEmbedder(nn.Module):
+    """fc1 -> GELU(tanh) -> fc2 without biases on the caption embeddings (mixer_seq_simple.py:124-164)."""
+
+    class _MLP(nn.Module):
+        def __init__(self, d, device=None, dtype=None):
+            super().__init__()
+            self.fc1 = nn.Linear(d, d, bias=False, device=device, dtype=dtype)
+            self.act = nn.GELU(approximate="tanh")
+            self.fc2 = nn.Linear(d, d, bias=False, device=device, dtype=dtype)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    def __init__(self, in_channels, hidden_size, device=None, dtype=None):
+        super().__init__()
+        assert in_channels == hidden_size
+        self.cap_proj = CaptionEmbedder._MLP(hidden_size, device=device, dtype=dtype)
+
+    def forward(self, caption, train=False, force_drop_ids=None):
+        return self.cap_proj(caption)
 
 
 class TaskLoRALinear(nn.Linear):
@@ -158,27 +217,36 @@ class ResidualBlock(nn.Module):
 
 
 class MixerStack(nn.Module):
+    """The reference's MixerModel (mixer_seq_simple.py:265-440) without the dead adaLN branches."""
+
     def __init__(self, cfg: StackConfig, device=None, dtype=None):
         super().__init__()
         fk = {"device": device, "dtype": dtype}
         self.cfg = cfg
         d = cfg.d_model
-        self.embedding = nn.Embedding(cfg.padded_vocab, d, **fk)
+        self.t2i_task, self.mmu_task = cfg.t2i_task, cfg.mmu_task
+        self.img_sq_len = cfg.img_sq_len
         if cfg.t2i_task:
-            self.img_embeddings = nn.Embedding(cfg.vqvae_vocab_size, d, **fk)
+            self.img_embeddings = ImageTokenEmbeddings(d, cfg.vqvae_vocab_size, token_drop=cfg.token_drop, **fk)
             self.pos_embed = nn.Parameter(nn.init.trunc_normal_(torch.zeros(1, cfg.t2i_positions, d, **fk), 0.0, 0.02))
+            self.caption_embed = CaptionEmbedder(d, d, **fk)
         if cfg.mmu_task:
             self.mmu_pos_embed = nn.Parameter(nn.init.trunc_normal_(torch.zeros(1, cfg.mmu_positions, d, **fk), 0.0, 0.02))
+        self.embedding = nn.Embedding(cfg.padded_vocab, d, **fk)
         self.layers = nn.ModuleList([ResidualBlock(d, i, cfg, **fk) for i in range(cfg.n_layer)])
         self.norm_f = RMSNorm(d, eps=cfg.norm_epsilon, **fk)
-        # reference _init_weights (mixer_seq_simple.py:233-262): embeddings N(0, 0.02), out_proj / sqrt(n_layer)
-        nn.init.normal_(self.embedding.weight, std=0.02)
-        if cfg.t2i_task:
-            nn.init.normal_(self.img_embeddings.weight, std=0.02)
-        for blk in self.layers:
-            nn.init.kaiming_uniform_(blk.mixer.out_proj.weight, a=math.sqrt(5))
-            with torch.no_grad():
-                blk.mixer.out_proj.weight /= math.sqrt(cfg.n_layer)
+        # reference _init_weights (mixer_seq_simple.py:233-262): Linear biases zero, embeddings N(0, 0.02),
+        # out_proj.weight and fc2.weight kaiming-uniform / sqrt(n_layer)
+        for m in self.modules():
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, std=0.02)
+        for n, p in self.named_parameters():
+            if n.endswith("out_proj.weight") or n.endswith("fc2.weight"):
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                with torch.no_grad():
+                    p /= math.sqrt(cfg.n_layer)
         # reference _find_and_replace (lora.py:78-112): every mixer.in_proj becomes the task-switched LoRA Linear that
         # shares the base weight tensor
         for blk in self.layers:
@@ -198,12 +266,14 @@ class MixerStack(nn.Module):
         return {i: blk.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs) for i, blk in enumerate(self.layers)}
 
     def forward(self, input_ids, input_embeddings, position_ids=None, task="t2i", inference_params=None):
-        """Training / prefill: ``input_embeddings`` (B, L, d) given.  Decode: ``input_ids`` (B, 1) + ``position_ids``
-        (reference MixerModel.forward, mixer_seq_simple.py:375-440, minus the dead adaLN branches)."""
+        """Training / prefill: ``input_embeddings`` (B, L, d) given -- for 'mmu' the position table is added here when
+        ``position_ids`` is None, for 't2i' the CALLER has added ``pos_embed`` (reference omnimamba.py:264,319-320).
+        Decode: ``input_ids`` (B, 1) + ``position_ids`` (reference MixerModel.forward, mixer_seq_simple.py:375-440)."""
         self.set_lora_mode(task)
         if input_embeddings is not None:
-            h = input_embeddings     # the reference adds the position table in OmniMamba.forward (omnimamba.py:264 / mixer_seq_simple.py:386)
-            h = h + (self.mmu_pos_embed if task == "mmu" else self.pos_embed)[:, : h.shape[1]]
+            h = input_embeddings
+            if task == "mmu" and position_ids is None:
+                h = h + self.mmu_pos_embed[:, : h.shape[1]]
         else:
             if task == "t2i":
                 h = self.img_embeddings(input_ids)
@@ -226,12 +296,20 @@ class OmniMambaLM(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.backbone = MixerStack(cfg, device=device, dtype=dtype)
-        self.lm_head = nn.Linear(cfg.d_model, cfg.padded_vocab, bias=False, device=device, dtype=dtype)
-        self.lm_head.weight = self.backbone.embedding.weight
         if cfg.t2i_task:
             self.img_head = nn.Linear(cfg.d_model, cfg.vqvae_vocab_size, bias=False, device=device, dtype=dtype)
-            self.img_head.weight = self.backbone.img_embeddings.weight
+        self.lm_head = nn.Linear(cfg.d_model, cfg.padded_vocab, bias=False, device=device, dtype=dtype)
+        self.tie_weights()
         self._decoding_cache = None
+
+    def tie_weights(self):
+        """mixer_seq_simple.py:498-502: both heads share their embedding tables."""
+        if self.cfg.t2i_task:
+            self.img_head.weight = self.backbone.img_embeddings.word_embeddings.weight
+        self.lm_head.weight = self.backbone.embedding.weight
+
+    def get_input_embeddings(self):
+        return self.backbone.embedding
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.backbone.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
@@ -245,13 +323,27 @@ class OmniMambaLM(nn.Module):
                               mmu_logits=self.lm_head(h) if task == "mmu" else None)
 
     def set_stage(self, stage: str):
-        """Which parameters train (reference omnimamba.py:119-188): 'align' = LoRA adapters (+ embeddings of the new
-        modality), 'finetune' = everything in the Mamba stack."""
+        """Which parameters train (reference omnimamba.py:119-188).  'align': the stack is frozen except -- with the T2I
+        task -- img_embeddings, embedding, pos_embed, caption_embed, img_head, and the LoRA adapters; 'finetune':
+        everything (mamba.requires_grad_(True) overrides the LoRA base-weight freeze, Appendix C of SURVEY.md).
+        Deviation (SURVEY.md hard parts): adapters of a task the model is not configured for stay frozen, because DDP with
+        find_unused_parameters=False (train_stage2.py:38) cannot carry parameters that never receive a gradient."""
         if stage == "finetune":
             for p in self.parameters():
                 p.requires_grad_(True)
         elif stage == "align":
+            tasks = [t for t, on in (("t2i", self.cfg.t2i_task), ("mmu", self.cfg.mmu_task)) if on]
             for n, p in self.named_parameters():
-                p.requires_grad_("lora" in n or "img_embeddings" in n or "pos_embed" in n)
+                on = any(f"{t}_lora_" in n for t in tasks)
+                if self.cfg.t2i_task and (n.startswith("backbone.img_embeddings.") or n == "backbone.embedding.weight"
+                                          or n == "backbone.pos_embed" or n.startswith("backbone.caption_embed.")
+                                          or n == "img_head.weight" or n == "lm_head.weight"):
+                    on = True
+                p.requires_grad_(on)
         else:
             raise ValueError(stage)
+        for t, on in (("t2i", self.cfg.t2i_task), ("mmu", self.cfg.mmu_task)):
+            if not on:
+                for n, p in self.named_parameters():
+                    if f"{t}_lora_" in n:
+                        p.requires_grad_(False)

@@ -14,7 +14,6 @@ import os
 from dataclasses import dataclass
 
 import torch
-import torch.nn.functional as F
 
 
 @dataclass
@@ -62,13 +61,11 @@ def wrap_ddp(model, cfg: TrainConfig, device_ids=None):
                broadcast_buffers=False)
 
 
-def lm_loss(logits, labels):
-    """Shift-by-one cross entropy (reference models/mamba_vlm.py:88-102); labels == -100 are ignored."""
-    return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), labels[:, 1:].reshape(-1), ignore_index=-100)
-
-
 class Stage2Step:
-    """loss = t2i_loss + mmu_loss from two forwards, one backward, clip, AdamW, cosine LR (trainer.py:113-127)."""
+    """loss = model(inputs, 't2i') + model(inputs, 'mmu') from two forwards, one backward, clip, AdamW, cosine LR
+    (trainer.py:113-127; HF Trainer defaults of train_stage2.py:16-44).  ``model`` is omnimamba_amd.omni.OmniMambaPath
+    (forward(inputs, task) -> loss, like the reference's OmniMamba.forward); a batch holding only one of the two flows
+    runs the stage-1 single-task step."""
 
     def __init__(self, model, cfg: TrainConfig, ddp_model=None):
         self.model, self.cfg = model, cfg
@@ -87,13 +84,10 @@ class Stage2Step:
         total = 0.0
         with torch.autocast(dev_type, dtype=self.cfg.amp_dtype, enabled=self.cfg.amp_dtype != torch.float32):
             for task in ("t2i", "mmu"):
-                if task not in batch:
+                if f"{task}_flow" not in batch:
                     continue
-                emb, labels = batch[task]
-                out = self.net(None, emb, task=task)
-                logits = out.t2i_logits if task == "t2i" else out.mmu_logits
-                loss = lm_loss(logits, labels)
-                self.last[task] = loss.detach()
+                loss = self.net(batch, task)
+                self.last[task] = loss.detach()      # logged from the device scalar: no per-step .item() (trainer.py:122-125)
                 total = total + loss
         total.backward()
         if self.cfg.clip:
@@ -103,13 +97,32 @@ class Stage2Step:
         return total.detach()
 
 
-def synthetic_batch(cfg, batch, seqlen, device, dtype, rank=0, tasks=("t2i", "mmu"), step=0):
-    """Synthetic embeddings + labels of the reference shapes: seeds = 1234 + rank."""
+def synthetic_batch(cfg, batch, seqlen, device, dtype, rank=0, tasks=("t2i", "mmu"), step=0, caption_len=73):
+    """Synthetic inputs of the reference shapes, total sequence length ``seqlen`` per task:
+      t2i_flow: caption ids (B, caption_len) ~ U[0, vocab), image ids (B, seqlen - caption_len) ~ U[0, vq vocab)
+                (reference: 73 + 256 = 329, omnimamba.py:264);
+      mmu_flow: images_feat ~ N(0, 1) (B, img_sq_len, fused_vision_dim) standing for the frozen vision towers' output,
+                text ids (B, seqlen - img_sq_len - 4) ~ U[0, vocab), labels = ids (reference: 4 + 729 + 449, :190-218).
+    Seeds = 1234 + rank (DistributedSampler-style per-rank shards, trainer.py:50-56,79-85)."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank + 1000003 * step)
     out = {}
-    for task in tasks:
-        vocab = cfg.vqvae_vocab_size if task == "t2i" else cfg.vocab_size
-        emb = torch.randn(batch, seqlen, cfg.d_model, generator=g).to(device=device, dtype=dtype)
-        labels = torch.randint(0, vocab, (batch, seqlen), generator=g).to(device)
-        out[task] = (emb, labels)
+    if "t2i" in tasks:
+        n_img = seqlen - caption_len
+        assert n_img > 0
+        out["t2i_flow"] = {"caption_ids": torch.randint(0, cfg.vocab_size, (batch, caption_len), generator=g).to(device),
+                           "inputs": torch.randint(0, cfg.vqvae_vocab_size, (batch, n_img), generator=g).to(device)}
+    if "mmu" in tasks:
+        n_txt = seqlen - cfg.img_sq_len - 4
+        assert n_txt > 0
+        ids = torch.randint(0, cfg.vocab_size, (batch, n_txt), generator=g).to(device)
+        out["mmu_flow"] = {"images_feat": torch.randn(batch, cfg.img_sq_len, cfg.fused_vision_dim, generator=g).to(device=device, dtype=dtype),
+                           "input_ids": ids, "labels": ids.clone()}
     return out
+
+
+def shard_batch(batch, rank, world):
+    """Rows [rank * B / world, (rank + 1) * B / world) of every tensor in a synthetic batch."""
+    def cut(t):
+        n = t.shape[0] // world
+        return t[rank * n:(rank + 1) * n]
+    return {flow: {k: (cut(v) if torch.is_tensor(v) else v) for k, v in d.items()} for flow, d in batch.items()}

@@ -7,6 +7,11 @@ own Python from /root/reference, which never travels to the GPU box):
                        eval mode) -- pins omnimamba_amd.stack.TaskLoRALinear
   oracle_ops.npz       seeded input/output vectors of the CPU oracle for every op on the path (fp32) -- pins the oracle
                        against drift and is what the HIP kernels are compared with in tests/test_golden.py
+  reference_model.npz  the reference's UNMODIFIED models/stage2/{block.py, lora.py, mixer_seq_simple.py, generation.py}
+                       instantiated and run here on the oracle-backed `mamba_ssm` provider (oracle/provider.py -- plain
+                       PyTorch, no kernel under test): state dict of a 2-layer MambaLMHeadModel, Block.forward
+                       (hidden, residual), logits of both tasks, and the greedy generate() id sequence with the
+                       (seqlen_offset, position_ids) trace of every model call (SURVEY.md section 8c ii-iv)
 """
 import importlib.util
 import os
@@ -91,7 +96,83 @@ def oracle_ops():
     np.savez_compressed(os.path.join(HERE, "oracle_ops.npz"), **out)
 
 
+def reference_model():
+    """captures from the reference's own classes.  `transformers` 5.x dropped the two
+    output classes generation.py:16 imports (the reference pins 4.46.1): they are injected as plain containers."""
+    import oracle.provider as P
+    import transformers.generation as TG
+    sys.path.insert(0, "/root/reference")
+    P.install()
+
+    class _Out:
+        def __init__(self, sequences=None, scores=None):
+            self.sequences, self.scores = sequences, scores
+    for n in ("GreedySearchDecoderOnlyOutput", "SampleDecoderOnlyOutput"):
+        if not hasattr(TG, n):
+            setattr(TG, n, _Out)
+    from models.stage2.config_mamba import MambaConfig
+    from models.stage2.mixer_seq_simple import MambaLMHeadModel
+
+    torch.manual_seed(20260928)
+    cfg = MambaConfig(d_model=32, n_layer=2, vqvae_vocab_size=40, num_tokens=8, vocab_size=50,
+                      ssm_cfg={"layer": "Mamba2", "d_state": 16, "headdim": 8, "chunk_size": 16}, t2i_task=True, mmu_task=True)
+    model = MambaLMHeadModel(cfg)
+    model.eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn_like(p) * 0.05)          # zero-initialised upstream: make both adapters visible
+        model.backbone.img_embeddings.word_embeddings.weight.mul_(30.0)   # well separated logits: robust argmax
+        model.backbone.embedding.weight.mul_(6.0)
+    out = {"sd." + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    out["cfg"] = np.array([32, 2, 40, 8, 50, 16, 8, 16])   # d_model, n_layer, vq vocab, num_tokens, vocab, d_state, headdim, chunk
+
+    # (ii) Block.forward: first block (residual None) and second block (fp32 residual in)
+    h = torch.randn(2, 11, 32)
+    with torch.no_grad():
+        model.backbone.set_lora_mode("mmu")
+        h1, r1 = model.backbone.layers[0](h, None, None, task="mmu")
+        h2, r2 = model.backbone.layers[1](h1, r1, None, task="mmu")
+    out.update({"block.h": h.numpy(), "block.h1": h1.numpy(), "block.r1": r1.numpy(), "block.h2": h2.numpy(), "block.r2": r2.numpy()})
+
+    # (iv) MambaLMHeadModel logits, both tasks (layer order, LoRA switch, final norm, tied heads)
+    emb = torch.randn(2, 19, 32)
+    with torch.no_grad():
+        out["fwd.emb"] = emb.numpy()
+        out["fwd.t2i_logits"] = model(None, emb, task="t2i").t2i_logits.numpy()
+        out["fwd.mmu_logits"] = model(None, emb, task="mmu").mmu_logits.numpy()
+
+    # (iii) greedy generate(): ids + the integer trace of every model call
+    for task, Bsz, Pn, max_len in (("t2i", 2, 5, 5 + 8), ("mmu", 1, 7, 16)):
+        trace = []
+        orig = model.backbone.forward
+
+        def spy(input_ids, input_embeddings, position_ids, cond, task, inference_params=None, **kw):
+            trace.append((inference_params.seqlen_offset, -1 if position_ids is None else int(position_ids[0, 0]),
+                          -1 if input_ids is None else int(input_ids.shape[1])))
+            return orig(input_ids, input_embeddings, position_ids, cond, task, inference_params=inference_params, **kw)
+        model.backbone.forward = spy
+        ids = torch.zeros(Bsz, Pn, dtype=torch.long)
+        pemb = torch.randn(Bsz, Pn, 32)
+        res = model.generate(input_ids=ids, input_embeddings=pemb, cond=None, max_length=max_len, temperature=1.0, top_p=0.0,
+                             top_k=1, cg=False, task=task, return_dict_in_generate=True, output_scores=True)
+        model.backbone.forward = orig
+        out.update({f"gen.{task}.prompt_emb": pemb.numpy(), f"gen.{task}.sequences": res.sequences.numpy(),
+                    f"gen.{task}.trace": np.array(trace, dtype=np.int64), f"gen.{task}.max_length": np.array(max_len),
+                    f"gen.{task}.scores": torch.stack(res.scores, 1).numpy()})
+        top2 = torch.stack(res.scores, 1).topk(2, dim=-1).values
+        print(task, "ids", res.sequences.tolist(), "min top-1/top-2 logit margin", float((top2[..., 0] - top2[..., 1]).min()))
+    np.savez_compressed(os.path.join(HERE, "reference_model.npz"), **out)
+    print("reference_model.npz:", {k: v.shape for k, v in out.items() if not k.startswith("sd.")})
+    print("state dict keys:", [k[3:] for k in out if k.startswith("sd.")])
+
+
 if __name__ == "__main__":
-    lora_reference()
-    oracle_ops()
+    which = sys.argv[1:] or ["lora", "ops", "model"]
+    if "lora" in which:
+        lora_reference()
+    if "ops" in which:
+        oracle_ops()
+    if "model" in which:
+        reference_model()
     print(os.listdir(HERE))

@@ -19,7 +19,16 @@ def rel(a, b):
 def tiny_cfg():
     from omnimamba_amd.stack import StackConfig
     return StackConfig(d_model=32, n_layer=2, vocab_size=50, pad_vocab_size_multiple=16, vqvae_vocab_size=40, num_tokens=8,
-                       t2i_positions=24, mmu_positions=40, ssm_cfg=dict(d_state=16, headdim=8, chunk_size=16), lora_dropout=0.0)
+                       t2i_positions=24, mmu_positions=40, ssm_cfg=dict(d_state=16, headdim=8, chunk_size=16), lora_dropout=0.0,
+                       img_sq_len=5, fused_vision_dim=12)
+
+
+TINY_SPECIAL = {"<|soi|>": 51, "<|eoi|>": 52, "<|sot|>": 53, "<|mmu|>": 56}   # inside the 64 padded rows of the toy vocabulary
+
+
+def tiny_path(stage="finetune"):
+    from omnimamba_amd.omni import OmniMambaPath
+    return OmniMambaPath(tiny_cfg(), stage=stage, special_ids=TINY_SPECIAL)
 
 
 def test_lora_matches_reference_golden():
@@ -68,7 +77,7 @@ def test_greedy_decode_trace_and_tokens(dev):
     cfg = tiny_cfg()
     model = OmniMambaLM(cfg).to(dev).eval()
     with torch.no_grad():
-        model.backbone.img_embeddings.weight.mul_(30.0)   # make logits well separated so argmax is robust
+        model.backbone.img_embeddings.word_embeddings.weight.mul_(30.0)   # make logits well separated so argmax is robust
     B, Pn, max_len = 2, 5, 12
     prompt_ids = torch.zeros(B, Pn, dtype=torch.long, device=dev)
     prompt_emb = torch.randn(B, Pn, 32).to(dev)
@@ -79,7 +88,9 @@ def test_greedy_decode_trace_and_tokens(dev):
     # teacher-forced full forward over the generated ids reproduces every greedy choice
     toks = seqs[:, Pn:]
     with torch.no_grad():
-        emb_gen = model.backbone.img_embeddings(toks[:, :-1])     # the stack adds pos_embed[:, :L] itself
+        # decode steps add pos_embed[position] to the image-token embeddings; the prompt embeddings arrive with theirs
+        # already added by the caller (reference omnimamba.py:319-320)
+        emb_gen = model.backbone.img_embeddings(toks[:, :-1]) + model.backbone.pos_embed[:, Pn:max_len - 1]
         full = model(None, torch.cat([prompt_emb, emb_gen], 1), task="t2i").t2i_logits
     assert torch.equal(full[:, Pn - 1:].argmax(-1).cpu(), toks.cpu())
 
@@ -139,7 +150,7 @@ def test_decode_hipgraph_equals_eager():
     torch.manual_seed(2)
     model = OmniMambaLM(tiny_cfg()).to(dev).eval()
     with torch.no_grad():
-        model.backbone.img_embeddings.weight.mul_(30.0)
+        model.backbone.img_embeddings.word_embeddings.weight.mul_(30.0)
     ids, emb = torch.zeros(2, 5, dtype=torch.long, device=dev), torch.randn(2, 5, 32, device=dev)
     a = decode(ids, emb, model, 14, top_k=1, task="t2i", cg=False)
     b = decode(ids, emb, model, 14, top_k=1, task="t2i", cg=True)
@@ -154,20 +165,17 @@ def _ddp_worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from emu.loader import use_emulator
-    from omnimamba_amd.stack import OmniMambaLM
-    from omnimamba_amd.train import Stage2Step, TrainConfig, init_distributed, synthetic_batch, wrap_ddp
+    from omnimamba_amd.train import Stage2Step, TrainConfig, init_distributed, shard_batch, synthetic_batch, wrap_ddp
     torch.set_num_threads(1)
     with use_emulator():
         init_distributed("gloo")
         torch.manual_seed(0)
         cfg = tiny_cfg()
-        model = OmniMambaLM(cfg)
-        model.set_stage("finetune")
+        model = tiny_path("finetune")
         tc = TrainConfig(amp_dtype=torch.float32, clip=0.0, lr=0.0)
         step = Stage2Step(model, tc, ddp_model=wrap_ddp(model, tc))
-        full = synthetic_batch(cfg, 2 * world, 9, "cpu", torch.float32, rank=0)
-        mine = {k: (e[rank * 2:(rank + 1) * 2], l[rank * 2:(rank + 1) * 2]) for k, (e, l) in full.items()}
-        step(mine)
+        full = synthetic_batch(cfg, 2 * world, 14, "cpu", torch.float32, rank=0, caption_len=4)
+        step(shard_batch(full, rank, world))
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
         if rank == 0:
             q.put({k: v.numpy() for k, v in grads.items()})
@@ -180,7 +188,6 @@ def test_ddp_gloo_two_ranks_equals_single_process():
     kernels) == 1 process x 4 samples."""
     import torch.multiprocessing as mp
     from emu.loader import use_emulator
-    from omnimamba_amd.stack import OmniMambaLM
     from omnimamba_amd.train import Stage2Step, TrainConfig, synthetic_batch
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -195,11 +202,11 @@ def test_ddp_gloo_two_ranks_equals_single_process():
     with use_emulator():
         torch.manual_seed(0)
         cfg = tiny_cfg()
-        model = OmniMambaLM(cfg)
-        model.set_stage("finetune")
+        model = tiny_path("finetune")
         tc = TrainConfig(amp_dtype=torch.float32, clip=0.0, lr=0.0)
-        Stage2Step(model, tc)(synthetic_batch(cfg, 4, 9, "cpu", torch.float32, rank=0))
+        Stage2Step(model, tc)(synthetic_batch(cfg, 4, 14, "cpu", torch.float32, rank=0, caption_len=4))
         ref = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert sorted(ref) == sorted(got)
+    assert sorted(ref) == sorted(n for n, p in model.named_parameters() if p.requires_grad)   # nothing trainable is left unused
     for n in ref:
         assert rel(torch.from_numpy(got[n]), ref[n]) < 1e-4, n
