@@ -2,19 +2,30 @@
 """bench.py -- BASELINE.json configs[1]: one Mamba-2 block (OmniMamba-1.3B shape), forward + backward,
 B=8 L=4096 d_model=2048 d_state=128, bf16 autocast over fp32 parameters, synthetic data, on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE
+in the environment) or started plainly, in which case it re-executes itself under torch.distributed.run on 127.0.0.1.
 
 Prints ONE JSON line on rank 0.  value = selective-scan M-elements/s of the whole job =
 world * B * L * (H*P = 4096 scanned channels) / step_time / 1e6, a step being fwd + bwd of the block (in_proj GEMM ->
-fused conv1d + SSD scan + gated RMSNorm + out_proj node and its backward; with N > 1 the block is wrapped in DDP so
-the parameter gradients are all-reduced over RCCL, overlapped with backward).  `roofline` is for the dominant
-hand-written kernel (the SSD scan forward, algorithmic bytes SURVEY.md section 8d) timed with HIP events on the launch
-stream inside the timed region; `cpu_baseline` is the CPU oracle (a port, not the reference: mamba_ssm is absent) on a
-bounded sample of the same workload.
+fused conv1d + SSD scan + gated RMSNorm + out_proj node and its backward; with N > 1 the block is wrapped in DDP so the
+parameter gradients are all-reduced over RCCL, overlapped with backward).  The timed region holds K steps repeated until
+it lasts >= --min-seconds (default 5 s: the driver's utilisation sampler has a 5 s period); `steps` is the number
+actually timed, `steps_requested` is K.
+  roofline / roofline_bwd   the SSD scan forward / backward launches (algorithmic bytes of SURVEY.md section 8d) timed
+                            with HIP events on the launch stream inside the timed region
+  cpu_baseline              the CPU oracle (a port: mamba_ssm is absent) on a bounded sample of the same workload
+  train_1p3b                BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU step (projector + MMU LoRA train), L=2048,
+                            bf16 autocast, DDP over RCCL when N > 1 -- tokens/s of the whole job
+  selscan_cfg1              BASELINE configs[0]: Mamba-1 selective_scan at B2 L1024 D768 N16 fp32 -- HIP kernel next
+                            to the CPU selective_scan_ref restatement on the host cores
 """
 import argparse
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -59,27 +70,149 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"oracle.mamba2_forward_ref block fwd+bwd, B=1 L={L} d_model={D_MODEL} fp32, {dt_s:.2f} s"}
 
 
+def selscan_cfg1(dev):
+    """BASELINE configs[0] (SURVEY.md section 8d 'Cfg 1 inputs'): the host restatement of selective_scan_ref, best of 5
+    after a warm-up, next to the HIP selective_scan_fn on the same tensors (and at 32x the batch, where the launch is long
+    enough to read a bandwidth from)."""
+    import oracle as O
+    from omnimamba_amd.selective_scan import selective_scan_fn
+    torch.manual_seed(0)
+    Bsz, Dm, L, N = 2, 768, 1024, 16
+    u, delta = torch.randn(Bsz, Dm, L), torch.rand(Bsz, Dm, L) * 0.5
+    A = -(torch.rand(Dm, N) + 0.1)
+    Bm, Cm = torch.randn(Bsz, N, L), torch.randn(Bsz, N, L)
+    D, z, db = torch.randn(Dm), torch.randn(Bsz, Dm, L), 0.1 * torch.randn(Dm)
+    O.selective_scan_ref(u, delta, A, Bm, Cm, D, z, db, True)
+    best = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref = O.selective_scan_ref(u, delta, A, Bm, Cm, D, z, db, True)
+        best = min(best, time.perf_counter() - t0)
+    out = {"shape": {"B": Bsz, "L": L, "D": Dm, "N": N, "dtype": "f32"},
+           "cpu_ref": {"value": round(Bsz * L * Dm / best / 1e6, 3), "unit": "M-elements/s", "cores": torch.get_num_threads(),
+                       "kind": "port", "sample": f"oracle.selective_scan_ref, best of 5, {best * 1e3:.1f} ms"}}
+    for rep in (1, 32):
+        g = [t.to(dev).repeat(*([rep] + [1] * (t.dim() - 1))) if t.dim() == 3 else t.to(dev) for t in (u, delta, A, Bm, Cm, D, z, db)]
+        got = selective_scan_fn(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], True)
+        if rep == 1:
+            err = ((got.cpu() - ref).norm() / ref.norm()).item()
+            assert err < 1e-3, f"selective_scan_fn vs selective_scan_ref: rel-L2 {err:.2e}"
+            out["rel_l2_vs_cpu_ref"] = err
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50
+        e0.record()
+        for _ in range(n):
+            selective_scan_fn(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        nb = rep * Bsz * L * (4 * Dm * 4 + 2 * N * 4)          # u, delta, z in, out + B, C (SURVEY.md section 8d)
+        out[f"hip_B{rep * Bsz}"] = {"value": round(rep * Bsz * L * Dm / (ms * 1e-3) / 1e6, 1), "unit": "M-elements/s", "launch_ms": round(ms, 4),
+                                    "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
+                                    "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048):
+    """BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU pretrain step on synthetic image features + text ids, L = 2048:
+    images_feat (B, 729, 2176) -> projector, text ids of length L - 733, labels = ids; stage 'align' with only the MMU
+    task configured (projector + MMU LoRA adapters train); bf16 autocast, AdamW, clip 1.0."""
+    from omnimamba_amd.omni import OmniMambaPath
+    from omnimamba_amd.stack import StackConfig
+    from omnimamba_amd.train import Stage2Step, TrainConfig, synthetic_batch, wrap_ddp
+    torch.manual_seed(0)
+    cfg = StackConfig.omnimamba_1_3b(t2i_task=False, mmu_task=True, mmu_positions=max(seqlen, 1500))
+    model = OmniMambaPath(cfg, stage="align", device=dev, dtype=torch.float32)
+    tc = TrainConfig()
+    net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
+    step = Stage2Step(model, tc, ddp_model=net)
+    data = synthetic_batch(cfg, batch, seqlen, dev, torch.bfloat16, rank=rank, tasks=("mmu",))
+    for _ in range(warmup):
+        step(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    loss = float(step.last["mmu"])
+    assert math.isfinite(loss)
+    out = {"tokens_per_s": round(world * batch * seqlen * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+           "warmup": warmup, "loss": round(loss, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+           "config": {"workload": "OmniMamba-1.3B stage-1 MMU pretrain step (BASELINE.json configs[3])", "n_layer": cfg.n_layer,
+                      "d_model": cfg.d_model, "seq_len": seqlen, "batch_per_gpu": batch, "global_batch": batch * world,
+                      "trainable_params": sum(p.numel() for p in model.parameters() if p.requires_grad),
+                      "params": sum(p.numel() for p in model.parameters()), "dtype": "bf16 autocast, fp32 masters",
+                      "parallelism": f"dp{world}" if world > 1 else "single"}}
+    del step, net, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="repeat the K timed steps until the timed region lasts this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-1p3b", action="store_true")
+    ap.add_argument("--no-selscan-cfg1", action="store_true")
+    ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the CPU launch test passes gloo)")
+    ap.add_argument("--dry-launch", action="store_true", help="only initialise the process group and report ranks (CPU test of the launch path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if args.dry_launch:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend or "gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            ok = t.item() == world * (world - 1) / 2
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "ok": bool(ok)}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend or "nccl", device_id=dev)
 
     from omnimamba_amd import _prof
     from omnimamba_amd._lib import get_lib
@@ -109,67 +242,83 @@ def main():
         for p in block.parameters():
             p.grad = None
 
+    def timed(n):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
+
     for _ in range(args.warmup):
         step()
+    rounds = 1
+    if args.min_seconds > 0:
+        probe = timed(args.steps)              # untimed for the result: sizes the timed region (same on every rank: MAX-reduced)
+        rounds = max(1, math.ceil(args.min_seconds / probe))
+    nsteps = args.steps * rounds
     _prof.ENABLED = True
     _prof.reset()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(nsteps)
     _prof.ENABLED = False
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B_LOCAL * SEQ * D_SCAN / (elapsed / args.steps) / 1e6
+    ms_per_step = elapsed / nsteps * 1e3
+    value = world * B_LOCAL * SEQ * D_SCAN / (elapsed / nsteps) / 1e6
 
+    out = None
     if rank == 0:
         prof = _prof.summary()
         tok = B_LOCAL * SEQ
         n_f, ms_f = prof.get("ssd_scan_fwd", (0, float("nan")))
         n_b, ms_b = prof.get("ssd_scan_bwd", (0, float("nan")))
-        fwd_bytes = tok * SCAN_FWD_BYTES_PER_TOK
-        ach = fwd_bytes / (ms_f * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of the same kernel at this shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        fwd_bytes, bwd_bytes = tok * SCAN_FWD_BYTES_PER_TOK, tok * SCAN_BWD_BYTES_PER_TOK
+        ach_f, ach_b = fwd_bytes / (ms_f * 1e-3) / 1e9, bwd_bytes / (ms_b * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of the same kernels at this shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot be read inside this process
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "ssd_fwd_traffic.json")) as fh:
-                tj = json.load(fh)
-                traffic, traffic_src = int(tj["traffic_bytes_per_launch"]), tj.get("source")
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = {}
+        for key, fn in (("fwd", "ssd_fwd_traffic.json"), ("bwd", "ssd_bwd_traffic.json")):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                    tj = json.load(fh)
+                    traffic[key] = (int(tj["traffic_bytes_per_launch"]), tj.get("source"))
+            except (OSError, KeyError, ValueError):
+                traffic[key] = (None, None)
         out = {
             "metric": "selective-scan M-elements/sec", "value": round(value, 1), "unit": "M-elements/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": world, "steps": nsteps, "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "timed_seconds": round(elapsed, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "single Mamba-2 block fwd+bwd (BASELINE.json configs[1])", "batch_per_gpu": B_LOCAL,
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
                        "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
             "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel)",
-                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4),
-                         "launches_timed": n_f},
-            "scan_bwd": {"launch_ms": round(ms_b, 4), "algorithmic_bytes_per_launch": tok * SCAN_BWD_BYTES_PER_TOK,
-                         "achieved_GBs": round(tok * SCAN_BWD_BYTES_PER_TOK / (ms_b * 1e-3) / 1e9, 1), "launches_timed": n_b},
-            "tokens_per_s": round(world * tok / (elapsed / args.steps), 1),
+                         "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
+                         "traffic": traffic["fwd"][0], "traffic_source": traffic["fwd"][1],
+                         "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
+            "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + the backward scans + finish)",
+                             "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                             "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1],
+                             "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": round(ms_b, 4), "launches_timed": n_b},
+            "tokens_per_s": round(world * tok / (elapsed / nsteps), 1),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+    del model, block, u, dy
+    torch.cuda.empty_cache()
+    extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
+    if rank == 0:
+        out["train_1p3b"] = extra_t
+        out["selscan_cfg1"] = None if (args.no_selscan_cfg1 or world > 1) else selscan_cfg1(dev)
+        out["cpu_baseline"] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -12,7 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libomnimamba_hip.so")
+# OMK_LIB_SUFFIX: a second, developer build next to the product library (e.g. _prof with OMK_PHASE_PROF=1), used with
+# tools/with_lib.py for same-box A/B runs
+SUFFIX = os.environ.get("OMK_LIB_SUFFIX", "")
+LIB = os.path.join(LIBDIR, f"libomnimamba_hip{SUFFIX}.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-ffp-contract=fast"] + (["-DOMK_PHASE_PROF"] if os.environ.get("OMK_PHASE_PROF") else [])
@@ -37,7 +40,7 @@ def _compile(src, obj, verbose):
 
 def build(verbose: bool = True, force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + SUFFIX)
     os.makedirs(objdir, exist_ok=True)
     hm = _headers_mtime()
     jobs, objs = [], []

@@ -433,6 +433,9 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
   auto base = [&](int mode) {
     GScan g = {};
     g.mode = mode; g.dtp = w.dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L;
+#ifdef OMK_PHASE_PROF
+    if (const char* e = getenv("OMK_ABLATE_B")) g.ablate = atoi(e);
+#endif
     return g;
   };
   {  // dC: state [n][p], forward in time

@@ -652,12 +652,17 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     for (int i = 0; i < 4; i++) ckv[i] = ld16(cp + 256 * i);
   };
   if (want_bnd) load_ckpt(c0);
+#ifdef OMK_PHASE_PROF   // developer build: skip phases (bit i of OMK_ABLATE_B), results are wrong
+  const int ablb = a.ablate;
+#else
+  constexpr int ablb = 0;
+#endif
 
   for (int c = c0; c < c1; c++) {
     const int tlo = chunk_lo(c);
     const int cnext = c + 1 < c1 ? c + 1 : c;
     OMK_OPAQUE(o_mu); OMK_OPAQUE(o_su); OMK_OPAQUE(o_x4); OMK_OPAQUE(o_ps); OMK_OPAQUE(o_tk);
-    if (want_bnd) {
+    if (want_bnd && !(ablb & 8)) {
       // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
       //   dl(first token of chunk id + 1) = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan
       //   checkpoint of chunk id) >;  bnd[id + 1] holds the inner product
@@ -676,6 +681,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     f32x4 acc[8];
 #pragma unroll
     for (int ut = 0; ut < 8; ut++) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(ablb & 1))
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
 #pragma unroll
@@ -740,14 +746,15 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
           acc[ut] = mfma16x16x32_bf16(fu, as_s16x8(ml), acc[ut]);
         }
       };
-      if (w == 0) { block(0, false, true, false); }
+      if (ablb & 2) { }
+      else if (w == 0) { block(0, false, true, false); }
       else if (w == 1) { block(0, true, false, true); }
       else if (w == 2) { block(0, true, false, false); block(1, false, true, false); }
       else { block(0, true, false, false); block(1, true, false, true); }
     }
     prefetch_q();
     // ---- (3) state update: S^T[p][n] = exp2(cs_end) S^T + sum_l (ws_l K[l][p]) U[l][n]
-    {
+    if (!(ablb & 4)) {
       const float dec = sm.ecs[hh][QC - 1];
 #pragma unroll
       for (int ut = 0; ut < 8; ut++) accS[ut] *= dec;
@@ -773,7 +780,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
         }
       }
     }
-    if (MODE == GS_DC && ck) {   // forward state at the END of this chunk, fragment order, bf16 pairs
+    if (MODE == GS_DC && ck && !(ablb & 8)) {   // forward state at the END of this chunk, fragment order, bf16 pairs
       uint32_t* cp = ck + (int64_t)c * 8192 + wave * 1024 + lane * 4;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     }
     // ---- (4) token scalar of this head: X4_l . O_l (row l = 16 w + t16: 32 products per lane, 4 lanes per row)
     const int trow = tlo + rtk_q;
-    {
+    if (!(ablb & 16)) {
       float pv = 0.f;
 #pragma unroll
       for (int ut = 0; ut < 8; ut++) {
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       for (int ut = 0; ut < 8; ut++) *reinterpret_cast<f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]) = acc[ut];
     }
     block_sync();   // E: exchange buffer complete; nobody reads this chunk's tiles / scalars any more
-    if (hh == 0 && trow < a.L) {
+    if (hh == 0 && trow < a.L && !(ablb & 32)) {
       float* prow = part + (int64_t)trow * 128 + 4 * g16;
 #pragma unroll
       for (int ut = 0; ut < 8; ut++) {
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
         *reinterpret_cast<f32x4*>(prow + 16 * ut) = acc[ut] + o1;
       }
     }
-    if (want_bnd) load_ckpt(cnext);
+    if (want_bnd && !(ablb & 8)) load_ckpt(cnext);
     publish_state();
     commit();
     if (w == 0) scalars();

@@ -12,14 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_json_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--min-seconds", "0", "--no-train-1p3b"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "roofline_bwd", "cpu_baseline", "train_1p3b", "selscan_cfg1", "steps_requested"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
     assert j["unit"] == "M-elements/s" and j["value"] > 0 and abs(j["value"] - 8 * 4096 * 4096 / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 1e-2
@@ -27,3 +27,38 @@ def test_bench_json_contract():
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.05 < rf["frac"] < 1.0 and (rf["traffic"] is None or rf["traffic"] >= 0.9 * rf["algorithmic_bytes_per_launch"])
+    rb = j["roofline_bwd"]
+    assert rb["bound"] == "hbm" and rb["algorithmic_bytes_per_launch"] == 8 * 4096 * 25856 and 0.02 < rb["frac"] < 1.0
+    c1 = j["selscan_cfg1"]                         # BASELINE configs[0]: HIP selective_scan next to the CPU restatement
+    assert c1["rel_l2_vs_cpu_ref"] < 1e-3 and c1["cpu_ref"]["value"] > 0 and c1["hip_B2"]["value"] > c1["cpu_ref"]["value"]
+
+
+@pytest.mark.gpu
+def test_bench_timed_region_is_stretched_to_min_seconds():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--min-seconds", "1.0", "--no-train-1p3b", "--no-selscan-cfg1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert j["steps_requested"] == 3 and j["steps"] % 3 == 0 and j["steps"] > 3 and j["timed_seconds"] >= 0.9
+    assert j["roofline"]["launches_timed"] == j["steps"]
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_launches_itself_for_n_gpus(n):
+    """The driver runs `python bench.py --gpus N` WITHOUT a launcher: bench.py must re-execute itself under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).  CPU check of that path with gloo."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-launch"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_launch": True, "n_gpus": n, "ok": True}
+
+
+def test_bench_under_an_external_launcher_does_not_relaunch():
+    """The documented driver form: torch.distributed.run starts the ranks, bench.py reads RANK / WORLD_SIZE."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29400 + os.getpid() % 500), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
