@@ -226,6 +226,7 @@ struct FinishArgs {
   float* dA; float* ddtb;
   const float* bnd;   // optional (B, H, nT + 1): < g, h > at the boundary behind tile ti (MFMA path): dl restarts from exp(a) * bnd
   int B, H, L, P, N;
+  int ckpt_every;   // bnd is valid at tile boundaries j with j % ckpt_every == 0 and at the end of the sequence
 };
 __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, lane = threadIdx.x;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   const int nT = (a.L + 63) / 64;
   for (int ti = nT - 1; ti >= 0; ti--) {
     // bf16-level errors in e / w must not accumulate over the whole sequence: restart from the exact boundary value
-    if (a.bnd) {
+    if (a.bnd && (((ti + 1) % (a.ckpt_every > 0 ? a.ckpt_every : 1)) == 0 || ti + 1 == nT)) {
       const int tn = (ti + 1) * 64;   // bnd holds < g, h > at the boundary; the decay of the first token behind it is applied here
       carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
     }
@@ -283,23 +284,29 @@ __global__ __launch_bounds__(1024) void ssd_bwd_finish_par_kernel(FinishArgs a) 
   const int64_t base = (int64_t)bh * a.L;
   const float Ah = a.A[h];
   const int nT = (a.L + 63) / 64;
+  const int cke = a.ckpt_every > 0 ? a.ckpt_every : 1;
+  const int nR = (nT + cke - 1) / cke;   // runs of cke tiles between two restart boundaries (the sequence end is one)
   float dAacc = 0.f, dbacc = 0.f;
-  for (int ti = wave; ti < nT; ti += 16) {
-    const int tn = (ti + 1) * 64;   // bnd holds < g, h > at the boundary; apply the decay of the first token behind it
-    const float carry = a.bnd[(int64_t)bh * (nT + 1) + ti + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
-    const int t = ti * 64 + lane;
-    const bool ok = t < a.L;
-    const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
-    const float ds = ok ? a.dsoft[base + t] : 0.f;
-    const float v0 = ok ? a.e[base + t] - d * w : 0.f;
-    // inclusive suffix sum = total - exclusive prefix
-    const float incl = wave_incl_scan_add(v0);
-    const float dl = wave_read_lane(incl, 63) - incl + v0 + carry;
-    if (ok) {
-      const float draw = (w + Ah * dl) * ds;
-      dAacc += d * dl;
-      dbacc += draw;
-      store_rt(a.ddt, (int64_t)b * a.dsb + (int64_t)t * a.dsl + (int64_t)h * a.dsh, a.ddt_dt, draw);
+  for (int run = wave; run < nR; run += 16) {
+    const int t_hi = ((run + 1) * cke < nT ? (run + 1) * cke : nT) - 1;   // last tile of the run
+    const int tn = (t_hi + 1) * 64;   // bnd holds < g, h > at the boundary; apply the decay of the first token behind it
+    float carry = a.bnd[(int64_t)bh * (nT + 1) + t_hi + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
+    for (int ti = t_hi; ti >= run * cke; ti--) {
+      const int t = ti * 64 + lane;
+      const bool ok = t < a.L;
+      const float d = ok ? a.dtp[base + t] : 0.f, w = ok ? a.wsum[base + t] : 0.f;
+      const float ds = ok ? a.dsoft[base + t] : 0.f;
+      const float v0 = ok ? a.e[base + t] - d * w : 0.f;
+      // inclusive suffix sum = total - exclusive prefix
+      const float incl = wave_incl_scan_add(v0);
+      const float dl = wave_read_lane(incl, 63) - incl + v0 + carry;
+      carry = wave_read_lane(dl, 0);
+      if (ok) {
+        const float draw = (w + Ah * dl) * ds;
+        dAacc += d * dl;
+        dbacc += draw;
+        store_rt(a.ddt, (int64_t)b * a.dsb + (int64_t)t * a.dsl + (int64_t)h * a.dsh, a.ddt_dt, draw);
+      }
     }
   }
   dAacc = wave_sum(dAacc); dbacc = wave_sum(dbacc);
@@ -416,7 +423,7 @@ static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N,
   const size_t bhl = (size_t)B * H * L * 4, blgn = (size_t)B * L * G * N * 4;
   w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl); w.dB32 = take(blgn); w.dC32 = take(blgn);
   w.sfin = need_sfin ? take((size_t)B * H * P * N * 4) : nullptr;
-  w.part = need_part ? take((size_t)B * (H / 2) * L * 128 * 4) : nullptr;
+  w.part = need_part ? take((size_t)B * (H / 2) * L * 128 * 2) : nullptr;   // bf16 head-pair partial tiles
   const size_t nC = (size_t)(L + 63) / 64;
   w.ckpt = need_part ? take((size_t)B * (H / 2) * nC * (8 * 2 * 8 * 64) * 4) : nullptr;
   w.bnd = need_part ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
@@ -447,7 +454,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.isb = p->initial_states.stride[0]; g.ish = p->initial_states.stride[1]; g.isk = p->initial_states.stride[2]; g.isu = p->initial_states.stride[3];
     }
     if (has_dfin) { g.fin = w.sfin; g.fsb = (int64_t)d.H * d.N * d.P; g.fsh = (int64_t)d.N * d.P; g.fsu = d.P; g.fsk = 1; }
-    if (mfma) { g.part = w.part; g.tokscal = w.e; g.ckpt = w.ckpt; } else { g.acc32 = w.dC32; g.tokscal = w.e; }
+    if (mfma) { g.part = w.part; g.tokscal = w.e; g.ckpt = w.ckpt; g.ckpt_every = ssd_ckpt_every(); } else { g.acc32 = w.dC32; g.tokscal = w.e; }
     *gdc = g;
   }
   {  // dx: state [p][n], reverse in time
@@ -475,7 +482,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.init = p->dfinal_states.data; g.init_dt = OMK_F32;
       g.isb = p->dfinal_states.stride[0]; g.ish = p->dfinal_states.stride[1]; g.isk = p->dfinal_states.stride[2]; g.isu = p->dfinal_states.stride[3];
     }
-    if (mfma) { g.part = w.part; g.tokscal = w.wsum; g.ckpt = w.ckpt; g.bnd = w.bnd; }
+    if (mfma) { g.part = w.part; g.tokscal = w.wsum; g.ckpt = w.ckpt; g.bnd = w.bnd; g.ckpt_every = ssd_ckpt_every(); }
     else { g.acc32 = w.dB32; g.tokscal = w.wsum; }
     if (present(p->dD)) { g.dD = (float*)p->dD.data; g.dDsh = p->dD.stride[0]; g.dDsp = p->dD.ndim == 2 ? p->dD.stride[1] : 0; }
     *gdb = g;
@@ -537,11 +544,12 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
       gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
     }
     gf.seg = w.segf;
-    if ((rc = ssd_mfma_prepare_segments(gf, stream))) return rc;
-    if ((rc = ssd_mfma_prepare_segments(gdx, stream))) return rc;
-    gdc.seg = w.segf; gdc.seg_ready = 1;
-    gdx.seg_ready = 1;
-    gdb.seg = w.seg; gdb.seg_ready = 1;
+    int fmt_f = 0, fmt_a = 0;   // element order each pass left its states in (ssd_scan.h: seg_fmt)
+    if ((rc = ssd_mfma_prepare_segments(gf, stream, &fmt_f))) return rc;
+    if ((rc = ssd_mfma_prepare_segments(gdx, stream, &fmt_a))) return rc;
+    gdc.seg = w.segf; gdc.seg_ready = 1; gdc.seg_fmt = fmt_f;
+    gdx.seg_ready = 1; gdx.seg_fmt = fmt_a;
+    gdb.seg = w.seg; gdb.seg_ready = 1; gdb.seg_fmt = fmt_a;
   }
   if (mfma) {
     if ((rc = ssd_mfma_launch(gdc, stream))) return rc;   // forward in time: e_t, state checkpoints, dC partials
@@ -563,6 +571,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     }
     f.ddt = p->ddt.data; f.dsb = p->ddt.stride[0]; f.dsl = p->ddt.stride[1]; f.dsh = p->ddt.stride[2]; f.ddt_dt = p->ddt.dtype;
     f.bnd = mfma ? w.bnd : nullptr;
+    f.ckpt_every = mfma ? ssd_ckpt_every() : 1;
     f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
     if (f.bnd && !f.dfin) {
       dim3 grid((unsigned)(d.B * d.H)), block(1024);

@@ -18,16 +18,11 @@
 // LDS; 32x32 output tiles; strips split into intra / state waves) were measured slower and live in the git history --
 // DESIGN.md section 4 has the numbers.
 #include "ssd_scan.h"
+#include "ssd_tiles.h"
 
 namespace omk {
 
 constexpr int QC = 64;     // chunk length (tokens)
-
-__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
-__device__ __forceinline__ s16x8 as_s16x8(u32x4 v) { return __builtin_bit_cast(s16x8, v); }
-__device__ __forceinline__ float bf_lo(uint32_t v) { return bf16_to_f32((uint16_t)(v & 0xffffu)); }
-__device__ __forceinline__ float bf_hi(uint32_t v) { return bf16_to_f32((uint16_t)(v >> 16)); }
 
 // =========================================================================================================
 // class A ("row strips"): one head per 256-thread workgroup, two workgroups per CU.
@@ -52,10 +47,6 @@ __device__ __forceinline__ float bf_hi(uint32_t v) { return bf16_to_f32((uint16_
 //   64-column tiles (128 B rows, two rows per 256 B bank row): seg ^ swzU(row) with swzU = swzK & 7 -- searched the same
 //     way over every pattern the class A / class B kernels use on them (8 rows x 2 segments, 4 rows x 4 segments,
 //     16 rows x 1 segment, the ds_read_b128 row reads, rows {0-3, 8-11} x 2 segments).
-__device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
-__device__ __forceinline__ int swzU(int r) { return swzK(r) & 7; }
-__device__ __forceinline__ int kx3(int row, int col) { return row * 128 + ((((col >> 3) ^ swzK(row)) << 3) | (col & 7)); }
-__device__ __forceinline__ int ux3(int row, int col) { return row * 64 + ((((col >> 3) ^ swzU(row)) << 3) | (col & 7)); }
 // 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
 // rows r0 + 8 h32 + 4 m + {0..3}, column c0 + (lane & 31)
 template <bool KT>
@@ -610,7 +601,8 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
         // start state of the segment, folded in the class A accumulator order of the transposed state [p][n]:
         // element ((2 (n >> 5) + (p >> 5)) * 16 + 4 ((n >> 3) & 3) + (n & 3)) * 64 + 32 ((n >> 2) & 1) + (p & 31)
         const int n = u, pp = k;
-        const int e = ((2 * (n >> 5) + (pp >> 5)) * 16 + 4 * ((n >> 3) & 3) + (n & 3)) * 64 + 32 * ((n >> 2) & 1) + (pp & 31);
+        const int e = a.seg_fmt ? pp * 128 + n
+                                : ((2 * (n >> 5) + (pp >> 5)) * 16 + 4 * ((n >> 3) & 3) + (n & 3)) * 64 + 32 * ((n >> 2) & 1) + (pp & 31);
         v = a.seg[(((int64_t)b * a.H + hcur) * a.nseg + seg - 1) * SEG_STATE + e];
       } else if (a.init) {
         v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)hcur * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt);
@@ -632,7 +624,8 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
   if (w == 0) scalars();
   publish_state();
   block_sync();
-  float* part = a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
+  // head-pair partial tiles, bf16 (round 2: the fp32 form was 537 MB written and 537 MB read back per scan at B 8, L 4096)
+  uint16_t* part = (uint16_t*)a.part + ((int64_t)b * pairs + hp) * (int64_t)a.L * 128;
   // state checkpoints in fragment order: [b][pair][chunk][wave 8][q 4][lane 64][4] packed bf16 pairs (u32), entry
   // (q, i) = tile ut = 2 q + (i >> 1), register pair i & 1: four fully coalesced 16-byte accesses per lane (sixteen
   // 4-byte loads per lane cost the dB scan 108 us)
@@ -651,7 +644,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) ckv[i] = ld16(cp + 256 * i);
   };
-  if (want_bnd) load_ckpt(c0);
+  // boundary j (between chunks j - 1 and j in token order, j = 1 .. nC) carries a checkpoint / restart value when
+  // j % ckpt_every == 0 or j == nC
+  const int cke = a.ckpt_every > 0 ? a.ckpt_every : 1;
+  auto is_restart = [&](int j) -> bool { return (j % cke) == 0 || j == nC; };
+  if (want_bnd && is_restart(nC - c0)) load_ckpt(c0);
 #ifdef OMK_PHASE_PROF   // developer build: skip phases (bit i of OMK_ABLATE_B), results are wrong
   const int ablb = a.ablate;
 #else
@@ -662,7 +659,8 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     const int tlo = chunk_lo(c);
     const int cnext = c + 1 < c1 ? c + 1 : c;
     OMK_OPAQUE(o_mu); OMK_OPAQUE(o_su); OMK_OPAQUE(o_x4); OMK_OPAQUE(o_ps); OMK_OPAQUE(o_tk);
-    if (want_bnd && !(ablb & 8)) {
+    const bool bnd_here = want_bnd && is_restart(nC - c);   // the boundary behind chunk id = nC - 1 - c is j = nC - c
+    if (bnd_here && !(ablb & 8)) {
       // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
       //   dl(first token of chunk id + 1) = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan
       //   checkpoint of chunk id) >;  bnd[id + 1] holds the inner product
@@ -695,7 +693,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       for (int ut = 0; ut < 8; ut++) acc[ut] *= e1;
     }
     block_sync();   // X: every wave is done with S_in (and bred is complete)
-    if (want_bnd && tid < 2)   // raw < g, h >; the finish pass applies exp(a_first(id + 1)) (no dependent global load here)
+    if (bnd_here && tid < 2)   // raw < g, h >; the finish pass applies exp(a_first(id + 1)) (no dependent global load here)
       a.bnd[((int64_t)b * a.H + h0 + tid) * (nC + 1) + (nC - 1 - c) + 1] = sm.bred[4 * tid] + sm.bred[4 * tid + 1] + sm.bred[4 * tid + 2] + sm.bred[4 * tid + 3];
     stlo = chunk_lo(cnext);
     prefetch_tiles();
@@ -780,7 +778,7 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
         }
       }
     }
-    if (MODE == GS_DC && ck && !(ablb & 8)) {   // forward state at the END of this chunk, fragment order, bf16 pairs
+    if (MODE == GS_DC && ck && is_restart(c + 1) && !(ablb & 8)) {   // forward state at the END of this chunk, fragment order, bf16 pairs
       uint32_t* cp = ck + (int64_t)c * 8192 + wave * 1024 + lane * 4;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -818,14 +816,16 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
     }
     block_sync();   // E: exchange buffer complete; nobody reads this chunk's tiles / scalars any more
     if (hh == 0 && trow < a.L && !(ablb & 32)) {
-      float* prow = part + (int64_t)trow * 128 + 4 * g16;
+      uint16_t* prow = part + (int64_t)trow * 128 + 4 * g16;
 #pragma unroll
       for (int ut = 0; ut < 8; ut++) {
         const f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]);
-        *reinterpret_cast<f32x4*>(prow + 16 * ut) = acc[ut] + o1;
+        const f32x4 sv = acc[ut] + o1;
+        const u32x2 pv = {pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3])};
+        *reinterpret_cast<u32x2*>(prow + 16 * ut) = pv;
       }
     }
-    if (want_bnd && !(ablb & 8)) load_ckpt(cnext);
+    if (want_bnd && is_restart(nC - cnext) && !(ablb & 8)) load_ckpt(cnext);
     publish_state();
     commit();
     if (w == 0) scalars();
@@ -866,28 +866,36 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
   }
 }
 
-// out[b][t][g][n] = sum over the head pairs of group g of part[b][pair][t][n]
-__global__ void ssd_reduce_partials_kernel(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt,
+// out[b][t][g][n] = sum over the head pairs of group g of part[b][pair][t][n]   (bf16 partial tiles, fp32 sum)
+__global__ void ssd_reduce_partials_kernel(const uint16_t* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt,
                                            int B, int L, int G, int pairs) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = 4 consecutive n
-  const int64_t total = (int64_t)B * L * G * 32;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = 8 consecutive n
+  const int64_t total = (int64_t)B * L * G * 16;
   if (i >= total) return;
-  const int n4 = (int)(i % 32) * 4, g = (int)((i / 32) % G), t = (int)((i / (32 * (int64_t)G)) % L), b = (int)(i / (32 * (int64_t)G * L));
+  const int n8 = (int)(i % 16) * 8, g = (int)((i / 16) % G), t = (int)((i / (16 * (int64_t)G)) % L), b = (int)(i / (16 * (int64_t)G * L));
   const int ppg = pairs / G;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < ppg; p++) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(part + (((int64_t)b * pairs + g * ppg + p) * L + t) * 128 + n4);
-    acc += v;
-  }
-  const int64_t o = (int64_t)b * osb + (int64_t)t * osl + (int64_t)g * osg + n4;
+    const u32x4 v = ld16(part + (((int64_t)b * pairs + g * ppg + p) * L + t) * 128 + n8);
 #pragma unroll
-  for (int e = 0; e < 4; e++) store_rt(out, o + e, out_dt, acc[e]);
+    for (int e = 0; e < 4; e++) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+  }
+  const int64_t o = (int64_t)b * osb + (int64_t)t * osl + (int64_t)g * osg + n8;
+  if (out_dt == OMK_BF16 && ((o & 7) == 0) && (((uintptr_t)out & 15) == 0)) {
+    u32x4 pv;
+#pragma unroll
+    for (int e = 0; e < 4; e++) pv[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+    st16((uint16_t*)out + o, pv);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) store_rt(out, o + e, out_dt, acc[e]);
+  }
 }
 
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream) {
-  const int64_t total = (int64_t)B * L * G * 32;
+  const int64_t total = (int64_t)B * L * G * 16;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  OMK_LAUNCH(ssd_reduce_partials_kernel, grid, block, 0, stream, part, out, osb, osl, osg, out_dt, B, L, G, H / 2);
+  OMK_LAUNCH(ssd_reduce_partials_kernel, grid, block, 0, stream, (const uint16_t*)part, out, osb, osl, osg, out_dt, B, L, G, H / 2);
   return OMK_OK;
 }
 
@@ -922,7 +930,12 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
   return OMK_OK;
 }
 
-int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream) {
+int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
+  if (ssd_v5a_applies(g)) {
+    if (seg_fmt) *seg_fmt = 1;
+    return ssd_v5a_prepare_segments(g, stream);
+  }
+  if (seg_fmt) *seg_fmt = 0;
   GScan a = g;
   const SegPlan sp = ssd_segments(a.B * a.H, a.L);
   a.nseg = sp.nseg; a.cps = sp.cps;
@@ -947,6 +960,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (!stride_ok(g.K.sl) || !stride_ok(g.Q.sl) || !stride_ok(g.U.sl) || !stride_ok(g.osl) || (g.Z.p && !stride_ok(g.Z.sl))) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
+  if (ssd_v5a_applies(g) && (!g.seg_ready || g.seg_fmt == 1)) return ssd_v5a_launch(g, stream);
   // one head (x one segment of the sequence) per workgroup, two workgroups per CU
   GScan a = g;
   const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};

@@ -39,15 +39,18 @@ struct GScan {
   float* acc32;                                                  // DC/DB: (B, L, G, DU) f32, atomically accumulated
   float* tokscal;                                                // DC: e, DB: wsum  (B, H, L) f32, atomically accumulated
   float* dD; int64_t dDsh, dDsp;                                 // DB: optional grad of D
-  float* part;                                                   // DC/DB (MFMA): (B, H/2, L, 128) f32 per-head-pair partial tiles
+  float* part;                                                   // DC/DB (MFMA): (B, H/2, L, 128) per-head-pair partial tiles, stored as bf16
   // DC/DB (MFMA): forward-state checkpoints at every chunk end, written by the dC scan in MFMA fragment order
   // (bf16 pairs) and read back by the dB scan, which emits the exact decay-gradient restart values bnd (B, H, nC + 1)
   void* ckpt; float* bnd;
+  // checkpoints (and restart values) only at chunk boundaries j with j % ckpt_every == 0, and at the end of the sequence
+  int ckpt_every;
   // class A (MFMA) sequence split for few (batch, head) pairs: nseg segments of cps chunks in scan order.  A state-only
   // pass leaves every segment's end state from a zero start in seg[(bh * nseg + s) * SEG_STATE ..] (MFMA accumulator
   // order) and its total log2 decay in seg[BH * nseg * SEG_STATE + bh * nseg + s]; the scan proper folds them.
   float* seg; int nseg, cps;
   int seg_ready;                                                 // seg already holds the folded START states (slot j - 1 = segment j)
+  int seg_fmt;                                                   // element order of seg: 0 = ssd_mfma_a3 accumulator order, 1 = logical [u][k] of the class A state (ssd_v5)
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
@@ -58,6 +61,14 @@ struct SegPlan { int nseg, cps; };
 // workgroups per CU exist; the extra state pass re-reads x and B and costs about a third of a scan, so the split
 // only pays from four segments on (measured: B = 1 L = 8192 264 -> 106 us, B = 2 269 -> 190 us, B = 4 loses),
 // and segments stay >= 8 chunks long.
+// restart interval of the decay-gradient prefix in chunks.  Every checkpoint is 16 KB per head and boundary (537 MB written
+// and read back per backward at B 8, L 4096 with an interval of 1), but thinning them costs accuracy: measured on the
+// emulator, L = 1024, d(dt) / dA rel-L2 2.1e-3 / 4.4e-2 at 1, 2.2e-3 / 4.6e-2 at 2, 2.8e-3 / 9.0e-2 at 4, 3.8e-3 / 2.0e-1 at 8,
+// and at L = 130 an interval of 2 already breaks the 6e-3 bound on d(dt).  Default 1; OMK_SSD_CKPT is an experiment knob.
+inline int ssd_ckpt_every() {
+  if (const char* e = getenv("OMK_SSD_CKPT")) { const int v = atoi(e); if (v >= 1 && v <= 64) return v; }
+  return 1;
+}
 inline SegPlan ssd_segments(int BH, int L) {
   const int nC = (L + 63) / 64;
   SegPlan p = {1, nC};
@@ -82,7 +93,11 @@ int ssd_generic_launch(const GScan& g, omk_stream stream);
 int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 1: only answer whether it applies
 // split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the
 // state at the START of segment j (initial state included).  Shared by the scans whose state this is (y and dC; dx and dB).
-int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream);
+int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = nullptr);   // *seg_fmt: the order it left the states in
+// the two-waves-per-head kernels of round 2 (ssd_v5.hip)
+bool ssd_v5a_applies(const GScan& g);
+int ssd_v5a_launch(const GScan& g, omk_stream stream);
+int ssd_v5a_prepare_segments(const GScan& g, omk_stream stream);
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
 }  // namespace omk

@@ -185,3 +185,29 @@ def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
         if a is not None:
             e = rel(a.grad, b.grad)
             assert e < tol[n], (n, e)
+
+
+@pytest.mark.parametrize("L,minc", [(200, None), (330, 2)])
+def test_ssd_v5_two_waves_per_head_kernel(dev, monkeypatch, L, minc):
+    """ssd_v5.hip (two independent waves per head, 32x32x16 MFMAs, state never in LDS): selectable with OMK_SSD_V5=1, measured
+    slower than the default strips on the MI355X; kept correct: forward (D per head and per column, z gate, initial and final
+    state, split sequence) and the dx scan of the backward against the oracle."""
+    monkeypatch.setenv("OMK_SSD_V5", "1")
+    if minc:
+        monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
+    import omnimamba_amd.ssd_combined as S
+    H, P, N, G = 4, 64, 128, 2
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=11)
+    for Dv in (D, torch.randn(H, P)):
+        y, yx, fin = S.ssd_scan_fwd(x.to(dev), dt.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), D=Dv.to(dev), z=z.to(dev), dt_bias=dtb.to(dev),
+                                    initial_states=init.to(dev), dt_softplus=True, return_final_states=True, want_out_x=True)
+        y0, f0 = O.ssd_ref_chunked(x.float(), dt.float(), A, Bm.float(), Cm.float(), 64, D=Dv, z=z.float(), dt_bias=dtb, initial_states=init,
+                                   dt_softplus=True, return_final_states=True)
+        assert rel(y, y0) < 2.5e-3 and rel(fin, f0) < 2.5e-3
+    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
+    yy = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6], dt_softplus=True)
+    gy = torch.randn(yy.shape).bfloat16()
+    yy.backward(gy.to(dev))
+    ref = [t.double().clone().requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
+    O.ssd_ref_sequential(ref[0], ref[1], ref[2], ref[3], ref[4], D=ref[5], dt_bias=ref[6], dt_softplus=True, compute_dtype=torch.float64).backward(gy.double())
+    assert rel(leaves[0].grad, ref[0].grad) < 5e-3 and rel(leaves[3].grad, ref[3].grad) < 5e-3 and rel(leaves[4].grad, ref[4].grad) < 5e-3
