@@ -290,6 +290,22 @@ typedef struct {
 size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p);
 int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream);
 
+/* ---- cross entropy over one block of logits: loss per row + the gradient written over the logits ----------------
+ * The loss the reference forms from the heads' outputs (models/mamba_vlm.py:88-102 shift + flatten; models/omnimamba.py:63,
+ * 276-279,305-306: torch.nn.CrossEntropyLoss(), mean over the labels that are not -100).  Used by the chunked fused
+ * linear + cross-entropy of omnimamba_amd/fused_ce.py, which never holds more than one token block of logits
+ * (SURVEY.md section 8 row f1).  Per row r (label y):  loss[r] = logsumexp(logits[r]) - logits[r][y];
+ * logits[r][v] <- (softmax(logits[r])[v] - [v == y]) * grad_scale[0]   (rows with label == ignore_index: loss 0, gradient 0). */
+typedef struct {
+  OmkTensor logits;        /* (T, V) in / out (the gradient), unit stride on V */
+  const int64_t* labels;   /* (T) */
+  OmkTensor losses;        /* out (T) f32 */
+  const float* grad_scale; /* device scalar the gradient is multiplied with (1 / number of counted labels); NULL = 1 */
+  int64_t ignore_index;
+  int32_t write_grad;      /* 0: only the losses */
+} OmkCrossEntropy;
+int omk_cross_entropy(const OmkCrossEntropy* p, omk_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

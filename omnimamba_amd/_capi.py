@@ -79,7 +79,10 @@ SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "dt
                                             "dinitial_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
 
-STRUCTS = {s.__name__: s for s in (OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
+CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("losses", _t), ("grad_scale", C.c_void_p),
+                                      ("ignore_index", _i64), ("write_grad", _i)])
+
+STRUCTS = {s.__name__: s for s in (CrossEntropy, OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
                                    Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, NormLinear, LoraAdd, SsdFwd, SsdBwd)}
 
 # every symbol include/omk.h declares
@@ -91,6 +94,7 @@ SYMBOLS = [
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add",
     "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
+    "omk_cross_entropy",
 ]
 
 

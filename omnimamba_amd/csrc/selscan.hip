@@ -8,6 +8,8 @@
 // following whichever of (d, l) has unit stride, so both (B, L, D) "channel-last" storage (adjacent lanes =
 // adjacent channels) and upstream's (B, D, L) storage are read in full coalesced rows; B_t / C_t rows of the tile
 // are staged once per workgroup and broadcast from LDS to every channel thread.
+#include <cstdlib>
+
 #include "omk_common.h"
 
 namespace omk {
@@ -132,6 +134,172 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
     for (int n = 0; n < NREG; n++)
       if (n < a.N) a.last[((int64_t)b * a.Dm + d) * a.N + n] = x[n];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward for L-contiguous storage (upstream's (B, D, L) / (B, G, N, L)): CHUNKED ASSOCIATIVE SCAN, lanes = time.
+//
+// One wave owns one (batch, channel) sequence.  A pass covers 64 * SSC_LC tokens: lane j holds the SSC_LC consecutive
+// tokens of chunk j (u, delta, z, B, C rows are contiguous in L, so every lane reads its own 16-byte vectors and the wave
+// reads the whole span; B / C rows are shared by the channel waves of a workgroup through L1).  Per state index n:
+//   reduce     the lane folds its chunk into the affine pair (P, X): x_end = P x_start + X      (a_t = exp2(delta_t A2))
+//   scan       inclusive scan of the 64 pairs across the wave, (P2, X2) o (P1, X1) = (P2 P1, P2 X1 + X2): DPP row shifts
+//              inside rows of 16 lanes + two row broadcasts -- no LDS, no barrier
+//   downsweep  every lane re-walks its chunk from its true start state and accumulates y_t += C_t[n] x_t[n]
+// The carry into the next pass of 64 * SSC_LC tokens is lane 63's end state, kept per n in a small LDS array private to
+// the wave.  No cross-lane reduction over n (the n loop is inside the lane), no atomics.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SSC_LC = 16;
+
+__device__ __forceinline__ void wave_scan_affine(float& p, float& x) {
+#ifdef OMK_EMU
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ps = shfl_up(p, off), xs = shfl_up(x, off);
+    if (lane_id() >= off) { x = fmaf(p, xs, x); p = p * ps; }
+  }
+#else
+  // lanes without a source (start of a row / rows outside the row mask) receive the identity pair (1, 0)
+#define OMK_AFF_STEP(ctrl, rowmask) { \
+    const float ps = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, p), ctrl, rowmask, 0xf, false)); \
+    const float xs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rowmask, 0xf, false)); \
+    x = fmaf(p, xs, x); p = p * ps; }
+  OMK_AFF_STEP(0x111, 0xf)   // row_shr:1
+  OMK_AFF_STEP(0x112, 0xf)   // row_shr:2
+  OMK_AFF_STEP(0x114, 0xf)   // row_shr:4
+  OMK_AFF_STEP(0x118, 0xf)   // row_shr:8
+  OMK_AFF_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
+  OMK_AFF_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
+#undef OMK_AFF_STEP
+#endif
+}
+
+// SSC_LC consecutive elements of a unit-stride row starting at t0 (tokens >= L read as 0); 16-byte vectors when possible
+template <class T>
+__device__ __forceinline__ void ssc_load_row(const T* row, int t0, int L, float (&out)[SSC_LC]) {
+  constexpr int VEC = 16 / sizeof(T);
+  const T* p = row + t0;
+  if (t0 + SSC_LC <= L && (((uintptr_t)p) & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < SSC_LC / VEC; i++) {
+      float v[VEC];
+      load_vec<T, VEC>(p + i * VEC, v);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) out[i * VEC + e] = v[e];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SSC_LC; i++) out[i] = (t0 + i < L) ? to_f32(p[i]) : 0.f;
+  }
+}
+template <class T>
+__device__ __forceinline__ void ssc_store_row(T* row, int t0, int L, const float (&v)[SSC_LC]) {
+  constexpr int VEC = 16 / sizeof(T);
+  T* p = row + t0;
+  if (t0 + SSC_LC <= L && (((uintptr_t)p) & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < SSC_LC / VEC; i++) {
+      float w[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) w[e] = v[i * VEC + e];
+      store_vec<T, VEC>(p + i * VEC, w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SSC_LC; i++)
+      if (t0 + i < L) p[i] = from_f32<T>(v[i]);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
+  __shared__ float scarry[4][64];   // per wave: state at the start of the pass, per n
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t seq = (int64_t)blockIdx.x * 4 + wv;   // the four waves of a workgroup: adjacent channels of one batch element
+  if (seq >= (int64_t)a.B * a.Dm) return;
+  const int b = (int)(seq / a.Dm), d = (int)(seq % a.Dm);
+  const int g = d / (a.Dm / a.G);
+  const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
+  const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
+  const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
+  T* orow = (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd;
+  const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+  const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+  float* carry = scarry[wv];
+  carry[lane] = 0.f;
+  for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
+    const int t0 = tile0 + lane * SSC_LC;
+    float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
+    ssc_load_row<T>(urow, t0, a.L, u);
+    ssc_load_row<T>(drow, t0, a.L, dl);
+#pragma unroll
+    for (int i = 0; i < SSC_LC; i++) {
+      float v = dl[i] + db;
+      if (a.softplus) v = v > 20.f ? v : 0.6931471805599453f * log2_fast(1.f + exp2_fast(v * LOG2E));
+      dl[i] = (t0 + i < a.L) ? v : 0.f;     // tokens past the end: a = 1, b = 0 (the identity pair)
+      u[i] *= dl[i];                          // delta_t u_t
+      y[i] = 0.f;
+    }
+    for (int n = 0; n < a.N; n++) {
+      const float A2 = load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) * LOG2E;
+      float Bv[SSC_LC], Cv[SSC_LC];
+      if (a.Bvar) {
+        if (a.bdt == OMK_F32) ssc_load_row<float>((const float*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
+        else if (a.bdt == OMK_BF16) ssc_load_row<bf16_t>((const bf16_t*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
+        else ssc_load_row<f16_t>((const f16_t*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
+      } else {
+        const float bc = load_rt(a.Bm, (int64_t)d * a.Bsg + (int64_t)n * a.Bsn, a.bdt);
+#pragma unroll
+        for (int i = 0; i < SSC_LC; i++) Bv[i] = bc;
+      }
+      if (a.Cvar) {
+        if (a.cdt == OMK_F32) ssc_load_row<float>((const float*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
+        else if (a.cdt == OMK_BF16) ssc_load_row<bf16_t>((const bf16_t*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
+        else ssc_load_row<f16_t>((const f16_t*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
+      } else {
+        const float cc = load_rt(a.Cm, (int64_t)d * a.Csg + (int64_t)n * a.Csn, a.cdt);
+#pragma unroll
+        for (int i = 0; i < SSC_LC; i++) Cv[i] = cc;
+      }
+      // ---- reduce: the chunk as an affine map x -> P x + X
+      float av[SSC_LC];
+      float P = 1.f, X = 0.f;
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) {
+        av[i] = exp2_fast(dl[i] * A2);
+        Bv[i] *= u[i];                        // b_t = delta_t u_t B_t[n]
+        X = fmaf(av[i], X, Bv[i]);
+        P *= av[i];
+      }
+      // ---- scan across the wave, then the start state of this lane's chunk
+      wave_scan_affine(P, X);
+      const float cin = carry[n];
+      const float xend = fmaf(P, cin, X);                 // state at the end of this lane's chunk
+      float x = shfl_up(xend, 1);
+      if (lane == 0) x = cin;
+      const float cout = wave_read_lane(xend, 63);
+      // ---- downsweep
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) {
+        x = fmaf(av[i], x, Bv[i]);
+        y[i] = fmaf(Cv[i], x, y[i]);
+      }
+      if (lane == 0) carry[n] = cout;
+    }
+    // ---- epilogue: + D u, gate, store   (u[] holds delta u: the raw u is re-read -- it is still in L1)
+    float ur[SSC_LC];
+    ssc_load_row<T>(urow, t0, a.L, ur);
+    if (zrow) {
+      float zv[SSC_LC];
+      ssc_load_row<T>(zrow, t0, a.L, zv);
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]) * (zv[i] * rcp_fast(1.f + exp2_fast(-zv[i] * LOG2E)));
+    } else {
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]);
+    }
+    ssc_store_row<T>(orow, t0, a.L, y);
+  }
+  if (a.last && lane < a.N) a.last[((int64_t)b * a.Dm + d) * a.N + lane] = carry[lane];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -327,6 +495,15 @@ static int ss_fill(SsArgs& a, const OmkTensor& u, const OmkTensor& delta, const 
 }
 
 static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
+  // L-contiguous storage (upstream's layout): the chunked associative scan, one wave per (batch, channel)
+  const bool lcontig = a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.out && a.osl == 1 && (!a.Bvar || a.Bsl == 1) &&
+                       (!a.Cvar || a.Csl == 1) && !a.ckpt && a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
+  if (lcontig) {
+    const int64_t nseq = (int64_t)a.B * a.Dm;
+    dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
+    OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T>), grid, block, 0, stream, a));
+    return OMK_OK;
+  }
   const int dpg = a.Dm / a.G;
   a.DT = dpg >= 128 ? 128 : ((dpg + 63) / 64) * 64;
   const int tiles_per_group = (dpg + a.DT - 1) / a.DT;

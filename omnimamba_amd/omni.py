@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_ce
 from .generation import decode
 from .stack import FusedMLPProjector, OmniMambaLM, StackConfig
 
@@ -46,6 +47,10 @@ def shifted_ce(hidden, head_weight, labels, loss_impl=None):
     t = labels[:, 1:].reshape(-1)
     if loss_impl is not None:
         return loss_impl(h, head_weight, t)
+    if fused_ce.applies(h, head_weight):
+        # token blocks: GEMM -> omk_cross_entropy (loss + gradient over the block's logits) -> gradient GEMMs; the (tokens, vocab)
+        # fp32 logits of the reference (13 GB at vocab 50 288, L 8192, batch 8) never exist
+        return fused_ce.fused_linear_cross_entropy(h, head_weight, t)
     return F.cross_entropy(F.linear(h, head_weight.to(h.dtype)).float(), t, ignore_index=IGNORE_ID)
 
 
