@@ -149,7 +149,7 @@ __global__ void selscan_fwd_kernel(SsArgs a) {
 // The carry into the next pass of 64 * SSC_LC tokens is lane 63's end state, kept per n in a small LDS array private to
 // the wave.  No cross-lane reduction over n (the n loop is inside the lane), no atomics.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int SSC_LC = 16;
+constexpr int SSC_LC_MAX = 16;   // tokens per lane and pass: 16 (fewer scans per token) or 8 (half the registers: more waves per SIMD)
 
 __device__ __forceinline__ void wave_scan_affine(float& p, float& x) {
 #ifdef OMK_EMU
@@ -174,7 +174,7 @@ __device__ __forceinline__ void wave_scan_affine(float& p, float& x) {
 }
 
 // SSC_LC consecutive elements of a unit-stride row starting at t0 (tokens >= L read as 0); 16-byte vectors when possible
-template <class T>
+template <class T, int SSC_LC>
 __device__ __forceinline__ void ssc_load_row(const T* row, int t0, int L, float (&out)[SSC_LC]) {
   constexpr int VEC = 16 / sizeof(T);
   const T* p = row + t0;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void ssc_load_row(const T* row, int t0, int L, float 
     for (int i = 0; i < SSC_LC; i++) out[i] = (t0 + i < L) ? to_f32(p[i]) : 0.f;
   }
 }
-template <class T>
+template <class T, int SSC_LC>
 __device__ __forceinline__ void ssc_store_row(T* row, int t0, int L, const float (&v)[SSC_LC]) {
   constexpr int VEC = 16 / sizeof(T);
   T* p = row + t0;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void ssc_store_row(T* row, int t0, int L, const float
   }
 }
 
-template <class T>
+template <class T, int SSC_LC>
 __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
   __shared__ float scarry[4][64];   // per wave: state at the start of the pass, per n
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
   for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
     const int t0 = tile0 + lane * SSC_LC;
     float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
-    ssc_load_row<T>(urow, t0, a.L, u);
-    ssc_load_row<T>(drow, t0, a.L, dl);
+    ssc_load_row<T, SSC_LC>(urow, t0, a.L, u);
+    ssc_load_row<T, SSC_LC>(drow, t0, a.L, dl);
 #pragma unroll
     for (int i = 0; i < SSC_LC; i++) {
       float v = dl[i] + db;
@@ -239,27 +239,42 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
       u[i] *= dl[i];                          // delta_t u_t
       y[i] = 0.f;
     }
-    for (int n = 0; n < a.N; n++) {
-      const float A2 = load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) * LOG2E;
-      float Bv[SSC_LC], Cv[SSC_LC];
+    // B_t[n] / C_t[n] rows of the lane's tokens: the rows of n + 1 are requested before n is computed (one L2 round trip per n
+    // would otherwise sit in front of every scan)
+    auto load_bc = [&](int n, float (&Bo)[SSC_LC], float (&Co)[SSC_LC]) {
       if (a.Bvar) {
-        if (a.bdt == OMK_F32) ssc_load_row<float>((const float*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
-        else if (a.bdt == OMK_BF16) ssc_load_row<bf16_t>((const bf16_t*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
-        else ssc_load_row<f16_t>((const f16_t*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn, t0, a.L, Bv);
+        const int64_t ro = (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn;
+        if (a.bdt == dtype_of<T>::value) ssc_load_row<T, SSC_LC>((const T*)a.Bm + ro, t0, a.L, Bo);
+        else {
+#pragma unroll
+          for (int i = 0; i < SSC_LC; i++) Bo[i] = t0 + i < a.L ? load_rt(a.Bm, ro + t0 + i, a.bdt) : 0.f;
+        }
       } else {
         const float bc = load_rt(a.Bm, (int64_t)d * a.Bsg + (int64_t)n * a.Bsn, a.bdt);
 #pragma unroll
-        for (int i = 0; i < SSC_LC; i++) Bv[i] = bc;
+        for (int i = 0; i < SSC_LC; i++) Bo[i] = bc;
       }
       if (a.Cvar) {
-        if (a.cdt == OMK_F32) ssc_load_row<float>((const float*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
-        else if (a.cdt == OMK_BF16) ssc_load_row<bf16_t>((const bf16_t*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
-        else ssc_load_row<f16_t>((const f16_t*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn, t0, a.L, Cv);
+        const int64_t ro = (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn;
+        if (a.cdt == dtype_of<T>::value) ssc_load_row<T, SSC_LC>((const T*)a.Cm + ro, t0, a.L, Co);
+        else {
+#pragma unroll
+          for (int i = 0; i < SSC_LC; i++) Co[i] = t0 + i < a.L ? load_rt(a.Cm, ro + t0 + i, a.cdt) : 0.f;
+        }
       } else {
         const float cc = load_rt(a.Cm, (int64_t)d * a.Csg + (int64_t)n * a.Csn, a.cdt);
 #pragma unroll
-        for (int i = 0; i < SSC_LC; i++) Cv[i] = cc;
+        for (int i = 0; i < SSC_LC; i++) Co[i] = cc;
       }
+    };
+    float Bn[SSC_LC], Cn[SSC_LC];
+    load_bc(0, Bn, Cn);
+    for (int n = 0; n < a.N; n++) {
+      const float A2 = load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) * LOG2E;
+      float Bv[SSC_LC], Cv[SSC_LC];
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) { Bv[i] = Bn[i]; Cv[i] = Cn[i]; }
+      load_bc(n + 1 < a.N ? n + 1 : n, Bn, Cn);
       // ---- reduce: the chunk as an affine map x -> P x + X
       float av[SSC_LC];
       float P = 1.f, X = 0.f;
@@ -287,17 +302,17 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
     }
     // ---- epilogue: + D u, gate, store   (u[] holds delta u: the raw u is re-read -- it is still in L1)
     float ur[SSC_LC];
-    ssc_load_row<T>(urow, t0, a.L, ur);
+    ssc_load_row<T, SSC_LC>(urow, t0, a.L, ur);
     if (zrow) {
       float zv[SSC_LC];
-      ssc_load_row<T>(zrow, t0, a.L, zv);
+      ssc_load_row<T, SSC_LC>(zrow, t0, a.L, zv);
 #pragma unroll
       for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]) * (zv[i] * rcp_fast(1.f + exp2_fast(-zv[i] * LOG2E)));
     } else {
 #pragma unroll
       for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]);
     }
-    ssc_store_row<T>(orow, t0, a.L, y);
+    ssc_store_row<T, SSC_LC>(orow, t0, a.L, y);
   }
   if (a.last && lane < a.N) a.last[((int64_t)b * a.Dm + d) * a.N + lane] = carry[lane];
 }
@@ -501,7 +516,10 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
   if (lcontig) {
     const int64_t nseq = (int64_t)a.B * a.Dm;
     dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
-    OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T>), grid, block, 0, stream, a));
+    const char* lce = getenv("OMK_SELSCAN_LC");
+    const bool lc16 = lce ? atoi(lce) == 16 : a.L >= 1024 && nseq < 4096;   // few sequences: fewer, longer passes; many: occupancy
+    if (lc16) OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 16>), grid, block, 0, stream, a));
+    else OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 8>), grid, block, 0, stream, a));
     return OMK_OK;
   }
   const int dpg = a.Dm / a.G;

@@ -104,15 +104,69 @@ class StepGraph:
         return self.logits.clone()
 
 
+class GreedyLoopGraph:
+    """Greedy decoding with the SAMPLING ON THE DEVICE: one captured graph holds the 1-token
+    model step, the argmax, the write of the new id into the step's own input buffer and into the output slot, and the
+    position / length counters.  The host only replays it -- no per-token copy_, clone, argmax launch or torch.cat from
+    Python (the reference's loop, generation.py:239-257, does all of those per token).  Same ids as the host loop; used
+    when top_k == 1 and there is no EOS test (the T2I path: exactly num_tokens codes, omnimamba.py:321)."""
+
+    def __init__(self, model, inference_params, batch_size, max_seqlen, n_steps, task, n_warmups=2):
+        dev = next(iter(model.parameters())).device
+        self.ip = inference_params
+        self.input_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
+        self.position_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
+        self.slot = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
+        self.tokens = torch.zeros(batch_size, max(n_steps, 1), dtype=torch.long, device=dev)
+        off = inference_params.seqlen_offset
+        inference_params.seqlen_offset = max_seqlen - 1        # warm-ups run the STEP branch; prefill overwrites the caches later
+        inference_params.lengths_per_sample[:] = inference_params.seqlen_offset
+
+        def step():
+            out = model(self.input_ids, None, position_ids=self.position_ids, task=task, inference_params=inference_params,
+                        num_last_tokens=1)
+            nxt = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1).argmax(dim=-1, keepdim=True)
+            self.tokens.scatter_(1, self.slot.clamp(max=self.tokens.shape[1] - 1), nxt)
+            self.input_ids.copy_(nxt)
+            self.position_ids.add_(1)
+            self.slot.add_(1)
+            inference_params.lengths_per_sample.add_(1)
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(n_warmups):
+                self.position_ids.zero_()
+                step()
+            s.synchronize()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        self.position_ids.zero_()
+        with torch.cuda.graph(self.graph):
+            step()
+        inference_params.seqlen_offset = off
+
+    def run(self, first_ids, first_pos, n_steps):
+        self.input_ids.copy_(first_ids)
+        self.position_ids.fill_(first_pos)
+        self.slot.zero_()
+        self.ip.lengths_per_sample[:] = first_pos
+        for _ in range(n_steps):
+            self.graph.replay()
+        return self.tokens[:, :n_steps].clone()
+
+
 @torch.inference_mode()
 def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0,
-           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None):
+           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None, device_loop=False):
     """Prefill with ``input_embeddings`` (batch, seqlen_og, d), then sample until ``seqlen_offset >= max_length - 1`` (or
     EOS).  Returns the token matrix (batch, seqlen_og + n_sampled): prompt ids followed by the sampled ids.
     ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact."""
     batch_size, seqlen_og = input_ids.shape
     dev = input_embeddings.device
     graph = None
+    if device_loop and cg and top_k == 1 and eos_token_id is None and teacher_outputs is None and vocab_size is None and trace is None:
+        return _decode_device_loop(input_ids, input_embeddings, model, max_length, task)
     if cg:
         cache = getattr(model, "_decoding_cache", None)
         key = (batch_size, max_length, task)
@@ -162,4 +216,30 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
             tok = sample(lg, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temperature)
         last = tok.unsqueeze(1)
         seqs = torch.cat([seqs, last], dim=1)
+    return seqs
+
+
+def _decode_device_loop(input_ids, input_embeddings, model, max_length, task):
+    """Prefill (eager, fills the caches), then max_length - P - 1 replays of GreedyLoopGraph."""
+    batch_size, seqlen_og = input_ids.shape
+    dev = input_embeddings.device
+    n_steps = max_length - 1 - seqlen_og
+    cache = getattr(model, "_decoding_cache", None)
+    key = ("device_loop", batch_size, max_length, n_steps, task)
+    if cache is None or cache.get("key") != key:
+        dtype = next(iter(model.parameters())).dtype
+        ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
+                             key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
+                             lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
+        cache = {"key": key, "ip": ip, "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task)}
+        model._decoding_cache = cache
+    ip, graph = cache["ip"], cache["graph"]
+    ip.reset(max_length, batch_size)
+    out = model(None, input_embeddings, position_ids=None, task=task, inference_params=ip, num_last_tokens=1)
+    first = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1).argmax(dim=-1, keepdim=True)
+    ip.seqlen_offset = seqlen_og
+    seqs = torch.cat([input_ids, first], dim=1)
+    if n_steps > 0:
+        seqs = torch.cat([seqs, graph.run(first, seqlen_og, n_steps)], dim=1)
+        ip.seqlen_offset = seqlen_og + n_steps
     return seqs

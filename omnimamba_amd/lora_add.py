@@ -25,19 +25,34 @@ def applies(result2d: torch.Tensor, h2d: torch.Tensor, lora_b: torch.Tensor) -> 
             and (result2d.stride(0) * result2d.element_size()) % 16 == 0 and (h2d.stride(0) * h2d.element_size()) % 16 == 0)
 
 
+# autograd nodes that may have produced the base projection's output WITHOUT saving that output for their own backward
+# (omnimamba_amd.linear's two nodes, the library linear / matmul nodes, pure view nodes).  Anything else -- an activation
+# checkpoint wrapper, a node with saved-tensor hooks on its result -- makes TaskLoRALinear take the out-of-place addmm.
+_SAFE_PRODUCERS = {"_XGradFnBackward", "_WGradFnBackward", "MmBackward0", "AddmmBackward0", "LinearBackward0", "BmmBackward0",
+                   "ViewBackward0", "UnsafeViewBackward0", "ReshapeAliasBackward0", "AliasBackward0", "ToCopyBackward0"}
+
+
+def producer_is_safe(result: torch.Tensor) -> bool:
+    """True when overwriting `result` cannot invalidate what its producer saved (see _SAFE_PRODUCERS)."""
+    fn = result.grad_fn
+    return fn is None or type(fn).__name__ in _SAFE_PRODUCERS
+
+
 class _LoraAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, result2d, h2d, lora_b, scale):
         lib = get_lib()
         require_device(lib, result2d, h2d, lora_b)
-        # in place on `result2d`, declared to autograd (mark_dirty bumps the version counter): a producer or hook that
-        # saved the base projection's output for its own backward now raises instead of silently reading the sum
-        p = K.LoraAdd(out=K.T(result2d), h=K.T(h2d), lora_b=K.T(lora_b), scale=float(scale))
-        K.run(lib, "omk_lora_add", p, result2d)
-        ctx.mark_dirty(result2d)
+        # in place on the storage of `result2d`: nothing keeps the base projection's output for backward (its gradient only
+        # needs dy, x and W), so overwriting it is safe; autograd sees an ordinary out-of-place node returning an alias.
+        # (ctx.mark_dirty cannot be used: the base projection's output is a view made inside a custom Function --
+        # linear._WGradFn -- and autograd forbids in-place on those.)  `producer_is_safe` guards the assumption.
+        out = result2d.detach()
+        p = K.LoraAdd(out=K.T(out), h=K.T(h2d), lora_b=K.T(lora_b), scale=float(scale))
+        K.run(lib, "omk_lora_add", p, out)
         ctx.save_for_backward(h2d, lora_b)
         ctx.scale = float(scale)
-        return result2d
+        return out
 
     @staticmethod
     def backward(ctx, dy):

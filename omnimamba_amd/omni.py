@@ -129,14 +129,24 @@ class OmniMambaPath(nn.Module):
         hidden = lm.backbone(None, emb, None, "mmu")
         return shifted_ce(hidden, lm.lm_head.weight, labels, self.loss_impl)
 
-    # ---- T2I generation (omnimamba.py:311-337 minus the VQ decode tail)
+    @staticmethod
+    def codebook_entries(codebook, indices, shape, l2_norm=True):
+        """The entry of the VQ tail: `quantize.get_codebook_entry` (llamagen_tokenizer/tokenizer_image/vq_model.py:261-277,
+        reached from mamba_vlm.py:104-108 with shape [B, 8, 16, 16]): l2-normalised codebook rows of the sampled ids as a
+        channel-first latent.  The convolutional decoder behind it is out of scope."""
+        emb = F.normalize(codebook, p=2, dim=-1) if l2_norm else codebook
+        zq = emb[indices.reshape(-1)]
+        return zq.reshape(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous()
+
+    # ---- T2I generation (omnimamba.py:311-337 minus the VQ decoder network)
     @torch.no_grad()
     def t2i_generate(self, text_ids, temperature=1.0, top_k=0, top_p=1.0, fast=True):
         bb = self.backbone
         emb = bb.caption_embed(self.llm_backbone.embed_input_ids(text_ids), train=False)
         emb = emb + bb.pos_embed[:, : emb.shape[1]]
         max_length = self.llm_backbone.num_tokens + emb.shape[1]
+        # greedy + graph: the sampling runs inside the captured step (generation.GreedyLoopGraph), same ids as the host loop
         x = decode(text_ids, emb, self.llm_backbone.mamba, max_length, top_k=top_k, top_p=top_p, temperature=temperature,
-                   cg=fast, task="t2i")
+                   cg=fast, task="t2i", device_loop=fast and top_k == 1)
         self.llm_backbone.mamba._decoding_cache = None
         return x[: text_ids.shape[0], emb.shape[1]:]

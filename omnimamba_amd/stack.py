@@ -148,7 +148,7 @@ class TaskLoRALinear(nn.Linear):
         # (an in-place addmm_ on the base GEMM's output would save the 279 MB copy the out-of-place form starts with, but
         # the library then picks a much slower GEMM: 461 -> 509 ms per 1.3B training step)
         r2, h2 = result.reshape(-1, out_f), h.reshape(-1, h.shape[-1])
-        if os.environ.get("OMK_LORA_ADDMM") != "1" and r2.data_ptr() == result.data_ptr() and LA.applies(r2, h2, B.weight):
+        if os.environ.get("OMK_LORA_ADDMM") != "1" and r2.data_ptr() == result.data_ptr() and LA.applies(r2, h2, B.weight) and LA.producer_is_safe(result):
             # one streaming pass over the result (read once, write once) instead of the library's copy + K = 8 GEMM
             return LA.lora_add(r2, h2, B.weight, self.scaling).view(result.shape)
         fused = torch.addmm(r2, h2, B.weight.t().to(h.dtype), alpha=self.scaling)

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd.generation import decode  # noqa: E402
+from omnimamba_amd.omni import OmniMambaPath  # noqa: E402
 from omnimamba_amd.stack import OmniMambaLM, StackConfig  # noqa: E402
 from omnimamba_amd.train import Stage2Step, TrainConfig, init_distributed, synthetic_batch, wrap_ddp  # noqa: E402
 
@@ -24,7 +25,7 @@ def bench_decode(args, dev):
     model = OmniMambaLM(cfg, device=dev, dtype=wdt).eval()
     B, P, new = args.batch, 72, 256
     ids = torch.zeros(B, P, dtype=torch.long, device=dev)
-    emb = torch.randn(B, P, cfg.d_model, device=dev, dtype=wdt)
+    emb = torch.randn(B, P, cfg.d_model, device=dev, dtype=wdt) * 0.02 + model.backbone.pos_embed[:, :P].to(wdt)
     out = {}
     for cg in (True, False) if args.eager_too else (True,):
         decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=cg)          # warm-up (captures the graph)
@@ -49,13 +50,13 @@ def bench_train(args, dev, rank, world):
     master weights; DDP over RCCL when world > 1."""
     torch.manual_seed(0)
     L = args.seqlen
-    cfg = StackConfig.omnimamba_1_3b(t2i_positions=max(L, 329), mmu_positions=max(L, 1500))
-    model = OmniMambaLM(cfg, device=dev, dtype=torch.float32)
-    model.set_stage(args.stage)
+    tasks = tuple(args.tasks.split(","))
+    cfg = StackConfig.omnimamba_1_3b(t2i_positions=max(L, 329), mmu_positions=max(L, 1500), t2i_task="t2i" in tasks, mmu_task="mmu" in tasks)
+    model = OmniMambaPath(cfg, stage=args.stage, device=dev, dtype=torch.float32)
     tc = TrainConfig()
     net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
     step = Stage2Step(model, tc, ddp_model=net)
-    batch = synthetic_batch(cfg, args.batch, L, dev, torch.bfloat16, rank=rank)
+    batch = synthetic_batch(cfg, args.batch, L, dev, torch.bfloat16, rank=rank, tasks=tasks)
     for _ in range(args.warmup):
         step(batch)
     torch.cuda.synchronize()
@@ -74,9 +75,9 @@ def bench_train(args, dev, rank, world):
         dt = t.item()
     if rank == 0:
         trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        print(json.dumps({"workload": f"OmniMamba-1.3B stage-2 step ({args.stage}), 2 tasks x L={L}", "n_gpus": world,
+        print(json.dumps({"workload": f"OmniMamba-1.3B step (stage {args.stage}), tasks {tasks} x L={L}", "n_gpus": world,
                           "batch_per_gpu": args.batch, "ms_per_step": round(dt * 1e3, 2),
-                          "tokens_per_s": round(world * 2 * args.batch * L / dt, 1), "trainable_params": trainable,
+                          "tokens_per_s": round(world * len(tasks) * args.batch * L / dt, 1), "trainable_params": trainable,
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "dtype": "bf16 autocast"}), flush=True)
 
 
@@ -88,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)   # one warm-up step is not enough: optimizer state and GEMM heuristics settle in the second
     ap.add_argument("--stage", default="finetune")
+    ap.add_argument("--tasks", default="t2i,mmu", help="t2i,mmu (stage 2) or mmu (stage-1 MMU pretrain, BASELINE configs[3])")
     ap.add_argument("--eager-too", action="store_true")
     ap.add_argument("--weights", choices=["f32", "bf16"], default="f32")
     args = ap.parse_args()

@@ -1,0 +1,21 @@
+"""Developer tool: Mamba-1 selective_scan forward at BASELINE configs[0] (B 2, L 1024, D 768, N 16 fp32) and scaled batches."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omnimamba_amd.selective_scan import selective_scan_fn  # noqa: E402
+from tools.bench_scan import timeit  # noqa: E402
+
+dev = torch.device("cuda:0")
+Dm, L, N = 768, 1024, 16
+for dtype in (torch.float32, torch.bfloat16):
+    for Bsz in (2, 16, 64):
+        torch.manual_seed(0)
+        u, delta, z = (torch.randn(Bsz, Dm, L, device=dev).to(dtype) for _ in range(3))
+        A = -(torch.rand(Dm, N, device=dev) + 0.1)
+        Bm, Cm = torch.randn(Bsz, N, L, device=dev).to(dtype), torch.randn(Bsz, N, L, device=dev).to(dtype)
+        D, db = torch.randn(Dm, device=dev), 0.1 * torch.randn(Dm, device=dev)
+        ms = min(timeit(lambda: selective_scan_fn(u, delta, A, Bm, Cm, D, z, db, True), 20, 3) for _ in range(3))
+        es = 4 if dtype == torch.float32 else 2
+        nb = Bsz * L * (4 * Dm * es + 2 * N * es)
+        print(f"{str(dtype):15s} B={Bsz:3d}: {ms * 1e3:8.1f} us  {Bsz * L * Dm / ms / 1e3:9.1f} M-elem/s  {nb / ms / 1e6:7.1f} GB/s = {nb / ms / 1e6 / 80:5.1f} % of 8 TB/s  (LC={os.environ.get('OMK_SELSCAN_LC', 'auto')})", flush=True)
