@@ -210,14 +210,28 @@ __device__ __forceinline__ void ssc_store_row(T* row, int t0, int L, const float
   }
 }
 
-template <class T, int SSC_LC>
-__global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
-  __shared__ float scarry[4][64];   // per wave: state at the start of the pass, per n
+// SHARE: the eight waves of a workgroup are eight adjacent channels of one (batch, group) and share the B / C rows of the pass
+// through LDS (one coalesced fill per pass instead of every wave pulling every row through its CU's L1: at B 64 the per-wave
+// form moved 6.4 GB through the vector caches for 0.8 GB of HBM data).  LDS image of a row: 16-byte piece v of lane j's
+// tokens at slot v * 64 + j, so that a ds_read_b128 of the wave is 1 KB contiguous.
+template <class T, int SSC_LC, bool SHARE>
+__global__ __launch_bounds__(SHARE ? 512 : 256) void selscan_fwd_chunked_kernel(SsArgs a) {
+  constexpr int NW = SHARE ? 8 : 4;
+  constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
+  __shared__ float scarry[NW][64];   // per wave: state at the start of the pass, per n
+  OMK_DYN_SMEM(bc_raw);              // SHARE: [2][N][64 * SSC_LC] of T
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t seq = (int64_t)blockIdx.x * 4 + wv;   // the four waves of a workgroup: adjacent channels of one batch element
-  if (seq >= (int64_t)a.B * a.Dm) return;
+  int64_t seq;
+  if (SHARE) {   // workgroup = (batch, 8-channel tile inside one group)
+    const int tpb = a.Dm / 8;
+    seq = (int64_t)(blockIdx.x / tpb) * a.Dm + (int64_t)(blockIdx.x % tpb) * 8 + wv;
+  } else {
+    seq = (int64_t)blockIdx.x * 4 + wv;   // the four waves of a workgroup: adjacent channels of one batch element
+    if (seq >= (int64_t)a.B * a.Dm) return;
+  }
   const int b = (int)(seq / a.Dm), d = (int)(seq % a.Dm);
   const int g = d / (a.Dm / a.G);
+  T* sBC = (T*)bc_raw;
   const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
   const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
   const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
@@ -228,6 +242,27 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
   carry[lane] = 0.f;
   for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
     const int t0 = tile0 + lane * SSC_LC;
+    if (SHARE) {
+      block_sync();   // every wave is done with the rows of the previous pass
+      const int rows = (a.Bvar ? a.N : 0) + (a.Cvar ? a.N : 0);
+      for (int i = threadIdx.x; i < rows * PPR; i += 512) {
+        const int r = i / PPR, q = i % PPR;
+        const bool isB = a.Bvar && r < a.N;
+        const int n = isB ? r : r - (a.Bvar ? a.N : 0);
+        const T* row = isB ? (const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn
+                           : (const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn;
+        const int e0 = q * VEC, tq = tile0 + e0;
+        T* dst = sBC + ((size_t)(isB || !a.Bvar ? 0 : a.N) + n) * (64 * SSC_LC) + ((e0 % SSC_LC) / VEC * 64 + e0 / SSC_LC) * VEC;
+        const T* src = row + tq;
+        if (tq + VEC <= a.L && (((uintptr_t)src) & 15) == 0) {
+          *reinterpret_cast<vec_t<T, VEC>*>(dst) = *reinterpret_cast<const vec_t<T, VEC>*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) dst[e] = tq + e < a.L ? src[e] : T{};
+        }
+      }
+      block_sync();
+    }
     float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, u);
     ssc_load_row<T, SSC_LC>(drow, t0, a.L, dl);
@@ -241,8 +276,18 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
     }
     // B_t[n] / C_t[n] rows of the lane's tokens: the rows of n + 1 are requested before n is computed (one L2 round trip per n
     // would otherwise sit in front of every scan)
+    auto lds_row = [&](const T* rowp, float (&o)[SSC_LC]) {
+#pragma unroll
+      for (int v = 0; v < SSC_LC / VEC; v++) {
+        float w[VEC];
+        load_vec<T, VEC>(rowp + (v * 64 + lane) * VEC, w);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o[v * VEC + e] = w[e];
+      }
+    };
     auto load_bc = [&](int n, float (&Bo)[SSC_LC], float (&Co)[SSC_LC]) {
-      if (a.Bvar) {
+      if (SHARE && a.Bvar) lds_row(sBC + (size_t)n * (64 * SSC_LC), Bo);
+      else if (a.Bvar) {
         const int64_t ro = (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn;
         if (a.bdt == dtype_of<T>::value) ssc_load_row<T, SSC_LC>((const T*)a.Bm + ro, t0, a.L, Bo);
         else {
@@ -254,7 +299,8 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
 #pragma unroll
         for (int i = 0; i < SSC_LC; i++) Bo[i] = bc;
       }
-      if (a.Cvar) {
+      if (SHARE && a.Cvar) lds_row(sBC + ((size_t)(a.Bvar ? a.N : 0) + n) * (64 * SSC_LC), Co);
+      else if (a.Cvar) {
         const int64_t ro = (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn;
         if (a.cdt == dtype_of<T>::value) ssc_load_row<T, SSC_LC>((const T*)a.Cm + ro, t0, a.L, Co);
         else {
@@ -268,22 +314,27 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
       }
     };
     float Bn[SSC_LC], Cn[SSC_LC];
-    load_bc(0, Bn, Cn);
+    if (!SHARE) load_bc(0, Bn, Cn);
+    float sdl = 0.f;   // the chunk's decay is exp2(A2 * sum of delta): one product per n instead of a running one
+#pragma unroll
+    for (int i = 0; i < SSC_LC; i++) sdl += dl[i];
     for (int n = 0; n < a.N; n++) {
       const float A2 = load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) * LOG2E;
       float Bv[SSC_LC], Cv[SSC_LC];
+      if (SHARE) load_bc(n, Bv, Cv);
+      else {
 #pragma unroll
-      for (int i = 0; i < SSC_LC; i++) { Bv[i] = Bn[i]; Cv[i] = Cn[i]; }
-      load_bc(n + 1 < a.N ? n + 1 : n, Bn, Cn);
+        for (int i = 0; i < SSC_LC; i++) { Bv[i] = Bn[i]; Cv[i] = Cn[i]; }
+        load_bc(n + 1 < a.N ? n + 1 : n, Bn, Cn);
+      }
       // ---- reduce: the chunk as an affine map x -> P x + X
       float av[SSC_LC];
-      float P = 1.f, X = 0.f;
+      float P = exp2_fast(sdl * A2), X = 0.f;
 #pragma unroll
       for (int i = 0; i < SSC_LC; i++) {
         av[i] = exp2_fast(dl[i] * A2);
         Bv[i] *= u[i];                        // b_t = delta_t u_t B_t[n]
         X = fmaf(av[i], X, Bv[i]);
-        P *= av[i];
       }
       // ---- scan across the wave, then the start state of this lane's chunk
       wave_scan_affine(P, X);
@@ -515,11 +566,27 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
                        (!a.Cvar || a.Csl == 1) && !a.ckpt && a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
   if (lcontig) {
     const int64_t nseq = (int64_t)a.B * a.Dm;
-    dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
     const char* lce = getenv("OMK_SELSCAN_LC");
     const bool lc16 = lce ? atoi(lce) == 16 : a.L >= 1024 && nseq < 4096;   // few sequences: fewer, longer passes; many: occupancy
-    if (lc16) OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 16>), grid, block, 0, stream, a));
-    else OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 8>), grid, block, 0, stream, a));
+    const int lc = lc16 ? 16 : 8;
+    // shared B / C rows: 8 adjacent channels of one group per workgroup, rows of u's dtype, <= 64 KB of LDS
+    const size_t es = dtype_size(udt);
+    const size_t bc_bytes = (size_t)((a.Bvar ? a.N : 0) + (a.Cvar ? a.N : 0)) * 64 * lc * es;
+    const bool share = (a.Bvar || a.Cvar) && (a.Dm / a.G) % 8 == 0 && (!a.Bvar || a.bdt == udt) && (!a.Cvar || a.cdt == udt) &&
+                       bc_bytes <= 64 * 1024 && !getenv("OMK_SELSCAN_NOSHARE");
+#define SSC_GO(T, LC_, SH_, GRID_, BLK_, SM_) do { \
+      if ((SM_) > 0 && OMK_SET_MAX_DYN_SMEM((selscan_fwd_chunked_kernel<T, LC_, SH_>), SM_)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", (size_t)(SM_)); \
+      OMK_LAUNCH((selscan_fwd_chunked_kernel<T, LC_, SH_>), GRID_, BLK_, SM_, stream, a); } while (0)
+    if (share) {
+      dim3 grid((unsigned)(nseq / 8)), block(512);
+      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 16, true, grid, block, bc_bytes));
+      else OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 8, true, grid, block, bc_bytes));
+    } else {
+      dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
+      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 16, false, grid, block, 0));
+      else OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 8, false, grid, block, 0));
+    }
+#undef SSC_GO
     return OMK_OK;
   }
   const int dpg = a.Dm / a.G;

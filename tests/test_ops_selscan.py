@@ -14,7 +14,9 @@ def rel(a, b):
 @pytest.mark.parametrize("Dm,L,N,G,bvar", [(70, 45, 16, 1, True), (12, 33, 8, 2, True), (6, 20, 4, 1, False), (130, 37, 24, 1, True),
                                            # L >= 64 with L-contiguous storage: the chunked associative scan (one wave per channel, lanes = time
                                            # chunks); 1100 = two passes of 1024 tokens with a carry, ragged tail, unaligned rows
-                                           (10, 200, 16, 1, True), (6, 1100, 16, 2, True), (5, 130, 4, 1, False), (3, 1024, 24, 1, True)])
+                                           (10, 200, 16, 1, True), (6, 1100, 16, 2, True), (5, 130, 4, 1, False), (3, 1024, 24, 1, True),
+                                           # 8 | channels per group: the workgroup's eight waves share the B / C rows of a pass through LDS
+                                           (16, 600, 16, 2, True), (8, 1100, 8, 1, True), (24, 130, 4, 1, False)])
 def test_selective_scan_fwd(dev, dtype, layout, Dm, L, N, G, bvar):
     from omnimamba_amd.selective_scan import selective_scan_fn
     torch.manual_seed(0)
