@@ -392,11 +392,10 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
   float* dtp = (float*)p->workspace;
   GScan g = {};
-  // the MFMA forward scan reads the raw dt itself (bias / softplus / clamp in its scalar pass): no preparation launch.  The
-  // generic kernel, the two-waves-per-head kernel and split sequences (their state pass) take the prepared (B, H, L) form.
-  g.dt_raw = p->dt.data; g.dt_sb = p->dt.stride[0]; g.dt_sl = p->dt.stride[1]; g.dt_sh = p->dt.stride[2]; g.dt_dt = p->dt.dtype;
-  g.dt_bias = p->dt_bias.data; g.dt_bias_dt = p->dt_bias.dtype; g.dt_softplus = p->dt_softplus;
-  g.dt_lo = p->dt_min; g.dt_hi = p->dt_max > 0.f ? p->dt_max : INFINITY;
+  // (tried in round 2: the scan reading the raw (B, L, H) dt itself and applying bias / softplus / clamp in its scalar pass, to
+  // save this 16 us launch -- 280 us against 236 + 16 us: the 2-byte loads at stride H are 64 requests per wave and chunk and the
+  // softplus lands on wave 0's critical path between the publish and the barrier.  Not kept.)
+  launch_dt_prep(p->dt, p->dt_bias, d, dtp, nullptr, p->dt_softplus, p->dt_min, p->dt_max, stream);
   g.mode = GS_Y; g.U = make_src(p->x, false); g.K = make_src(p->Bm, true); g.Q = make_src(p->Cm, true);
   if (present(p->z)) g.Z = make_src(p->z, false);
   g.dtp = dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L; g.DU = d.P; g.DK = d.N; g.reverse = 0; g.w_is_dt = 1;
@@ -415,9 +414,6 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
 #endif
   if (ssd_seg_bytes(d.B * d.H, d.L) && !getenv("OMK_SSD_NO_SPLIT")) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
-  const bool raw_ok = !p->force_generic && ssd_mfma_launch(g, nullptr, 1) == OMK_OK && !ssd_v5a_applies(g) &&
-                      !(g.seg && ssd_segments(d.B * d.H, d.L).nseg > 1) && !getenv("OMK_SSD_DT_PREP");
-  if (!raw_ok) launch_dt_prep(p->dt, p->dt_bias, d, dtp, nullptr, p->dt_softplus, p->dt_min, p->dt_max, stream);
   rc = run_scan(g, p->force_generic, stream);
   if (rc) return rc;
   return finish_launch("ssd_scan_fwd");

@@ -101,10 +101,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
   const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
   const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh;
-  constexpr bool RAWDT = MODE == GS_Y && !STATE;   // the forward scan proper reads the raw dt; every other pass the prepared dt'
   const float* dtrow = a.dtp + ((int64_t)b * a.H + h) * a.L;
-  const char* dtraw = (const char*)a.dt_raw + ((int64_t)b * a.dt_sb + (int64_t)h * a.dt_sh) * (a.dt_dt == OMK_F32 ? 4 : 2);
-  const float dtb_h = (RAWDT && a.dt_bias) ? load_rt(a.dt_bias, h, a.dt_bias_dt) : 0.f;
   const int ksl = (int)a.K.sl, qsl = (int)a.Q.sl, usl = (int)a.U.sl, osl = (int)a.osl;
   const uint32_t koff0 = (uint32_t)(rowtok(rowk) * ksl + ck8), uoff0 = (uint32_t)(rowtok(rowu) * usl + cu8);
   const uint32_t qoff0 = (uint32_t)(rowtok(16 * w + t16) * qsl + 8 * g16);
@@ -139,14 +136,8 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     for (int r = 0; r < 2; r++) ru[r] = ld16(Uc + (rtk_u + du32 * r < lim ? uoff0 + (uint32_t)(r * ustep) : (uint32_t)cu8));
     // token scalars (consumed by wave 0, loaded by every wave to keep the instruction stream uniform): lanes = rows
     const int t = stlo + rtk_l, ta = rev ? t + 1 : t;
-    if (RAWDT) {   // forward scan: dt straight from the caller's (B, L, H) tensor, bias / softplus / clamp applied in scalars()
-      const int64_t o = (int64_t)(t < a.L ? t : 0) * a.dt_sl;
-      rdt = a.dt_dt == OMK_BF16 ? bf16_to_f32(((const uint16_t*)dtraw)[o]) : load_rt(dtraw, o, a.dt_dt);
-      rda = rdt;
-    } else {
-      rdt = dtrow[t < a.L ? t : 0];   // raw loads: the selects wait in scalars() so nothing stalls on them here
-      rda = dtrow[ta < a.L ? ta : 0];
-    }
+    rdt = dtrow[t < a.L ? t : 0];   // raw loads: the selects wait in scalars() so nothing stalls on them here
+    rda = dtrow[ta < a.L ? ta : 0];
   };
   const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
   auto commit = [&](int buf) {
@@ -167,13 +158,6 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const float Ah2 = Ah * LOG2E;
   float segdec = 0.f;   // STATE: log2 of the segment's total decay (wave 0)
   auto scalars = [&](int buf, bool fresh) {   // wave 0 only; lanes = rows of the staged chunk (fresh: not a re-stage)
-    if (RAWDT) {   // the arithmetic of ssd_dt_prep_kernel (ssd.hip), one value per lane
-      float v = rdt + dtb_h;
-      if (a.dt_softplus) v = softplus_f(v);
-      v = v < a.dt_lo ? a.dt_lo : v;
-      v = v > a.dt_hi ? a.dt_hi : v;
-      rdt = v; rda = v;
-    }
     {
       const int t = stlo + rowtok(lane);
       const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;

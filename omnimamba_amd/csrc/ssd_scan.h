@@ -28,9 +28,6 @@ struct GScan {
   int mode;
   Src U, K, Q, X4, Z;   // X4: group vector of length DU for the token-scalar epilogue (C in dC, B in dB); Z: gate (Y)
   const float* dtp;     // (B, H, L) processed dt' (bias + softplus + clamp applied)
-  // forward scan (MFMA kernel): the raw dt instead -- element (b, t, h) at dt_raw[b * dt_sb + t * dt_sl + h * dt_sh]; the kernel
-  // applies bias / softplus / clamp itself (one value per lane and chunk) and the separate dt preparation launch is skipped
-  const void* dt_raw; int64_t dt_sb, dt_sl, dt_sh; int dt_dt; const void* dt_bias; int dt_bias_dt; int dt_softplus; float dt_lo, dt_hi;
   const float* A;       // (H)
   int B, H, G, L, DU, DK;
   int reverse, w_is_dt;

@@ -67,7 +67,7 @@ def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
 class StepGraph:
     """The captured 1-token model step: static input buffers refreshed by copy_, states updated in place."""
 
-    def __init__(self, model, inference_params, batch_size, max_seqlen, task, n_warmups=2):
+    def __init__(self, model, inference_params, batch_size, max_seqlen, task, n_warmups=2, mempool=None):
         dev = next(iter(model.parameters())).device
         self.ip = inference_params
         self.input_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
@@ -92,7 +92,7 @@ class StepGraph:
                 torch.distributed.barrier()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, pool=mempool):
             self.logits = fwd()
         inference_params.seqlen_offset = off
 
@@ -168,16 +168,23 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     if device_loop and cg and top_k == 1 and eos_token_id is None and teacher_outputs is None and vocab_size is None and trace is None:
         return _decode_device_loop(input_ids, input_embeddings, model, max_length, task)
     if cg:
+        # the reference's cache rule (generation.py:308-369): one set of state tensors and one graph memory pool, thrown away
+        # only when the device / dtype changes or a LARGER batch or max_seqlen arrives; captured steps are kept per
+        # (batch, decoding length 1) -- here per task as well, because the captured step bakes the task's LoRA and head.
+        # (Deviation: a SMALLER batch re-allocates too; the reference would run it on the larger state tensors.)
         cache = getattr(model, "_decoding_cache", None)
-        key = (batch_size, max_length, task)
-        if cache is None or cache.get("key") != key:
-            dtype = next(iter(model.parameters())).dtype
+        p0 = next(iter(model.parameters()))
+        if (cache is None or cache.get("kind") != "host" or (cache["device"], cache["dtype"]) != (p0.device, p0.dtype)
+                or batch_size != cache["max_batch_size"] or max_length > cache["max_seqlen"]):
             ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
-                                 key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
+                                 key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, p0.dtype),
                                  lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
-            cache = {"key": key, "ip": ip, "graph": StepGraph(model, ip, batch_size, max_length, task)}
+            cache = {"kind": "host", "device": p0.device, "dtype": p0.dtype, "max_batch_size": batch_size, "max_seqlen": max_length,
+                     "ip": ip, "mempool": torch.cuda.graphs.graph_pool_handle(), "graphs": {}}
             model._decoding_cache = cache
-        inference_params, graph = cache["ip"], cache["graph"]
+        if (batch_size, 1, task) not in cache["graphs"]:
+            cache["graphs"][batch_size, 1, task] = StepGraph(model, cache["ip"], batch_size, cache["max_seqlen"], task, mempool=cache["mempool"])
+        inference_params, graph = cache["ip"], cache["graphs"][batch_size, 1, task]
         inference_params.reset(max_length, batch_size)
     else:
         inference_params = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size)
@@ -226,12 +233,12 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task):
     n_steps = max_length - 1 - seqlen_og
     cache = getattr(model, "_decoding_cache", None)
     key = ("device_loop", batch_size, max_length, n_steps, task)
-    if cache is None or cache.get("key") != key:
+    if cache is None or cache.get("kind") != "device_loop" or cache.get("key") != key:
         dtype = next(iter(model.parameters())).dtype
         ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
                              key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
                              lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
-        cache = {"key": key, "ip": ip, "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task)}
+        cache = {"kind": "device_loop", "key": key, "ip": ip, "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task)}
         model._decoding_cache = cache
     ip, graph = cache["ip"], cache["graph"]
     ip.reset(max_length, batch_size)
