@@ -16,6 +16,9 @@ int fail(int code, const char* fmt, ...) {
 int finish_launch(const char* what) {
 #ifndef OMK_EMU
   hipError_t e = hipGetLastError();
+  // the library holds gfx950 code objects only: on any other device the launch fails to find a kernel image
+  if (e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction || e == hipErrorSharedObjectInitFailed || e == hipErrorInvalidImage)
+    return fail(OMK_EARCH, "%s: no kernel image for this device (%s): libomnimamba_hip is built for gfx950 (MI355X) only", what, hipGetErrorString(e));
   if (e != hipSuccess) return fail(OMK_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
 #endif
   (void)what;

@@ -75,3 +75,71 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     """u, delta, z: (batch, dim, L); A: (dim, dstate); B, C: (dim, dstate) | (batch, dstate, L) |
     (batch, ngroups, dstate, L); D, delta_bias: (dim).  out: (batch, dim, L) [, last_state (batch, dim, dstate) fp32]."""
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False):
+    """The pure-PyTorch form of the same signature (``mamba_ssm.ops.selective_scan_interface.selective_scan_ref``, the
+    function BASELINE.json configs[0] times on the host): the recurrence of SURVEY.md Appendix A.5 written with torch ops,
+    any device, fp32 arithmetic.  It is an API of its own, not a fallback of ``selective_scan_fn``."""
+    dtype_in = u.dtype
+    u, delta = u.float(), delta.float()
+    if delta_bias is not None:
+        delta = delta + delta_bias[..., None].float()
+    if delta_softplus:
+        delta = torch.nn.functional.softplus(delta)
+    batch, dim, dstate = u.shape[0], A.shape[0], A.shape[1]
+    is_variable_B, is_variable_C = B.dim() >= 3, C.dim() >= 3
+    B, C = B.float(), C.float()
+    if is_variable_B and B.dim() == 3:
+        B = B.unsqueeze(1)
+    if is_variable_C and C.dim() == 3:
+        C = C.unsqueeze(1)
+    x = A.new_zeros((batch, dim, dstate), dtype=torch.float32)
+    deltaA = torch.exp(torch.einsum("bdl,dn->bdln", delta, A.float()))
+    if not is_variable_B:
+        deltaB_u = torch.einsum("bdl,dn,bdl->bdln", delta, B, u)
+    else:
+        Bx = B.repeat_interleave(dim // B.shape[1], dim=1)                      # (batch, dim, dstate, L)
+        deltaB_u = torch.einsum("bdl,bdnl,bdl->bdln", delta, Bx, u)
+    if is_variable_C:
+        Cx = C.repeat_interleave(dim // C.shape[1], dim=1)
+    ys = []
+    for i in range(u.shape[2]):
+        x = deltaA[:, :, i] * x + deltaB_u[:, :, i]
+        ys.append(torch.einsum("bdn,dn->bd", x, C) if not is_variable_C else torch.einsum("bdn,bdn->bd", x, Cx[:, :, :, i]))
+    y = torch.stack(ys, dim=2)
+    out = y if D is None else y + u * D.float()[..., None]
+    if z is not None:
+        out = out * torch.nn.functional.silu(z.float())
+    out = out.to(dtype_in)
+    return out if not return_last_state else (out, x)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B=None,
+                   C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """The Mamba-1 mixer after in_proj (``mamba_ssm.ops.selective_scan_interface.mamba_inner_fn``): causal conv1d + SiLU on
+    x, x_proj -> (dt, B, C), dt_proj, selective scan gated by z, out_proj.  xz: (batch, 2 * d_inner, L).  Upstream fuses these
+    into one autograd node to save memory; here they are this package's own differentiable ops in sequence (omk_causal_conv1d,
+    library GEMMs, omk_selective_scan) -- same arithmetic, same argument list."""
+    import torch.nn.functional as F
+    from .causal_conv1d import causal_conv1d_fn
+    L = xz.shape[-1]
+    d_inner, dt_rank = delta_proj_weight.shape
+    d_state = A.shape[-1]
+    x, z = xz.chunk(2, dim=1)
+    w = conv1d_weight.squeeze(1) if conv1d_weight.dim() == 3 else conv1d_weight
+    x = causal_conv1d_fn(x, w, conv1d_bias, activation="silu")
+    x_dbl = F.linear(x.transpose(1, 2).reshape(-1, d_inner), x_proj_weight.to(x.dtype))                 # (batch * L, dt_rank + 2 d_state)
+    delta = (delta_proj_weight.to(x.dtype) @ x_dbl[:, :dt_rank].t()).reshape(d_inner, -1, L).transpose(0, 1)   # (batch, d_inner, L)
+    if B is None:
+        B = x_dbl[:, dt_rank:dt_rank + d_state]
+        if B_proj_bias is not None:
+            B = B + B_proj_bias.to(B.dtype)
+        B = B.reshape(-1, L, d_state).transpose(1, 2).contiguous()                                           # (batch, d_state, L)
+    if C is None:
+        C = x_dbl[:, -d_state:]
+        if C_proj_bias is not None:
+            C = C + C_proj_bias.to(C.dtype)
+        C = C.reshape(-1, L, d_state).transpose(1, 2).contiguous()
+    y = selective_scan_fn(x, delta.contiguous(), A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+    return F.linear(y.transpose(1, 2), out_proj_weight.to(y.dtype), None if out_proj_bias is None else out_proj_bias.to(y.dtype))
