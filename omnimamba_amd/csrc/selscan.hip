@@ -210,28 +210,18 @@ __device__ __forceinline__ void ssc_store_row(T* row, int t0, int L, const float
   }
 }
 
-// SHARE: the eight waves of a workgroup are eight adjacent channels of one (batch, group) and share the B / C rows of the pass
-// through LDS (one coalesced fill per pass instead of every wave pulling every row through its CU's L1: at B 64 the per-wave
-// form moved 6.4 GB through the vector caches for 0.8 GB of HBM data).  LDS image of a row: 16-byte piece v of lane j's
-// tokens at slot v * 64 + j, so that a ds_read_b128 of the wave is 1 KB contiguous.
-template <class T, int SSC_LC, bool SHARE>
-__global__ __launch_bounds__(SHARE ? 512 : 256) void selscan_fwd_chunked_kernel(SsArgs a) {
-  constexpr int NW = SHARE ? 8 : 4;
-  constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
-  __shared__ float scarry[NW][64];   // per wave: state at the start of the pass, per n
-  OMK_DYN_SMEM(bc_raw);              // SHARE: [2][N][64 * SSC_LC] of T
+// general form (any B / C kind and dtype, any channel count): every wave pulls its own rows through L1
+template <class T, int SSC_LC>
+__global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
+  constexpr bool SHARE = false;
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float scarry[4][64];   // per wave: state at the start of the pass, per n
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int64_t seq;
-  if (SHARE) {   // workgroup = (batch, 8-channel tile inside one group)
-    const int tpb = a.Dm / 8;
-    seq = (int64_t)(blockIdx.x / tpb) * a.Dm + (int64_t)(blockIdx.x % tpb) * 8 + wv;
-  } else {
-    seq = (int64_t)blockIdx.x * 4 + wv;   // the four waves of a workgroup: adjacent channels of one batch element
-    if (seq >= (int64_t)a.B * a.Dm) return;
-  }
+  const int64_t seq = (int64_t)blockIdx.x * 4 + wv;   // the four waves of a workgroup: adjacent channels of one batch element
+  if (seq >= (int64_t)a.B * a.Dm) return;
   const int b = (int)(seq / a.Dm), d = (int)(seq % a.Dm);
   const int g = d / (a.Dm / a.G);
-  T* sBC = (T*)bc_raw;
+  T* sBC = nullptr;
   const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
   const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
   const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
@@ -242,27 +232,6 @@ __global__ __launch_bounds__(SHARE ? 512 : 256) void selscan_fwd_chunked_kernel(
   carry[lane] = 0.f;
   for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
     const int t0 = tile0 + lane * SSC_LC;
-    if (SHARE) {
-      block_sync();   // every wave is done with the rows of the previous pass
-      const int rows = (a.Bvar ? a.N : 0) + (a.Cvar ? a.N : 0);
-      for (int i = threadIdx.x; i < rows * PPR; i += 512) {
-        const int r = i / PPR, q = i % PPR;
-        const bool isB = a.Bvar && r < a.N;
-        const int n = isB ? r : r - (a.Bvar ? a.N : 0);
-        const T* row = isB ? (const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg + (int64_t)n * a.Bsn
-                           : (const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg + (int64_t)n * a.Csn;
-        const int e0 = q * VEC, tq = tile0 + e0;
-        T* dst = sBC + ((size_t)(isB || !a.Bvar ? 0 : a.N) + n) * (64 * SSC_LC) + ((e0 % SSC_LC) / VEC * 64 + e0 / SSC_LC) * VEC;
-        const T* src = row + tq;
-        if (tq + VEC <= a.L && (((uintptr_t)src) & 15) == 0) {
-          *reinterpret_cast<vec_t<T, VEC>*>(dst) = *reinterpret_cast<const vec_t<T, VEC>*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; e++) dst[e] = tq + e < a.L ? src[e] : T{};
-        }
-      }
-      block_sync();
-    }
     float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, u);
     ssc_load_row<T, SSC_LC>(drow, t0, a.L, dl);
@@ -352,6 +321,114 @@ __global__ __launch_bounds__(SHARE ? 512 : 256) void selscan_fwd_chunked_kernel(
       if (lane == 0) carry[n] = cout;
     }
     // ---- epilogue: + D u, gate, store   (u[] holds delta u: the raw u is re-read -- it is still in L1)
+    float ur[SSC_LC];
+    ssc_load_row<T, SSC_LC>(urow, t0, a.L, ur);
+    if (zrow) {
+      float zv[SSC_LC];
+      ssc_load_row<T, SSC_LC>(zrow, t0, a.L, zv);
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]) * (zv[i] * rcp_fast(1.f + exp2_fast(-zv[i] * LOG2E)));
+    } else {
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) y[i] = fmaf(Dv, ur[i], y[i]);
+    }
+    ssc_store_row<T, SSC_LC>(orow, t0, a.L, y);
+  }
+  if (a.last && lane < a.N) a.last[((int64_t)b * a.Dm + d) * a.N + lane] = carry[lane];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the same scan for the common case -- B and C both (B, G, N, L) rows of u's dtype, A fp32, 8 | channels per group: the eight
+// waves of a workgroup are eight adjacent channels of one (batch, group) and SHARE the B / C rows of a pass through LDS
+// (one coalesced fill per pass; the per-wave form pulls every row through the CU's L1 once per channel), A2 = A log2 e of
+// the wave's channel sits in LDS too, and the n loop carries no dtype or layout branches.
+// LDS image of a row: the 16-byte piece v of lane j's tokens at slot v * 64 + j, so a ds_read_b128 of a wave is 1 KB contiguous.
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int SSC_LC>
+__global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
+  constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
+  __shared__ float scarry[8][64], sA2[8][64];
+  OMK_DYN_SMEM(bc_raw);              // [2][N][64 * SSC_LC] of T
+  T* sBC = (T*)bc_raw;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tpb = a.Dm / 8;          // workgroup = (batch, 8-channel tile inside one group)
+  const int b = blockIdx.x / tpb, d = (blockIdx.x % tpb) * 8 + wv;
+  const int g = d / (a.Dm / a.G);
+  const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
+  const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
+  const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
+  T* orow = (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd;
+  const T* Bbase = (const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg;
+  const T* Cbase = (const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg;
+  const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+  const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+  float* carry = scarry[wv];
+  carry[lane] = 0.f;
+  sA2[wv][lane] = lane < a.N ? ((const float*)a.A)[(int64_t)d * a.Asd + (int64_t)lane * a.Asn] * LOG2E : 0.f;
+  for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
+    const int t0 = tile0 + lane * SSC_LC;
+    block_sync();   // every wave is done with the rows of the previous pass
+    for (int i = threadIdx.x; i < 2 * a.N * PPR; i += 512) {
+      const int r = i / PPR, q = i % PPR;
+      const T* row = r < a.N ? Bbase + (int64_t)r * a.Bsn : Cbase + (int64_t)(r - a.N) * a.Csn;
+      const int e0 = q * VEC, tq = tile0 + e0;
+      T* dst = sBC + (size_t)r * (64 * SSC_LC) + ((e0 % SSC_LC) / VEC * 64 + e0 / SSC_LC) * VEC;
+      const T* src = row + tq;
+      if (tq + VEC <= a.L && (((uintptr_t)src) & 15) == 0) {
+        *reinterpret_cast<vec_t<T, VEC>*>(dst) = *reinterpret_cast<const vec_t<T, VEC>*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) dst[e] = tq + e < a.L ? src[e] : T{};
+      }
+    }
+    float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
+    ssc_load_row<T, SSC_LC>(urow, t0, a.L, u);
+    ssc_load_row<T, SSC_LC>(drow, t0, a.L, dl);
+    float sdl = 0.f;   // the chunk's decay is exp2(A2 * sum of delta)
+#pragma unroll
+    for (int i = 0; i < SSC_LC; i++) {
+      float v = dl[i] + db;
+      if (a.softplus) v = v > 20.f ? v : 0.6931471805599453f * log2_fast(1.f + exp2_fast(v * LOG2E));
+      dl[i] = (t0 + i < a.L) ? v : 0.f;     // tokens past the end: a = 1, b = 0 (the identity pair)
+      u[i] *= dl[i];                          // delta_t u_t
+      y[i] = 0.f;
+      sdl += dl[i];
+    }
+    block_sync();   // rows staged
+    const T* pB = sBC + lane * VEC;
+    const T* pC = pB + (size_t)a.N * (64 * SSC_LC);
+    for (int n = 0; n < a.N; n++) {
+      const float A2 = sA2[wv][n];
+      float Bv[SSC_LC], Cv[SSC_LC];
+#pragma unroll
+      for (int v = 0; v < SSC_LC / VEC; v++) {
+        float wb[VEC], wc[VEC];
+        load_vec<T, VEC>(pB + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wb);
+        load_vec<T, VEC>(pC + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wc);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { Bv[v * VEC + e] = wb[e]; Cv[v * VEC + e] = wc[e]; }
+      }
+      float av[SSC_LC];
+      float P = exp2_fast(sdl * A2), X = 0.f;
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) {
+        av[i] = exp2_fast(dl[i] * A2);
+        Bv[i] *= u[i];                        // b_t = delta_t u_t B_t[n]
+        X = fmaf(av[i], X, Bv[i]);
+      }
+      wave_scan_affine(P, X);
+      const float cin = carry[n];
+      const float xend = fmaf(P, cin, X);     // state at the end of this lane's chunk
+      float x = shfl_up(xend, 1);
+      if (lane == 0) x = cin;
+      const float cout = wave_read_lane(xend, 63);
+#pragma unroll
+      for (int i = 0; i < SSC_LC; i++) {
+        x = fmaf(av[i], x, Bv[i]);
+        y[i] = fmaf(Cv[i], x, y[i]);
+      }
+      if (lane == 0) carry[n] = cout;
+    }
     float ur[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, ur);
     if (zrow) {
@@ -572,21 +649,21 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
     // shared B / C rows: 8 adjacent channels of one group per workgroup, rows of u's dtype, <= 64 KB of LDS
     const size_t es = dtype_size(udt);
     const size_t bc_bytes = (size_t)((a.Bvar ? a.N : 0) + (a.Cvar ? a.N : 0)) * 64 * lc * es;
-    const bool share = (a.Bvar || a.Cvar) && (a.Dm / a.G) % 8 == 0 && (!a.Bvar || a.bdt == udt) && (!a.Cvar || a.cdt == udt) &&
+    const bool share = a.Bvar && a.Cvar && (a.Dm / a.G) % 8 == 0 && a.bdt == udt && a.cdt == udt && a.adt == OMK_F32 && a.N <= 64 &&
                        bc_bytes <= 64 * 1024 && !getenv("OMK_SELSCAN_NOSHARE");
-#define SSC_GO(T, LC_, SH_, GRID_, BLK_, SM_) do { \
-      if ((SM_) > 0 && OMK_SET_MAX_DYN_SMEM((selscan_fwd_chunked_kernel<T, LC_, SH_>), SM_)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", (size_t)(SM_)); \
-      OMK_LAUNCH((selscan_fwd_chunked_kernel<T, LC_, SH_>), GRID_, BLK_, SM_, stream, a); } while (0)
     if (share) {
       dim3 grid((unsigned)(nseq / 8)), block(512);
-      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 16, true, grid, block, bc_bytes));
-      else OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 8, true, grid, block, bc_bytes));
+#define SSC_SH(T, LC_) do { \
+        if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, LC_>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", bc_bytes); \
+        OMK_LAUNCH((selscan_fwd_shared_kernel<T, LC_>), grid, block, bc_bytes, stream, a); } while (0)
+      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 16));
+      else OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8));
+#undef SSC_SH
     } else {
       dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
-      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 16, false, grid, block, 0));
-      else OMK_DISPATCH_DTYPE(udt, T, SSC_GO(T, 8, false, grid, block, 0));
+      if (lc16) OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 16>), grid, block, 0, stream, a));
+      else OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 8>), grid, block, 0, stream, a));
     }
-#undef SSC_GO
     return OMK_OK;
   }
   const int dpg = a.Dm / a.G;
