@@ -98,6 +98,8 @@ def selscan_cfg1(dev):
             err = ((got.cpu() - ref).norm() / ref.norm()).item()
             assert err < 1e-3, f"selective_scan_fn vs selective_scan_ref: rel-L2 {err:.2e}"
             out["rel_l2_vs_cpu_ref"] = err
+        for _ in range(5):
+            selective_scan_fn(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 50
@@ -314,10 +316,11 @@ def main():
         }
     del model, block, u, dy
     torch.cuda.empty_cache()
+    extra_s = None if (args.no_selscan_cfg1 or world > 1 or rank != 0) else selscan_cfg1(dev)
     extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
     if rank == 0:
         out["train_1p3b"] = extra_t
-        out["selscan_cfg1"] = None if (args.no_selscan_cfg1 or world > 1) else selscan_cfg1(dev)
+        out["selscan_cfg1"] = extra_s
         out["cpu_baseline"] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
