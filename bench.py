@@ -18,6 +18,8 @@ actually timed, `steps_requested` is K.
   cpu_baseline              the CPU oracle (a port: mamba_ssm is absent) on a bounded sample of the same workload
   train_1p3b                BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU step (projector + MMU LoRA train), L=2048,
                             bf16 autocast, DDP over RCCL when N > 1 -- tokens/s of the whole job
+  train_1p3b_stage2         BASELINE configs[4]: stage-2 unified fine-tune step, one T2I + one MMU forward of L=8192 each,
+                            every parameter trains (5.9 GB of fp32 gradients all-reduced per step when N > 1)
   selscan_cfg1              BASELINE configs[0]: Mamba-1 selective_scan at B2 L1024 D768 N16 fp32 -- HIP kernel next
                             to the CPU selective_scan_ref restatement on the host cores
 """
@@ -114,20 +116,23 @@ def selscan_cfg1(dev):
     return out
 
 
-def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048):
+def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048, stage2=False):
     """BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU pretrain step on synthetic image features + text ids, L = 2048:
     images_feat (B, 729, 2176) -> projector, text ids of length L - 733, labels = ids; stage 'align' with only the MMU
-    task configured (projector + MMU LoRA adapters train); bf16 autocast, AdamW, clip 1.0."""
+    task configured (projector + MMU LoRA adapters train); bf16 autocast, AdamW, clip 1.0.
+    stage2=True: BASELINE configs[4] -- stage 'finetune', one T2I + one MMU forward of L tokens each per step, one backward,
+    every parameter of the stack trains (position tables sized >= L: the documented deviation from the reference's caps)."""
     from omnimamba_amd.omni import OmniMambaPath
     from omnimamba_amd.stack import StackConfig
     from omnimamba_amd.train import Stage2Step, TrainConfig, synthetic_batch, wrap_ddp
     torch.manual_seed(0)
-    cfg = StackConfig.omnimamba_1_3b(t2i_task=False, mmu_task=True, mmu_positions=max(seqlen, 1500))
-    model = OmniMambaPath(cfg, stage="align", device=dev, dtype=torch.float32)
+    tasks = ("t2i", "mmu") if stage2 else ("mmu",)
+    cfg = StackConfig.omnimamba_1_3b(t2i_task=stage2, mmu_task=True, mmu_positions=max(seqlen, 1500), t2i_positions=max(seqlen, 329))
+    model = OmniMambaPath(cfg, stage="finetune" if stage2 else "align", device=dev, dtype=torch.float32)
     tc = TrainConfig()
     net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
     step = Stage2Step(model, tc, ddp_model=net)
-    data = synthetic_batch(cfg, batch, seqlen, dev, torch.bfloat16, rank=rank, tasks=("mmu",))
+    data = synthetic_batch(cfg, batch, seqlen, dev, torch.bfloat16, rank=rank, tasks=tasks)
     for _ in range(warmup):
         step(data)
     torch.cuda.synchronize()
@@ -146,11 +151,12 @@ def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
-    loss = float(step.last["mmu"])
+    loss = sum(float(step.last[t]) for t in tasks)
     assert math.isfinite(loss)
-    out = {"tokens_per_s": round(world * batch * seqlen * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+    out = {"tokens_per_s": round(world * len(tasks) * batch * seqlen * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
            "warmup": warmup, "loss": round(loss, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
-           "config": {"workload": "OmniMamba-1.3B stage-1 MMU pretrain step (BASELINE.json configs[3])", "n_layer": cfg.n_layer,
+           "config": {"workload": "OmniMamba-1.3B stage-2 unified fine-tune step, T2I + MMU (BASELINE.json configs[4])" if stage2 else
+                                  "OmniMamba-1.3B stage-1 MMU pretrain step (BASELINE.json configs[3])", "n_layer": cfg.n_layer,
                       "d_model": cfg.d_model, "seq_len": seqlen, "batch_per_gpu": batch, "global_batch": batch * world,
                       "trainable_params": sum(p.numel() for p in model.parameters() if p.requires_grad),
                       "params": sum(p.numel() for p in model.parameters()), "dtype": "bf16 autocast, fp32 masters",
@@ -316,8 +322,11 @@ def main():
     torch.cuda.empty_cache()
     extra_s = None if (args.no_selscan_cfg1 or world > 1 or rank != 0) else selscan_cfg1(dev)
     extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
+    torch.cuda.reset_peak_memory_stats()
+    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=2, warmup=1, batch=2, seqlen=8192, stage2=True)
     if rank == 0:
         out["train_1p3b"] = extra_t
+        out["train_1p3b_stage2"] = extra_t2
         out["selscan_cfg1"] = extra_s
         out["cpu_baseline"] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)

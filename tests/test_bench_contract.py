@@ -19,7 +19,7 @@ def test_bench_json_contract():
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "roofline_bwd", "cpu_baseline", "train_1p3b", "selscan_cfg1", "steps_requested"):
+              "dtype", "data", "config", "roofline", "roofline_bwd", "cpu_baseline", "train_1p3b", "train_1p3b_stage2", "selscan_cfg1", "steps_requested"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
     assert j["unit"] == "M-elements/s" and j["value"] > 0 and abs(j["value"] - 8 * 4096 * 4096 / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 1e-2
