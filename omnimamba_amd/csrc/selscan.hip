@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
 // the wave's channel sits in LDS too, and the n loop carries no dtype or layout branches.
 // LDS image of a row: the 16-byte piece v of lane j's tokens at slot v * 64 + j, so a ds_read_b128 of a wave is 1 KB contiguous.
 // ---------------------------------------------------------------------------------------------------------
-template <class T, int SSC_LC>
+template <class T, int SSC_LC, int NU>   // NU: state indices per trip of the n loop (2: two independent scans interleave)
 __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
   constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
   __shared__ float scarry[8][64], sA2[8][64];
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
     block_sync();   // rows staged
     const T* pB = sBC + lane * VEC;
     const T* pC = pB + (size_t)a.N * (64 * SSC_LC);
+#pragma unroll NU
     for (int n = 0; n < a.N; n++) {
       const float A2 = sA2[wv][n];
       float Bv[SSC_LC], Cv[SSC_LC];
@@ -653,11 +654,14 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
                        bc_bytes <= 64 * 1024 && !getenv("OMK_SELSCAN_NOSHARE");
     if (share) {
       dim3 grid((unsigned)(nseq / 8)), block(512);
-#define SSC_SH(T, LC_) do { \
-        if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, LC_>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", bc_bytes); \
-        OMK_LAUNCH((selscan_fwd_shared_kernel<T, LC_>), grid, block, bc_bytes, stream, a); } while (0)
-      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 16));
-      else OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8));
+#define SSC_SH(T, LC_, NU_) do { \
+        if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, LC_, NU_>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", bc_bytes); \
+        OMK_LAUNCH((selscan_fwd_shared_kernel<T, LC_, NU_>), grid, block, bc_bytes, stream, a); } while (0)
+      const char* nue = getenv("OMK_SELSCAN_NU");
+      const bool nu2 = nue ? atoi(nue) == 2 : false;
+      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 16, 1));
+      else if (nu2) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8, 2));
+      else OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8, 1));
 #undef SSC_SH
     } else {
       dim3 grid((unsigned)((nseq + 3) / 4)), block(256);

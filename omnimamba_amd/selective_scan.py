@@ -26,6 +26,13 @@ class SelectiveScanFn(torch.autograd.Function):
             z = z.to(u.dtype)
         B4 = B.unsqueeze(1) if B.dim() == 3 else B
         C4 = C.unsqueeze(1) if C.dim() == 3 else C
+        if u.shape[-1] >= 64:
+            # the chunked associative scan wants L-contiguous rows (lanes = time).  The Mamba-1 module hands over channel-last
+            # views of its (B, L, 2 D) projection: one copy pass here costs far less than the per-channel sequential kernel
+            u, delta = (t if t.stride(-1) == 1 else t.contiguous() for t in (u, delta))
+            z = z if z is None or z.stride(-1) == 1 else z.contiguous()
+            B4 = B4 if B4.dim() != 4 or B4.stride(-1) == 1 else B4.contiguous()
+            C4 = C4 if C4.dim() != 4 or C4.stride(-1) == 1 else C4.contiguous()
         out = torch.empty_like(u)
         Bsz, Dm, L = u.shape
         last = torch.empty(Bsz, Dm, A.shape[1], dtype=torch.float32, device=u.device) if return_last_state else None
