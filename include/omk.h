@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 1
+#define OMK_ABI_VERSION 2
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -177,6 +177,9 @@ typedef struct {
   OmkTensor delta_bias; /* optional (D) */
   OmkTensor out;        /* (B, D, L) */
   OmkTensor last_state; /* optional out (B, D, N) f32 */
+  OmkTensor pass_states;/* optional out (B, D, ceil(L / 512), N) f32, contiguous: the state in front of every 512-token pass of the
+                           chunked scan -- hand it to omk_selective_scan_bwd and the backward skips its state-only forward pass.
+                           Needs L-contiguous u / delta / z / out / B / C and L >= 64 (OMK_EUNSUPPORTED otherwise). */
   int32_t delta_softplus;
 } OmkSelScanFwd;
 int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream);
@@ -190,12 +193,14 @@ typedef struct {
   OmkTensor dD;                                    /* optional out (D) f32 accumulated */
   OmkTensor dz;                                    /* optional out (B, D, L) */
   OmkTensor ddelta_bias;                           /* optional out (D) f32 accumulated */
+  OmkTensor pass_states;                           /* optional in: what omk_selective_scan_fwd left (chunked form only) */
   void* workspace;                                 /* state checkpoints of the recomputed forward */
   size_t workspace_bytes;
   int32_t delta_softplus;
 } OmkSelScanBwd;
 size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p);
-int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* d_state <= 16 */
+int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* L-contiguous rows, variable B / C, L >= 64, 8 | channels
+                                                                             per group: d_state <= 64; other layouts: d_state <= 16 */
 
 /* ---- decode-step projection fused with the normalisation in front of it ----------------------------------
  * one launch for: reference block.py:86-95 (fused add + RMSNorm) -> lora.py:185-279 (base + task LoRA) at one token

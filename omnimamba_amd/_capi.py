@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 1
+OMK_ABI_VERSION = 2
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -62,9 +62,9 @@ Conv1dUpdate = _S("OmkConv1dUpdate", [(n, _t) for n in ("x", "conv_state", "weig
 StateUpdate = _S("OmkStateUpdate", [(n, _t) for n in ("state", "x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "out")]
                  + [("dt_softplus", _i)])
 SelScanFwd = _S("OmkSelScanFwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "out",
-                                                    "last_state")] + [("delta_softplus", _i)])
+                                                    "last_state", "pass_states")] + [("delta_softplus", _i)])
 SelScanBwd = _S("OmkSelScanBwd", [(n, _t) for n in ("u", "delta", "A", "Bm", "Cm", "D", "z", "delta_bias", "dout", "du",
-                                                    "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")] + _ws
+                                                    "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias", "pass_states")] + _ws
                 + [("delta_softplus", _i)])
 NormLinear = _S("OmkNormLinear", [(n, _t) for n in ("x", "residual", "z", "norm_weight", "weight", "bias", "lora_a", "lora_b",
                                                     "residual_out", "out", "conv_state", "conv_weight", "conv_bias")]

@@ -21,6 +21,15 @@ inline int64_t numel(const OmkTensor& t) {
   return n;
 }
 inline bool is_contig_last(const OmkTensor& t) { return t.ndim == 0 || t.shape[t.ndim - 1] == 1 || t.stride[t.ndim - 1] == 1; }
+// densely packed, row-major
+inline bool is_dense(const OmkTensor& t) {
+  int64_t st = 1;
+  for (int i = t.ndim - 1; i >= 0; i--) {
+    if (t.shape[i] > 1 && t.stride[i] != st) return false;
+    st *= t.shape[i];
+  }
+  return true;
+}
 inline size_t dtype_size(int dt) { return dt == OMK_F32 ? 4 : 2; }
 inline bool aligned16(const OmkTensor& t) { return ((uintptr_t)t.data & 15) == 0; }
 // every stride except the last is a multiple of `elems` (so 16-byte vector rows stay aligned)

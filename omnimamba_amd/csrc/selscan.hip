@@ -225,13 +225,15 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
   const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
   const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
   const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
-  T* orow = (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd;
+  T* orow = a.out ? (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd : nullptr;
   const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
   const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
   float* carry = scarry[wv];
   carry[lane] = 0.f;
   for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
     const int t0 = tile0 + lane * SSC_LC;
+    // first pass of the chunked backward: the state in front of every pass, (B, D, passes, N) f32
+    if (a.ckpt && lane < a.N) a.ckpt[(((int64_t)b * a.Dm + d) * a.nTB + tile0 / (64 * SSC_LC)) * a.N + lane] = carry[lane];
     float u[SSC_LC], dl[SSC_LC], y[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, u);
     ssc_load_row<T, SSC_LC>(drow, t0, a.L, dl);
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
       }
       if (lane == 0) carry[n] = cout;
     }
+    if (!orow) continue;
     // ---- epilogue: + D u, gate, store   (u[] holds delta u: the raw u is re-read -- it is still in L1)
     float ur[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, ur);
@@ -344,7 +347,9 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
 // the wave's channel sits in LDS too, and the n loop carries no dtype or layout branches.
 // LDS image of a row: the 16-byte piece v of lane j's tokens at slot v * 64 + j, so a ds_read_b128 of a wave is 1 KB contiguous.
 // ---------------------------------------------------------------------------------------------------------
-template <class T, int SSC_LC, int NU>   // NU: state indices per trip of the n loop (2: two independent scans interleave)
+// STATE_ONLY (first pass of the chunked backward): no C rows, no y, no output -- the state in front of every pass of 64 * SSC_LC
+// tokens goes to a.ckpt as (B, D, passes, N) f32
+template <class T, int SSC_LC, int NU, bool STATE_ONLY = false>   // NU: state indices per trip of the n loop (2: two independent scans interleave)
 __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
   constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
   __shared__ float scarry[8][64], sA2[8][64];
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
   const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
   const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
   const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
-  T* orow = (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd;
+  T* orow = STATE_ONLY ? nullptr : (T*)a.out + (int64_t)b * a.osb + (int64_t)d * a.osd;
   const T* Bbase = (const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg;
   const T* Cbase = (const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg;
   const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
@@ -368,7 +373,8 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
   for (int tile0 = 0; tile0 < a.L; tile0 += 64 * SSC_LC) {
     const int t0 = tile0 + lane * SSC_LC;
     block_sync();   // every wave is done with the rows of the previous pass
-    for (int i = threadIdx.x; i < 2 * a.N * PPR; i += 512) {
+    if ((STATE_ONLY || a.ckpt) && lane < a.N) a.ckpt[(((int64_t)b * a.Dm + d) * a.nTB + tile0 / (64 * SSC_LC)) * a.N + lane] = carry[lane];
+    for (int i = threadIdx.x; i < (STATE_ONLY ? 1 : 2) * a.N * PPR; i += 512) {
       const int r = i / PPR, q = i % PPR;
       const T* row = r < a.N ? Bbase + (int64_t)r * a.Bsn : Cbase + (int64_t)(r - a.N) * a.Csn;
       const int e0 = q * VEC, tq = tile0 + e0;
@@ -405,9 +411,9 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
       for (int v = 0; v < SSC_LC / VEC; v++) {
         float wb[VEC], wc[VEC];
         load_vec<T, VEC>(pB + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wb);
-        load_vec<T, VEC>(pC + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wc);
+        if (!STATE_ONLY) load_vec<T, VEC>(pC + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wc);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) { Bv[v * VEC + e] = wb[e]; Cv[v * VEC + e] = wc[e]; }
+        for (int e = 0; e < VEC; e++) { Bv[v * VEC + e] = wb[e]; Cv[v * VEC + e] = STATE_ONLY ? 0.f : wc[e]; }
       }
       float av[SSC_LC];
       float P = exp2_fast(sdl * A2), X = 0.f;
@@ -423,13 +429,16 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
       float x = shfl_up(xend, 1);
       if (lane == 0) x = cin;
       const float cout = wave_read_lane(xend, 63);
+      if (!STATE_ONLY) {
 #pragma unroll
-      for (int i = 0; i < SSC_LC; i++) {
-        x = fmaf(av[i], x, Bv[i]);
-        y[i] = fmaf(Cv[i], x, y[i]);
+        for (int i = 0; i < SSC_LC; i++) {
+          x = fmaf(av[i], x, Bv[i]);
+          y[i] = fmaf(Cv[i], x, y[i]);
+        }
       }
       if (lane == 0) carry[n] = cout;
     }
+    if (STATE_ONLY) continue;
     float ur[SSC_LC];
     ssc_load_row<T, SSC_LC>(urow, t0, a.L, ur);
     if (zrow) {
@@ -455,6 +464,53 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
 // x_t is rebuilt per tile of SSB_TL tokens from the checkpoints the forward kernel leaves in the workspace (a.ckpt) and
 // parked in LDS ([t][n][channel]); one wave = 64 channels of one group and batch element, tiles walked last to first.
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// backward for L-contiguous storage: the SAME chunked associative scan, run in both directions inside the n loop.
+//
+// Workgroup = NW (16 or 8) adjacent channels of one (batch, group), one wave per channel, lanes = 64 time chunks of 8 tokens,
+// passes of 512 tokens walked LAST to FIRST.  Per state index n and pass:
+//   forward   fold + wave scan + sweep from the pass-start state (left by the STATE_ONLY forward pass): x_{t-1} stays in 8
+//             registers, dy_t x_t goes to the dC accumulator, C_t x_t to the y needed by dz
+//   reverse   G_t = a_t (C_t dy_t + G_{t+1}) is affine in G_{t+1} with the SAME chunk decay: fold the chunk backwards, suffix
+//             scan of the 64 pairs (DPP row_shl inside rows of 16, the three row totals through v_readlane), sweep backwards:
+//             g_t = C_t dy_t + G_{t+1} meets x_{t-1} -> du, ddelta (registers), dA (lane sum, one wave reduction per n),
+//             g_t delta_t u_t -> the dB accumulator
+// dB / dC are sums over the channels of a group: the waves of a workgroup add into fp32 LDS rows (16-byte read-add-write, the
+// waves walk the state indices in rotated order so that no row has two owners -- see the n loop), a workgroup may walk several
+// channel tiles per pass (q.nOct) before the rows go to HBM as fp32 atomics -- one atomic per (tile group, n, token) instead of
+// one per channel.  State indices are processed in blocks of q.NB rows
+// (LDS: NB * 512 * (8 + 2 sizeof(T)) bytes); with more than one block a workgroup keeps one channel tile.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SSR_LC = 8, SSR_TP = 64 * SSR_LC;
+
+__device__ __forceinline__ void wave_scan_affine_rev(float& p, float& x) {
+  // suffix composition: lane j <- pairs of lanes j .. 63, the pair of the LOWER lane applied last
+#ifdef OMK_EMU
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ps = shfl_down(p, off), xs = shfl_down(x, off);
+    if (lane_id() + off < 64) { x = fmaf(p, xs, x); p = p * ps; }
+  }
+#else
+#define OMK_AFF_STEP(ctrl) { \
+    const float ps = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, p), ctrl, 0xf, 0xf, false)); \
+    const float xs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false)); \
+    x = fmaf(p, xs, x); p = p * ps; }
+  OMK_AFF_STEP(0x101)   // row_shl:1
+  OMK_AFF_STEP(0x102)   // row_shl:2
+  OMK_AFF_STEP(0x104)   // row_shl:4
+  OMK_AFF_STEP(0x108)   // row_shl:8
+#undef OMK_AFF_STEP
+  // lanes 16 / 32 / 48 hold the totals of rows 1 / 2 / 3; row r still needs rows r + 1 .. 3
+  const float p1 = wave_read_lane(p, 16), x1 = wave_read_lane(x, 16), p2 = wave_read_lane(p, 32), x2 = wave_read_lane(x, 32);
+  const float p3 = wave_read_lane(p, 48), x3 = wave_read_lane(x, 48);
+  const float p23 = p2 * p3, x23 = fmaf(p2, x3, x2), p123 = p1 * p23, x123 = fmaf(p1, x23, x1);
+  const int row = lane_id() >> 4;
+  const float ps = row == 0 ? p123 : row == 1 ? p23 : row == 2 ? p3 : 1.f;
+  const float xs = row == 0 ? x123 : row == 1 ? x23 : row == 2 ? x3 : 0.f;
+  x = fmaf(p, xs, x); p = p * ps;
+#endif
+}
+
 constexpr int SSB_TL = 16, SSB_DT = 64, SSB_N = 16;
 
 struct SsBwdArgs {
@@ -463,6 +519,8 @@ struct SsBwdArgs {
   void* du; void* ddelta; void* dz; int64_t dusb, dusd, dusl, ddsb, ddsd, ddsl, dzsb, dzsd, dzsl;
   float* dA; float* dB; float* dC; float* dD; float* ddb;
   int64_t dBsb, dBsg, dBsn, dBsl, dCsb, dCsg, dCsn, dCsl;   // variable: (B, G, N, L); constant: dBsg = stride over d, dBsn over n
+  int NB, nOct;   // chunked form: state indices per LDS block, channel tiles per workgroup
+  int dbg;        // developer ablation bits (OMK_SELSCAN_BWD_DBG): 2 no flush atomics, 4 no n loop
 };
 
 template <class T>
@@ -606,6 +664,239 @@ __global__ __launch_bounds__(SSB_DT) void selscan_bwd_kernel(SsBwdArgs q) {
   }
 }
 
+
+template <class T>
+__global__ __launch_bounds__(1024) void selscan_bwd_chunked_kernel(SsBwdArgs q) {
+  const SsArgs& a = q.f;
+  constexpr int LC = SSR_LC, TP = SSR_TP, VEC = 16 / sizeof(T), PPR = TP / VEC;
+  constexpr float LN2 = 0.6931471805599453f;
+  OMK_DYN_SMEM(smem);
+  const int NB = q.NB, nOct = q.nOct;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int NS = nOct > 1 ? 16 : 64;                            // stride over n of the per-(tile, wave) arrays (nOct > 1 only with N <= 16)
+  float* sAcc = (float*)smem;                                   // [2][NB][TP]: dB rows, dC rows of the pass
+  T* sBC = (T*)(sAcc + (size_t)2 * NB * TP);                    // [2][NB][TP]: B rows, C rows (16-byte piece v of lane j at slot v * 64 + j)
+  float* sA2 = (float*)(sBC + (size_t)2 * NB * TP);             // per (tile, wave, n): A log2 e
+  float* sG = sA2 + nOct * NW * NS;                             //                      adjoint carry between passes
+  float* sdA = sG + nOct * NW * NS;                             //                      dA sum
+  float* sH = sdA + nOct * NW * NS;                             // per (wave, n): state in front of the pass
+  const int tpb = a.Dm / (NW * nOct);
+  const int b = blockIdx.x / tpb, dbase = (blockIdx.x % tpb) * NW * nOct;
+  const int g = dbase / (a.Dm / a.G);
+  const T* Bbase = (const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg;
+  const T* Cbase = (const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg;
+  float* dBbase = q.dB + (int64_t)b * q.dBsb + (int64_t)g * q.dBsg;
+  float* dCbase = q.dC + (int64_t)b * q.dCsb + (int64_t)g * q.dCsg;
+  const int nPass = (a.L + TP - 1) / TP;
+  for (int oc = 0; oc < nOct; oc++) {
+    const int d = dbase + oc * NW + wv, ix = (oc * NW + wv) * NS + lane;
+    if (lane < NS) {
+      sA2[ix] = lane < a.N ? ((const float*)a.A)[(int64_t)d * a.Asd + (int64_t)lane * a.Asn] * LOG2E : 0.f;
+      sG[ix] = 0.f; sdA[ix] = 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < 2 * NB * TP; i += blockDim.x) sAcc[i] = 0.f;
+  float dDacc[4] = {0.f, 0.f, 0.f, 0.f}, ddbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pass = nPass - 1; pass >= 0; pass--) {
+    const int tile0 = pass * TP, t0 = tile0 + lane * LC;
+    float dl[LC], dlu[LC], dy[LC], gB[LC], ddl[LC], ypre[LC];   // gB = sum_n g_t B_t[n]: du = delta gB + D dy, ddelta += u gB
+    for (int nb0 = 0; nb0 < a.N; nb0 += NB) {
+      const int nbn = a.N - nb0 < NB ? a.N - nb0 : NB;
+      // ---- B / C rows of this block of state indices (the accumulators are zero: start of the kernel or the flush below)
+      for (int i = threadIdx.x; i < 2 * nbn * PPR; i += blockDim.x) {
+        const int r = i / PPR, pc = i % PPR, k = r / nbn, nl = r % nbn;
+        const T* row = k == 0 ? Bbase + (int64_t)(nb0 + nl) * a.Bsn : Cbase + (int64_t)(nb0 + nl) * a.Csn;
+        const int e0 = pc * VEC, tq = tile0 + e0;
+        T* dst = sBC + ((size_t)k * NB + nl) * TP + ((e0 % LC) / VEC * 64 + e0 / LC) * VEC;
+        const T* src = row + tq;
+        if (tq + VEC <= a.L && (((uintptr_t)src) & 15) == 0) {
+          *reinterpret_cast<vec_t<T, VEC>*>(dst) = *reinterpret_cast<const vec_t<T, VEC>*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) dst[e] = tq + e < a.L ? src[e] : T{};
+        }
+      }
+      block_sync();   // rows staged, accumulators zeroed
+#pragma unroll 1
+      for (int oc = 0; oc < nOct; oc++) {
+        const int d = dbase + oc * NW + wv, ixb = (oc * NW + wv) * NS;
+        const T* urow = (const T*)a.u + (int64_t)b * a.usb + (int64_t)d * a.usd;
+        const T* drow = (const T*)a.delta + (int64_t)b * a.dsb + (int64_t)d * a.dsd;
+        const T* zrow = a.z ? (const T*)a.z + (int64_t)b * a.zsb + (int64_t)d * a.zsd : nullptr;
+        const T* grow = (const T*)q.dout + (int64_t)b * q.gsb + (int64_t)d * q.gsd;
+        const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+        const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+        if (nb0 == 0) {
+          float u[LC];
+          ssc_load_row<T, LC>(urow, t0, a.L, u);
+          ssc_load_row<T, LC>(drow, t0, a.L, dl);
+          ssc_load_row<T, LC>(grow, t0, a.L, dy);
+          if (zrow) {
+            float zv[LC];
+            ssc_load_row<T, LC>(zrow, t0, a.L, zv);
+#pragma unroll
+            for (int i = 0; i < LC; i++) dy[i] *= zv[i] * rcp_fast(1.f + exp2_fast(-zv[i] * LOG2E));
+          }
+#pragma unroll
+          for (int i = 0; i < LC; i++) {
+            float v = dl[i] + db;
+            if (a.softplus) v = v > 20.f ? v : LN2 * log2_fast(1.f + exp2_fast(v * LOG2E));
+            dl[i] = (t0 + i < a.L) ? v : 0.f;     // tokens past the end: a = 1, b = 0, dy = 0 (identity pairs in both directions)
+            dlu[i] = dl[i] * u[i];
+            gB[i] = 0.f; ddl[i] = 0.f; ypre[i] = 0.f;
+          }
+          // the state in front of this pass, one n per lane
+          if (lane < a.N) sH[wv * 64 + lane] = a.ckpt[(((int64_t)b * a.Dm + d) * a.nTB + pass) * a.N + lane];
+        }
+        float sdl = 0.f;
+#pragma unroll
+        for (int i = 0; i < LC; i++) sdl += dl[i];
+        const T* pB = sBC + lane * VEC;
+        const T* pC = pB + (size_t)NB * TP;
+        float* aB = sAcc + lane * 4;
+        float* aC = aB + (size_t)NB * TP;
+        // dB / dC rows are sums over the channels (= waves) of the workgroup.  LDS float atomics run at a few cycles per LANE on this
+        // chip (measured: 16 ds_add_f32 per wave and state index made the kernel 5x slower), so the waves walk the state indices in
+        // ROTATED order -- at step k wave w owns row (k + w) mod R -- and stay in step through one barrier: no two waves ever touch
+        // the same accumulator row at the same time and a plain 16-byte read-add-write does the job.
+        const int R = nbn > NW ? nbn : NW;
+        for (int k = 0; k < ((q.dbg & 4) ? 0 : R); k++) {
+          int nl = k + wv;
+          nl = nl >= R ? nl - R : nl;
+          if (nl < nbn) {
+            const int n = nb0 + nl;
+            const float A2 = sA2[ixb + n], An = A2 * LN2;
+            float Bv[LC], Cv[LC];
+#pragma unroll
+            for (int v = 0; v < LC / VEC; v++) {
+              float wb[VEC], wc[VEC];
+              load_vec<T, VEC>(pB + (size_t)nl * TP + v * 64 * VEC, wb);
+              load_vec<T, VEC>(pC + (size_t)nl * TP + v * 64 * VEC, wc);
+#pragma unroll
+              for (int e = 0; e < VEC; e++) { Bv[v * VEC + e] = wb[e]; Cv[v * VEC + e] = wc[e]; }
+            }
+            // ---- forward: x_{t-1} of every token of the lane's chunk
+            float av[LC], hp[LC];
+            const float Pc = exp2_fast(sdl * A2);
+            float P = Pc, X = 0.f;
+#pragma unroll
+            for (int i = 0; i < LC; i++) {
+              av[i] = exp2_fast(dl[i] * A2);
+              X = fmaf(av[i], X, dlu[i] * Bv[i]);
+            }
+            wave_scan_affine(P, X);
+            const float cin = sH[wv * 64 + n];
+            const float xend = fmaf(P, cin, X);
+            float x = shfl_up(xend, 1);
+            if (lane == 0) x = cin;
+            {
+              float* rc = aC + (size_t)nl * TP;
+              f32x4 c0 = *(const f32x4*)rc, c1 = *(const f32x4*)(rc + 256);
+#pragma unroll
+              for (int i = 0; i < LC; i++) {
+                hp[i] = x;
+                x = fmaf(av[i], x, dlu[i] * Bv[i]);
+                ypre[i] = fmaf(Cv[i], x, ypre[i]);
+                if (i < 4) c0[i] = fmaf(dy[i], x, c0[i]); else c1[i - 4] = fmaf(dy[i], x, c1[i - 4]);
+              }
+              *(f32x4*)rc = c0; *(f32x4*)(rc + 256) = c1;
+            }
+            // ---- reverse: G_t = a_t (C_t dy_t + G_{t+1})
+            float Pr = Pc, Xr = 0.f;
+#pragma unroll
+            for (int i = LC - 1; i >= 0; i--) Xr = av[i] * fmaf(Cv[i], dy[i], Xr);
+            wave_scan_affine_rev(Pr, Xr);
+            const float gin = sG[ixb + n];
+            const float gout = fmaf(Pr, gin, Xr);          // G at the first token of this lane's chunk
+            float Gn = shfl_down(gout, 1);
+            if (lane == 63) Gn = gin;
+            const float g0 = wave_read_lane(gout, 0);
+            float dAl = 0.f;
+            {
+              float* rb = aB + (size_t)nl * TP;
+              f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 256);
+#pragma unroll
+              for (int i = LC - 1; i >= 0; i--) {
+                const float gt = fmaf(Cv[i], dy[i], Gn);      // adjoint of x_t
+                const float tmp = gt * hp[i] * av[i];
+                dAl = fmaf(tmp, dl[i], dAl);
+                ddl[i] = fmaf(tmp, An, ddl[i]);
+                gB[i] = fmaf(gt, Bv[i], gB[i]);
+                if (i < 4) b0[i] = fmaf(gt, dlu[i], b0[i]); else b1[i - 4] = fmaf(gt, dlu[i], b1[i - 4]);
+                Gn = av[i] * gt;
+              }
+              *(f32x4*)rb = b0; *(f32x4*)(rb + 256) = b1;
+            }
+            const float tot = wave_sum(dAl);
+            if (lane == 0) { sG[ixb + n] = g0; sdA[ixb + n] += tot; }
+          }
+          block_sync();   // next step: every wave moves to the next row
+        }
+        if (nb0 + NB >= a.N) {
+          // ---- per-token outputs of this channel: every state index is in
+          float u[LC], dr[LC];
+          ssc_load_row<T, LC>(urow, t0, a.L, u);     // second read of the pass: L1 / L2
+          ssc_load_row<T, LC>(drow, t0, a.L, dr);
+          if (zrow) {
+            float zv[LC], go[LC];
+            ssc_load_row<T, LC>(grow, t0, a.L, go);
+            ssc_load_row<T, LC>(zrow, t0, a.L, zv);
+#pragma unroll
+            for (int i = 0; i < LC; i++) {
+              const float sig = rcp_fast(1.f + exp2_fast(-zv[i] * LOG2E));
+              go[i] = go[i] * fmaf(Dv, u[i], ypre[i]) * sig * (1.f + zv[i] * (1.f - sig));
+            }
+            ssc_store_row<T, LC>((T*)q.dz + (int64_t)b * q.dzsb + (int64_t)d * q.dzsd, t0, a.L, go);
+          }
+          float dDl = 0.f, ddbl = 0.f;
+#pragma unroll
+          for (int i = 0; i < LC; i++) {
+            dDl = fmaf(dy[i], u[i], dDl);
+            ddl[i] = fmaf(gB[i], u[i], ddl[i]);
+            if (a.softplus) ddl[i] *= rcp_fast(1.f + exp2_fast(-(dr[i] + db) * LOG2E));
+            if (t0 + i >= a.L) ddl[i] = 0.f;
+            ddbl += ddl[i];
+            gB[i] = fmaf(gB[i], dl[i], Dv * dy[i]);   // du
+          }
+          ssc_store_row<T, LC>((T*)q.du + (int64_t)b * q.dusb + (int64_t)d * q.dusd, t0, a.L, gB);
+          ssc_store_row<T, LC>((T*)q.ddelta + (int64_t)b * q.ddsb + (int64_t)d * q.ddsd, t0, a.L, ddl);
+#pragma unroll
+          for (int o = 0; o < 4; o++)
+            if (o == oc) { dDacc[o] += dDl; ddbacc[o] += ddbl; }
+        }
+      }
+      block_sync();   // every wave has added its rows
+      // ---- the block's dB / dC rows -> HBM; the thread that reads a slot zeroes it for the next block
+      for (int i = threadIdx.x; i < 2 * nbn * TP; i += blockDim.x) {
+        const int r = i / TP, t = i % TP, k = r / nbn, nl = r % nbn;
+        float* slot = sAcc + ((size_t)k * NB + nl) * TP + ((t % LC) / 4 * 64 + t / LC) * 4 + t % 4;
+        const float v = *slot;
+        *slot = 0.f;
+        if (tile0 + t < a.L && !(q.dbg & 2)) {
+          if (k == 0) atomic_add_f32(dBbase + (int64_t)(nb0 + nl) * q.dBsn + (int64_t)(tile0 + t) * q.dBsl, v);
+          else atomic_add_f32(dCbase + (int64_t)(nb0 + nl) * q.dCsn + (int64_t)(tile0 + t) * q.dCsl, v);
+        }
+      }
+      // (the next block's staging overwrites sBC: every read of it sits before the barrier above)
+    }
+  }
+  // ---- per-channel sums
+#pragma unroll 1
+  for (int oc = 0; oc < nOct; oc++) {
+    const int d = dbase + oc * NW + wv, ixb = (oc * NW + wv) * NS;
+    if (lane < a.N) atomic_add_f32(q.dA + (int64_t)d * a.N + lane, sdA[ixb + lane]);
+    float dDt = 0.f, ddbt = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+      if (o == oc) { dDt = dDacc[o]; ddbt = ddbacc[o]; }
+    dDt = wave_sum(dDt); ddbt = wave_sum(ddbt);
+    if (lane == 0) {
+      if (q.dD) atomic_add_f32(q.dD + d, dDt);
+      if (q.ddb) atomic_add_f32(q.ddb + d, ddbt);
+    }
+  }
+}
+
 }  // namespace omk
 
 using namespace omk;
@@ -638,18 +929,19 @@ static int ss_fill(SsArgs& a, const OmkTensor& u, const OmkTensor& delta, const 
   return OMK_OK;
 }
 
-static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
+// pass_ckpt: first pass of the chunked backward (a.ckpt = state in front of every 512-token pass, no output)
+static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream, bool pass_ckpt = false) {
   // L-contiguous storage (upstream's layout): the chunked associative scan, one wave per (batch, channel)
-  const bool lcontig = a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.out && a.osl == 1 && (!a.Bvar || a.Bsl == 1) &&
-                       (!a.Cvar || a.Csl == 1) && !a.ckpt && a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
+  const bool lcontig = pass_ckpt || (a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.out && a.osl == 1 && (!a.Bvar || a.Bsl == 1) &&
+                                     (!a.Cvar || a.Csl == 1) && (!a.ckpt || a.TLB == SSR_TP) && a.L >= 64 && !getenv("OMK_SELSCAN_SEQ"));
   if (lcontig) {
     const int64_t nseq = (int64_t)a.B * a.Dm;
     const char* lce = getenv("OMK_SELSCAN_LC");
-    const bool lc16 = lce ? atoi(lce) == 16 : a.L >= 1024 && nseq < 4096;   // few sequences: fewer, longer passes; many: occupancy
+    const bool lc16 = (pass_ckpt || a.ckpt) ? false : lce ? atoi(lce) == 16 : a.L >= 1024 && nseq < 4096;   // pass states: 512-token passes   // few sequences: fewer, longer passes; many: occupancy
     const int lc = lc16 ? 16 : 8;
     // shared B / C rows: 8 adjacent channels of one group per workgroup, rows of u's dtype, <= 64 KB of LDS
     const size_t es = dtype_size(udt);
-    const size_t bc_bytes = (size_t)((a.Bvar ? a.N : 0) + (a.Cvar ? a.N : 0)) * 64 * lc * es;
+    const size_t bc_bytes = (size_t)((a.Bvar ? a.N : 0) + (a.Cvar && !pass_ckpt ? a.N : 0)) * 64 * lc * es;
     const bool share = a.Bvar && a.Cvar && (a.Dm / a.G) % 8 == 0 && a.bdt == udt && a.cdt == udt && a.adt == OMK_F32 && a.N <= 64 &&
                        bc_bytes <= 64 * 1024 && !getenv("OMK_SELSCAN_NOSHARE");
     if (share) {
@@ -659,10 +951,15 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream) {
         OMK_LAUNCH((selscan_fwd_shared_kernel<T, LC_, NU_>), grid, block, bc_bytes, stream, a); } while (0)
       const char* nue = getenv("OMK_SELSCAN_NU");
       const bool nu2 = nue ? atoi(nue) == 2 : false;
-      if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 16, 1));
+#define SSC_ST(T) do { \
+        if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, 8, 1, true>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_bwd: cannot raise dynamic LDS to %zu", bc_bytes); \
+        OMK_LAUNCH((selscan_fwd_shared_kernel<T, 8, 1, true>), grid, block, bc_bytes, stream, a); } while (0)
+      if (pass_ckpt) OMK_DISPATCH_DTYPE(udt, T, SSC_ST(T));
+      else if (lc16) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 16, 1));
       else if (nu2) OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8, 2));
       else OMK_DISPATCH_DTYPE(udt, T, SSC_SH(T, 8, 1));
 #undef SSC_SH
+#undef SSC_ST
     } else {
       dim3 grid((unsigned)((nseq + 3) / 4)), block(256);
       if (lc16) OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_chunked_kernel<T, 16>), grid, block, 0, stream, a));
@@ -691,6 +988,15 @@ extern "C" int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream)
   a.out = p->out.data; a.last = (float*)p->last_state.data;
   a.osb = p->out.stride[0]; a.osd = p->out.stride[1]; a.osl = p->out.stride[2];
   if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
+  if (present(p->pass_states)) {
+    const int nP = (a.L + SSR_TP - 1) / SSR_TP;
+    OMK_REQUIRE(p->pass_states.dtype == OMK_F32 && is_dense(p->pass_states) && numel(p->pass_states) == (int64_t)a.B * a.Dm * nP * a.N,
+                "selective_scan_fwd: pass_states must be contiguous f32 (B, D, ceil(L / 512), N)");
+    if (!(a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.osl == 1 && (!a.Bvar || a.Bsl == 1) && (!a.Cvar || a.Csl == 1) && a.L >= 64) ||
+        getenv("OMK_SELSCAN_SEQ"))
+      return fail(OMK_EUNSUPPORTED, "selective_scan_fwd: pass_states need L-contiguous u / delta / z / out / B / C and L >= 64");
+    a.ckpt = (float*)p->pass_states.data; a.TLB = SSR_TP; a.nTB = nP;
+  }
   if ((rc = ss_launch_fwd(a, p->u.dtype, stream))) return rc;
   return finish_launch("selective_scan_fwd");
 }
@@ -708,7 +1014,6 @@ extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream)
   SsArgs& a = q.f;
   int rc = ss_fill(a, p->u, p->delta, p->A, p->Bm, p->Cm, p->D, p->z, p->delta_bias, p->delta_softplus, "selective_scan_bwd");
   if (rc) return rc;
-  if (a.N > SSB_N) return fail(OMK_EUNSUPPORTED, "selective_scan_bwd: d_state %d > %d is not supported by the Mamba-1 backward", a.N, SSB_N);
   const int udt = p->u.dtype;
   OMK_REQUIRE(p->dout.ndim == 3 && p->du.ndim == 3 && p->ddelta.ndim == 3, "selective_scan_bwd: dout, du, ddelta must be (B, D, L)");
   OMK_REQUIRE(p->dout.dtype == udt && p->du.dtype == udt && p->ddelta.dtype == udt && (!present(p->dz) || p->dz.dtype == udt),
@@ -721,14 +1026,6 @@ extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream)
   OMK_REQUIRE(!present(p->z) || present(p->dz), "selective_scan_bwd: dz required when z is given");
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_selective_scan_bwd_workspace_bytes(p), "selective_scan_bwd: workspace too small");
   if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
-  // pass 1: the forward recurrence once more, leaving the state at every SSB_TL-token boundary in the workspace
-  a.ckpt = (float*)p->workspace; a.TLB = SSB_TL; a.nTB = (a.L + SSB_TL - 1) / SSB_TL;
-  {
-    SsArgs f = a;
-    f.out = nullptr; f.last = nullptr; f.z = nullptr;
-    if ((rc = ss_launch_fwd(f, udt, stream))) return rc;
-  }
-  // pass 2: adjoint sweep, tiles last to first
   q.dout = p->dout.data; q.gsb = p->dout.stride[0]; q.gsd = p->dout.stride[1]; q.gsl = p->dout.stride[2];
   q.du = p->du.data; q.dusb = p->du.stride[0]; q.dusd = p->du.stride[1]; q.dusl = p->du.stride[2];
   q.ddelta = p->ddelta.data; q.ddsb = p->ddelta.stride[0]; q.ddsd = p->ddelta.stride[1]; q.ddsl = p->ddelta.stride[2];
@@ -739,6 +1036,52 @@ extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream)
   if (a.Cvar) { q.dCsb = p->dC.stride[0]; q.dCsg = p->dC.stride[1]; q.dCsn = p->dC.stride[2]; q.dCsl = p->dC.stride[3]; }
   else { q.dCsg = p->dC.stride[0]; q.dCsn = p->dC.stride[1]; }
   const int dpg = a.Dm / a.G;
+  // ---- L-contiguous storage, input-dependent B and C of u's dtype: the chunked associative scan in both directions
+  const bool chunked = a.Bvar && a.Cvar && a.usl == 1 && a.dsl == 1 && (!a.z || (a.zsl == 1 && q.dzsl == 1)) && q.gsl == 1 && q.dusl == 1 &&
+                       q.ddsl == 1 && a.Bsl == 1 && a.Csl == 1 && a.bdt == udt && a.cdt == udt && a.adt == OMK_F32 && dpg % 8 == 0 &&
+                       a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
+  OMK_REQUIRE(!present(p->pass_states) || chunked, "selective_scan_bwd: pass_states belong to the chunked form (L-contiguous rows, variable B / C, L >= 64)");
+  if (chunked) {
+    a.TLB = SSR_TP; a.nTB = (a.L + SSR_TP - 1) / SSR_TP;
+    if (present(p->pass_states)) {
+      OMK_REQUIRE(p->pass_states.dtype == OMK_F32 && is_dense(p->pass_states) && numel(p->pass_states) == (int64_t)a.B * a.Dm * a.nTB * a.N,
+                  "selective_scan_bwd: pass_states must be contiguous f32 (B, D, ceil(L / 512), N)");
+      a.ckpt = (float*)p->pass_states.data;
+    } else {
+      a.ckpt = (float*)p->workspace;
+      SsArgs f = a;
+      f.out = nullptr; f.last = nullptr; f.z = nullptr; f.D = nullptr;
+      if ((rc = ss_launch_fwd(f, udt, stream, true))) return rc;
+    }
+    int NW = dpg % 16 == 0 ? 16 : 8;
+    if (const char* e = getenv("OMK_SELSCAN_BWD_NW")) { if (atoi(e) == 8) NW = 8; }
+    const size_t es = dtype_size(udt);
+    q.NB = a.N < 16 ? a.N : 16;
+    if (const char* e = getenv("OMK_SELSCAN_BWD_NB")) { const int v = atoi(e); if (v >= 1 && v <= 16) q.NB = v < a.N ? v : a.N; }
+    q.nOct = 1;
+    if (a.N <= q.NB)
+      for (int o = 4; o > 1; o >>= 1)
+        if (dpg % (NW * o) == 0 && (int64_t)a.B * a.Dm / (NW * o) >= 512) { q.nOct = o; break; }
+    if (const char* e = getenv("OMK_SELSCAN_BWD_OCT")) { const int o = atoi(e); if ((o == 1 || o == 2 || o == 4) && a.N <= q.NB && dpg % (NW * o) == 0) q.nOct = o; }
+    if (const char* e = getenv("OMK_SELSCAN_BWD_DBG")) q.dbg = atoi(e);
+    const size_t smem = (size_t)q.NB * SSR_TP * (8 + 2 * es) + (size_t)(3 * q.nOct * NW * (q.nOct > 1 ? 16 : 64) + NW * 64) * 4;
+    dim3 grid((unsigned)((int64_t)a.B * a.Dm / (NW * q.nOct))), block(NW * 64);
+#define SSR_GO(T) do { if (OMK_SET_MAX_DYN_SMEM((selscan_bwd_chunked_kernel<T>), smem)) return fail(OMK_ELAUNCH, "selective_scan_bwd: cannot raise dynamic LDS to %zu", smem); \
+      OMK_LAUNCH((selscan_bwd_chunked_kernel<T>), grid, block, smem, stream, q); } while (0)
+    OMK_DISPATCH_DTYPE(udt, T, SSR_GO(T));
+#undef SSR_GO
+    return finish_launch("selective_scan_bwd");
+  }
+  if (a.N > SSB_N) return fail(OMK_EUNSUPPORTED, "selective_scan_bwd: d_state %d > %d needs L-contiguous u / delta / z / dout / B / C (upstream's layout), L >= 64 "
+                                                 "and 8 | channels per group", a.N, SSB_N);
+  // pass 1: the forward recurrence once more, leaving the state at every SSB_TL-token boundary in the workspace
+  a.ckpt = (float*)p->workspace; a.TLB = SSB_TL; a.nTB = (a.L + SSB_TL - 1) / SSB_TL;
+  {
+    SsArgs f = a;
+    f.out = nullptr; f.last = nullptr; f.z = nullptr;
+    if ((rc = ss_launch_fwd(f, udt, stream))) return rc;
+  }
+  // pass 2: adjoint sweep, tiles last to first
   a.DT = SSB_DT;
   const int tiles_per_group = (dpg + SSB_DT - 1) / SSB_DT;
   dim3 grid((unsigned)((int64_t)a.B * a.G * tiles_per_group)), block(SSB_DT);

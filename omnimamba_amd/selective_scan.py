@@ -6,6 +6,8 @@ Mirrors ``mamba_ssm.ops.selective_scan_interface.selective_scan_fn`` (importable
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _capi as K
@@ -37,38 +39,54 @@ class SelectiveScanFn(torch.autograd.Function):
         Bsz, Dm, L = u.shape
         last = torch.empty(Bsz, Dm, A.shape[1], dtype=torch.float32, device=u.device) if return_last_state else None
         Af = A.float() if A.dtype != torch.float32 else A     # bound to a local: the kernel reads it after this line
+        # a backward will follow and the chunked form applies: keep the state in front of every 512-token pass (B D L / 512 N floats) --
+        # the backward then needs no second forward pass
+        ps = None
+        if (L >= 64 and any(ctx.needs_input_grad) and B4.dim() == 4 and C4.dim() == 4 and B4.dtype == u.dtype and C4.dtype == u.dtype and
+                (Dm // B4.shape[1]) % 8 == 0 and all(t is None or t.stride(-1) == 1 for t in (u, delta, z, B4, C4)) and
+                not os.environ.get("OMK_SELSCAN_SEQ") and not os.environ.get("OMK_SELSCAN_NO_PASS_STATES")):
+            # = the conditions of the chunked backward (selscan.hip); without the tensor the backward runs a state-only forward pass first
+            ps = torch.empty(Bsz, Dm, (L + 511) // 512, A.shape[1], dtype=torch.float32, device=u.device)
         if u.numel() > 0:
             p = K.SelScanFwd(u=K.T(u), delta=K.T(delta), A=K.T(Af), Bm=K.T(B4),
                              Cm=K.T(C4), D=K.T(D), z=K.T(z), delta_bias=K.T(delta_bias), out=K.T(out),
-                             last_state=K.T(last), delta_softplus=int(delta_softplus))
+                             last_state=K.T(last), pass_states=K.T(ps), delta_softplus=int(delta_softplus))
             K.run(lib, "omk_selective_scan_fwd", p, u)
         ctx.return_last_state = return_last_state
         ctx.delta_softplus = bool(delta_softplus)
         ctx.b3, ctx.c3 = B.dim() == 3, C.dim() == 3
-        ctx.save_for_backward(u, delta, A, B4, C4, D, z, delta_bias)
+        ctx.save_for_backward(u, delta, A, B4, C4, D, z, delta_bias, ps)
         if return_last_state:
             ctx.mark_non_differentiable(last)
         return (out, last) if return_last_state else out
 
     @staticmethod
     def backward(ctx, dout, *unused):
-        """Recomputes the states per 16-token tile from checkpoints of a second forward pass (omk_selective_scan_bwd);
-        d_state <= 16 (the Mamba-1 default)."""
+        """omk_selective_scan_bwd: L-contiguous inputs with input-dependent B / C run the chunked associative scan in both
+        directions (any d_state <= 64); other layouts the per-channel sequential kernel (d_state <= 16)."""
         lib = get_lib()
-        u, delta, A, B4, C4, D, z, delta_bias = ctx.saved_tensors
+        u, delta, A, B4, C4, D, z, delta_bias, ps = ctx.saved_tensors
         dout = dout.to(u.dtype)
+        if u.stride(-1) == 1 and dout.stride(-1) != 1:
+            dout = dout.contiguous()      # the gradient of a channel-last consumer: the chunked scan wants rows along L
         Af = A.float() if A.dtype != torch.float32 else A
-        f32 = dict(dtype=torch.float32, device=u.device)
         du, ddelta = torch.empty_like(u), torch.empty_like(delta)
         dz = None if z is None else torch.empty_like(z)
-        dA = torch.zeros(A.shape, **f32)
-        dB, dC = torch.zeros(B4.shape, **f32), torch.zeros(C4.shape, **f32)
-        dD = None if D is None else torch.zeros(D.shape, **f32)
-        ddb = None if delta_bias is None else torch.zeros(delta_bias.shape, **f32)
+        # the fp32 accumulators (the kernel adds into them) as slices of ONE zeroed buffer: one fill launch instead of five
+        shapes = [A.shape, B4.shape, C4.shape, None if D is None else D.shape, None if delta_bias is None else delta_bias.shape]
+        sizes = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]
+        sizes = [(n + 3) // 4 * 4 for n in sizes]                 # 16-byte aligned slices
+        acc = torch.zeros(sum(sizes), dtype=torch.float32, device=u.device)
+        parts, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            parts.append(None if sh is None else acc[o:o + int(torch.Size(sh).numel())].view(sh))
+            o += n
+        dA, dB, dC, dD, ddb = parts
         if u.numel() > 0:
             p = K.SelScanBwd(u=K.T(u), delta=K.T(delta), A=K.T(Af), Bm=K.T(B4), Cm=K.T(C4), D=K.T(D), z=K.T(z),
                              delta_bias=K.T(delta_bias), dout=K.T(dout), du=K.T(du), ddelta=K.T(ddelta), dA=K.T(dA), dB=K.T(dB),
-                             dC=K.T(dC), dD=K.T(dD), dz=K.T(dz), ddelta_bias=K.T(ddb), delta_softplus=int(ctx.delta_softplus))
+                             dC=K.T(dC), dD=K.T(dD), dz=K.T(dz), ddelta_bias=K.T(ddb), pass_states=K.T(ps),
+                             delta_softplus=int(ctx.delta_softplus))
             ws = K.workspace(lib, "omk_selective_scan_bwd_workspace_bytes", p, u)  # noqa: F841
             K.run(lib, "omk_selective_scan_bwd", p, u)
         dB = (dB.squeeze(1) if ctx.b3 else dB).to(B4.dtype)

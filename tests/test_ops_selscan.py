@@ -45,7 +45,12 @@ def test_selective_scan_fwd(dev, dtype, layout, Dm, L, N, G, bvar):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout,Dm,L,N,G,bvar,with_z,softplus", [("bdl", 70, 45, 16, 1, True, True, True), ("bld", 12, 33, 8, 2, True, False, True),
-                                                                  ("bdl", 6, 20, 4, 1, False, True, False), ("bld", 130, 37, 16, 1, True, True, True)])
+                                                                  ("bdl", 6, 20, 4, 1, False, True, False), ("bld", 130, 37, 16, 1, True, True, True),
+                                                                  # L >= 64, L-contiguous, 8 | channels per group: the chunked scan in both directions
+                                                                  # (two passes of 512 tokens, ragged tail; 16-wave and 8-wave workgroups; d_state 24 =
+                                                                  # two blocks of state rows; no z / no softplus; channel-last views are copied)
+                                                                  ("bdl", 16, 600, 16, 1, True, True, True), ("bdl", 16, 1100, 8, 2, True, False, True),
+                                                                  ("bdl", 32, 130, 24, 2, True, True, False), ("bld", 8, 200, 16, 1, True, True, True)])
 def test_selective_scan_bwd(dev, dtype, layout, Dm, L, N, G, bvar, with_z, softplus):
     """omk_selective_scan_bwd vs autograd through the fp64 oracle recurrence on identical inputs."""
     from omnimamba_amd.selective_scan import selective_scan_fn
@@ -79,3 +84,28 @@ def test_selective_scan_bwd(dev, dtype, layout, Dm, L, N, G, bvar, with_z, softp
         if a is not None:
             assert a.grad is not None and a.grad.shape == a.shape, name
             assert rel(a.grad, b.grad) < tol, (name, rel(a.grad, b.grad))
+
+
+def test_selective_scan_bwd_channel_tiles(dev, monkeypatch):
+    """Chunked backward with two channel tiles per workgroup (the dB / dC rows of a pass collect both before they go to HBM) ==
+    one tile per workgroup == the fp64 oracle."""
+    from omnimamba_amd.selective_scan import selective_scan_fn
+    torch.manual_seed(3)
+    Bsz, Dm, L, N = 1, 32, 600, 16
+    u, delta, z = torch.randn(Bsz, Dm, L), 0.5 * torch.rand(Bsz, Dm, L), torch.randn(Bsz, Dm, L)
+    A, Bm, Cm = -(torch.rand(Dm, N) + 0.1), torch.randn(Bsz, N, L), torch.randn(Bsz, N, L)
+    D, db = torch.randn(Dm), 0.1 * torch.randn(Dm)
+    src = [u, delta, A, Bm, Cm, D, z, db]
+    g = torch.randn(Bsz, Dm, L)
+    grads = {}
+    for oct_ in ("1", "2"):
+        monkeypatch.setenv("OMK_SELSCAN_BWD_OCT", oct_)
+        if oct_ == "2":
+            monkeypatch.setenv("OMK_SELSCAN_NO_PASS_STATES", "1")   # the backward's own state-only forward pass instead of the saved states
+        leaves = [t.clone().to(dev).requires_grad_() for t in src]
+        selective_scan_fn(*leaves, True).backward(g.to(dev))
+        grads[oct_] = [t.grad.cpu() for t in leaves]
+    dl = [t.double().clone().requires_grad_() for t in src]
+    O.selective_scan_ref(*dl, True, compute_dtype=torch.float64).backward(g.double())
+    for a, b, c in zip(grads["1"], grads["2"], dl):
+        assert rel(a, c.grad) < 2e-4 and rel(b, c.grad) < 2e-4 and rel(a, b) < 1e-5

@@ -1,4 +1,5 @@
-"""Developer tool: Mamba-1 selective_scan forward at BASELINE configs[0] (B 2, L 1024, D 768, N 16 fp32) and scaled batches."""
+"""Developer tool: Mamba-1 selective_scan forward (and, with --bwd, forward + backward) at BASELINE configs[0] (B 2, L 1024, D 768,
+N 16 fp32) and scaled batches."""
 import os
 import sys
 import torch
@@ -19,3 +20,15 @@ for dtype in (torch.float32, torch.bfloat16):
         es = 4 if dtype == torch.float32 else 2
         nb = Bsz * L * (4 * Dm * es + 2 * N * es)
         print(f"{str(dtype):15s} B={Bsz:3d}: {ms * 1e3:8.1f} us  {Bsz * L * Dm / ms / 1e3:9.1f} M-elem/s  {nb / ms / 1e6:7.1f} GB/s = {nb / ms / 1e6 / 80:5.1f} % of 8 TB/s  (LC={os.environ.get('OMK_SELSCAN_LC', 'auto')})", flush=True)
+        if "--bwd" in sys.argv:
+            leaves = [t.detach().clone().requires_grad_() for t in (u, delta, A, Bm, Cm, D, z, db)]
+            g = torch.randn_like(u)
+
+            def fb():
+                for t in leaves:
+                    t.grad = None
+                selective_scan_fn(*leaves, True).backward(g)
+            ms2 = min(timeit(fb, 10, 2) for _ in range(3))
+            # backward alone = (forward + backward) - forward; algorithmic bytes of the backward: u, delta, z, dout read, du, ddelta, dz written
+            nbb = Bsz * L * (7 * Dm * es + 2 * N * es + 2 * N * 4)
+            print(f"{'':15s}        fwd+bwd {ms2 * 1e3:8.1f} us   bwd alone ~{(ms2 - ms) * 1e3:8.1f} us  {nbb / (ms2 - ms) / 1e6:7.1f} GB/s = {nbb / (ms2 - ms) / 1e6 / 80:5.1f} % of 8 TB/s", flush=True)
