@@ -23,9 +23,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import lora_add as LA
+from . import lora_ext as LE
 from . import norm_linear as NL
 from .layer_norm import RMSNorm, layer_norm_fn
-from .linear import linear
+from .linear import _WGradFn, linear
 from .mamba2 import Mamba2
 
 CausalLMOutput = namedtuple("CausalLMOutput", ["t2i_logits", "mmu_logits"])
@@ -136,12 +137,20 @@ class TaskLoRALinear(nn.Linear):
             nn.init.zeros_(getattr(self, f"{task}_lora_B0").weight)
 
     def forward(self, x):
-        result = linear(x, self.weight, self.bias)   # F.linear; token-split weight gradient when the base weight trains
         if self.disable_adapters or self.task_types not in ("t2i", "mmu"):
-            return result
+            return linear(x, self.weight, self.bias)
         A = getattr(self, f"{self.task_types}_lora_A0")
         B = getattr(self, f"{self.task_types}_lora_B0")
         h = linear(self.lora_dropout(x), A.weight) if os.environ.get("OMK_LORA_A_PLAIN") != "1" else A(self.lora_dropout(x))   # token-split dA
+        # ---- many tokens, 16-bit GEMMs: the rank joins the contraction dimension, base + LoRA are ONE GEMM (lora_ext.py)
+        adt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        x2 = x.reshape(-1, x.shape[-1])
+        if self.bias is None and os.environ.get("OMK_LORA_EXT", "1") != "0" and LE.applies(x2, self.weight, self.r, adt):
+            y = LE.lora_ext_linear(self, x2, h.reshape(-1, self.r), self.weight.detach(), B.weight, self.scaling, adt)
+            if torch.is_grad_enabled() and self.weight.requires_grad:
+                y = _WGradFn.apply(y, x2.detach(), self.weight, None)   # the base weight trains ('finetune'): its gradient node
+            return y.view(*x.shape[:-1], y.shape[-1])
+        result = linear(x, self.weight, self.bias)   # F.linear; token-split weight gradient when the base weight trains
         # result + scaling * B(h) as ONE GEMM with a beta = 1 epilogue: the separate scale and add passes over the
         # (tokens, 8512) tensor cost two extra HBM round trips per call (8.7 % of the 1.3B training step)
         out_f = result.shape[-1]

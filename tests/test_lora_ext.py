@@ -1,0 +1,71 @@
+"""Base + task LoRA as one GEMM over the extended contraction dimension (omnimamba_amd/lora_ext.py) == the reference formula
+(models/stage2/lora.py:263-279: result + B(A(dropout(x))) * scaling), forward and every gradient; two task forwards before one
+backward (the reference's compute_loss order) must not disturb each other through the shared [W | B | 0] buffer."""
+import pytest
+import torch
+
+from omnimamba_amd.stack import TaskLoRALinear
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def _module(train_base):
+    torch.manual_seed(0)
+    m = TaskLoRALinear(64, 96, r=8, lora_dropout=0.0, dtype=torch.bfloat16)
+    for t in ("mmu", "t2i"):
+        torch.nn.init.normal_(getattr(m, f"{t}_lora_B0").weight, std=0.05)
+    m.weight.requires_grad_(train_base)
+    return m
+
+
+def _formula(m, x, task):
+    W, A, B = (t.detach().double().requires_grad_() for t in (m.weight, getattr(m, f"{task}_lora_A0").weight, getattr(m, f"{task}_lora_B0").weight))
+    xd = x.detach().double().requires_grad_()
+    return xd @ W.t() + m.scaling * (xd @ A.t()) @ B.t(), (xd, W, A, B)
+
+
+@pytest.mark.parametrize("train_base", [False, True])
+def test_lora_ext_matches_formula_two_tasks(train_base, monkeypatch):
+    m = _module(train_base)
+    x1 = torch.randn(4, 160, 64, dtype=torch.bfloat16, requires_grad=True)
+    x2 = torch.randn(2, 300, 64, dtype=torch.bfloat16, requires_grad=True)
+    g1, g2 = torch.randn(4, 160, 96, dtype=torch.bfloat16), torch.randn(2, 300, 96, dtype=torch.bfloat16)
+    monkeypatch.setenv("OMK_LORA_EXT", "1")
+    m.task_types = "t2i"
+    y1 = m(x1)
+    assert type(y1.grad_fn).__name__ in ("ViewBackward0", "_WGradFnBackward", "UnsafeViewBackward0", "_LoraExtFnBackward")
+    m.task_types = "mmu"
+    y2 = m(x2)                                   # rewrites the B columns of the shared buffer before y1's backward
+    ((y1.float() * g1.float()).sum() + (y2.float() * g2.float()).sum()).backward()
+    r1, l1 = _formula(m, x1, "t2i")
+    r2, l2 = _formula(m, x2, "mmu")
+    ((r1 * g1.double()).sum() + (r2 * g2.double()).sum()).backward()
+    assert rel(y1, r1) < 4e-3 and rel(y2, r2) < 4e-3
+    assert rel(x1.grad, l1[0].grad) < 6e-3 and rel(x2.grad, l2[0].grad) < 6e-3
+    for task, leaves in (("t2i", l1), ("mmu", l2)):
+        assert rel(getattr(m, f"{task}_lora_A0").weight.grad, leaves[2].grad) < 1.5e-2
+        assert rel(getattr(m, f"{task}_lora_B0").weight.grad, leaves[3].grad) < 1.5e-2
+    if train_base:
+        assert rel(m.weight.grad, l1[1].grad + l2[1].grad) < 6e-3
+    else:
+        assert m.weight.grad is None
+    # the buffer follows the master weight
+    with torch.no_grad():
+        m.weight.mul_(0.5)
+    m.task_types = "t2i"
+    y3 = m(x1.detach())
+    assert rel(y3, _formula(m, x1, "t2i")[0]) < 4e-3
+    assert "_omk_we" not in m.state_dict() and all("_omk" not in k for k in m.state_dict())
+
+
+def test_lora_ext_equals_streaming_add_path(monkeypatch):
+    m = _module(False)
+    m.task_types = "mmu"
+    x = torch.randn(1, 600, 64, dtype=torch.bfloat16)
+    monkeypatch.setenv("OMK_LORA_EXT", "1")
+    a = m(x)
+    monkeypatch.setenv("OMK_LORA_EXT", "0")
+    b = m(x)
+    assert rel(a, b) < 5e-3
