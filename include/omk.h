@@ -28,7 +28,7 @@ extern "C" {
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
-typedef enum { OMK_F32 = 0, OMK_BF16 = 1, OMK_F16 = 2 } omk_dtype;
+typedef enum { OMK_F32 = 0, OMK_BF16 = 1, OMK_F16 = 2, OMK_U8 = 3 /* masks only */ } omk_dtype;
 typedef void* omk_stream; /* hipStream_t */
 
 typedef struct {
@@ -241,6 +241,8 @@ typedef struct {
   OmkTensor out;     /* (T, N) in place */
   OmkTensor h;       /* (T, r) = lora_A(dropout(x)), dtype of out */
   OmkTensor lora_b;  /* (N, r) */
+  OmkTensor mask;    /* optional (T, N) u8, rows contiguous: only elements with a non-zero mask byte receive the update (the
+                        dropout in front of lora_A, seen from its backward: dx += mask / (1 - p) * (dh A)) */
   float scale;
 } OmkLoraAdd;
 int omk_lora_add(const OmkLoraAdd* p, omk_stream stream);

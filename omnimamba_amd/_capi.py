@@ -13,7 +13,7 @@ import torch
 
 OMK_ABI_VERSION = 2
 OMK_MAX_DIMS = 5
-_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
 
 class OmkTensor(C.Structure):
@@ -26,7 +26,7 @@ def T(t: Optional[torch.Tensor]) -> OmkTensor:
     if t is None:
         return o
     if t.dtype not in _DT:
-        raise TypeError(f"unsupported dtype {t.dtype} (f32/bf16/f16 only)")
+        raise TypeError(f"unsupported dtype {t.dtype} (f32/bf16/f16, u8/bool masks only)")
     if t.dim() > OMK_MAX_DIMS:
         raise ValueError("too many dims")
     o.data = t.data_ptr()
@@ -70,7 +70,7 @@ NormLinear = _S("OmkNormLinear", [(n, _t) for n in ("x", "residual", "z", "norm_
                                                     "residual_out", "out", "conv_state", "conv_weight", "conv_bias")]
                 + [("group_size", C.c_int64), ("conv_offset", C.c_int64), ("eps", _f), ("lora_scale", _f),
                    ("norm_before_gate", _i), ("conv_silu", _i)])
-LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b")] + [("scale", _f)])
+LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b", "mask")] + [("scale", _f)])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])

@@ -12,10 +12,11 @@ namespace omk {
 
 constexpr int LA_MAXR = 16;
 struct LoraAddArgs {
-  void* out; const void* h; const void* B; int64_t os, hs, bs; int T, N, R, tokens_per_block, bdt; float scale;
+  void* out; const void* h; const void* B; const uint8_t* mask; int64_t os, hs, bs, ms; int T, N, R, tokens_per_block, bdt; float scale;
 };
 
-template <class TO, int RR>   // RR: rank (8 or 16), a template parameter so that B's columns cost RR registers per feature
+// MASK: one byte per element of `out`; elements whose byte is zero keep their value
+template <class TO, int RR, bool MASK = false>   // RR: rank (8 or 16), a template parameter so that B's columns cost RR registers per feature
 __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
   constexpr int VEC = 16 / sizeof(TO) > 8 ? 8 : 16 / sizeof(TO);   // 8 features (16-bit) or 4 (fp32) per thread
   const int nvec = a.N / VEC;
@@ -35,10 +36,12 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
   constexpr int UN = RR == 8 ? 8 : 4;         // tokens in flight per thread
   for (int t = t0; t < t1; t += UN) {
     float o[UN][VEC], hv[UN][RR];
+    uint8_t mk[UN][VEC];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
       const int tc = t + u < t1 ? t + u : t1 - 1;        // clamped: unconditional loads
       load_vec<TO, VEC>(out + (int64_t)tc * a.os, o[u]);
+      if (MASK) memcpy(mk[u], a.mask + (int64_t)tc * a.ms + n0, VEC);
 #pragma unroll
       for (int r = 0; r < RR; r += 8) {                    // rank 8: one 16-byte (16-bit) broadcast load per token
         float tmp[8];
@@ -51,10 +54,10 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
     for (int u = 0; u < UN; u++) {
 #pragma unroll
       for (int i = 0; i < VEC; i++) {
-        float acc = o[u][i];
+        float acc = MASK ? 0.f : o[u][i];
 #pragma unroll
         for (int r = 0; r < RR; r++) acc += hv[u][r] * bw[i][r];
-        o[u][i] = acc;
+        o[u][i] = MASK ? (mk[u][i] ? o[u][i] + acc : o[u][i]) : acc;
       }
       if (t + u < t1) store_vec<TO, VEC>(out + (int64_t)(t + u) * a.os, o[u]);
     }
@@ -80,10 +83,18 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
     return fail(OMK_EUNSUPPORTED, "lora_add: rank must be 8 or 16 and rows 16-byte aligned (use addmm otherwise)");
   a.out = p->out.data; a.h = p->h.data; a.B = p->lora_b.data; a.os = p->out.stride[0]; a.hs = p->h.stride[0]; a.bs = p->lora_b.stride[0];
   a.bdt = p->lora_b.dtype; a.scale = p->scale;
+  if (present(p->mask)) {
+    OMK_REQUIRE(p->mask.dtype == OMK_U8 && p->mask.ndim == 2 && p->mask.shape[0] == a.T && p->mask.shape[1] == a.N && p->mask.stride[1] == 1,
+                "lora_add: mask must be u8 (T, N) with contiguous rows");
+    a.mask = (const uint8_t*)p->mask.data; a.ms = p->mask.stride[0];
+  }
   a.tokens_per_block = 64;
   const int nvec = a.N / vec, cvb = (nvec + 255) / 256, tbs = (a.T + a.tokens_per_block - 1) / a.tokens_per_block;
   dim3 grid((unsigned)((int64_t)cvb * tbs)), block(256);
-  if (a.R == 8) OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 8>), grid, block, 0, stream, a));
+  if (a.mask) {
+    if (a.R == 8) OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 8, true>), grid, block, 0, stream, a));
+    else OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 16, true>), grid, block, 0, stream, a));
+  } else if (a.R == 8) OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 8>), grid, block, 0, stream, a));
   else OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 16>), grid, block, 0, stream, a));
   return finish_launch("lora_add");
 }

@@ -30,7 +30,7 @@ inline bool is_dense(const OmkTensor& t) {
   }
   return true;
 }
-inline size_t dtype_size(int dt) { return dt == OMK_F32 ? 4 : 2; }
+inline size_t dtype_size(int dt) { return dt == OMK_F32 ? 4 : dt == OMK_U8 ? 1 : 2; }
 inline bool aligned16(const OmkTensor& t) { return ((uintptr_t)t.data & 15) == 0; }
 // every stride except the last is a multiple of `elems` (so 16-byte vector rows stay aligned)
 inline bool strides_multiple_of(const OmkTensor& t, int64_t elems) {

@@ -65,6 +65,16 @@ class _LoraAdd(torch.autograd.Function):
         return dy, dh, db, None
 
 
+def lora_add_(out2d, h2d, lora_b, scale, mask=None):
+    """The kernel itself, no autograd: out2d += scale * h2d @ lora_b^T in place; with `mask` (bool / uint8, out2d's shape) only
+    where the mask is set.  `applies(out2d, h2d, lora_b)` must hold."""
+    lib = get_lib()
+    require_device(lib, out2d, h2d, lora_b, mask)
+    p = K.LoraAdd(out=K.T(out2d), h=K.T(h2d), lora_b=K.T(lora_b), mask=K.T(mask), scale=float(scale))
+    K.run(lib, "omk_lora_add", p, out2d)
+    return out2d
+
+
 def lora_add(result2d, h2d, lora_b, scale):
     """result2d (tokens, out) + scale * h2d (tokens, r) @ lora_b (out, r)^T; overwrites result2d's storage."""
     return _LoraAdd.apply(result2d, h2d, lora_b, scale)

@@ -18,6 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import lora_add as LA
 from .linear import weight_grad
 
 PAD = 64          # columns appended to the contraction dimension (rank <= PAD); a multiple of the GEMM's K tile
@@ -46,36 +47,55 @@ def extended_weight(module, weight: torch.Tensor, lora_b: torch.Tensor, adt: tor
 
 
 class _LoraExtFn(torch.autograd.Function):
+    """The whole task-LoRA projection as one node: dropout -> A -> extended GEMM; backward with the A branch folded into dx."""
+
     @staticmethod
-    def forward(ctx, x2d, h2d, we, lora_b, scale, in_f):
-        r = h2d.shape[1]
-        xe = torch.empty(x2d.shape[0], in_f + PAD, dtype=we.dtype, device=x2d.device)
+    def forward(ctx, x2d, we, lora_a, lora_b, scale, in_f, p_drop):
+        adt = we.dtype
+        r = lora_a.shape[0]
+        mask = None
+        xd = x2d
+        if p_drop > 0.0:
+            xd, mask = torch.ops.aten.native_dropout(x2d, p_drop, True)
+        h2d = xd @ lora_a.to(adt).t()
+        xe = torch.empty(x2d.shape[0], in_f + PAD, dtype=adt, device=x2d.device)
         xe[:, :in_f].copy_(x2d)
         torch.mul(h2d, scale, out=xe[:, in_f:in_f + r])
         xe[:, in_f + r:].zero_()
-        ctx.save_for_backward(h2d, lora_b)
+        ctx.save_for_backward(xd, h2d, mask, lora_a, lora_b)
         # the buffer is NOT a saved tensor: its B columns are rewritten by the next call (the other task's forward runs before
         # this call's backward), which is harmless -- backward only reads the W columns -- but would trip the version check
         ctx.we = we
-        ctx.scale, ctx.in_f = float(scale), in_f
+        ctx.scale, ctx.in_f, ctx.p_drop = float(scale), in_f, float(p_drop)
         return F.linear(xe, we)
 
     @staticmethod
     def backward(ctx, dy):
-        h2d, lora_b = ctx.saved_tensors
-        dx = dh = db = None
-        if ctx.needs_input_grad[0]:
-            dx = dy @ ctx.we[:, :ctx.in_f]                  # the plain input gradient: rows of the buffer, stride in + PAD
-        if ctx.needs_input_grad[1]:
-            dh = (dy @ lora_b.to(dy.dtype)) * ctx.scale
+        xd, h2d, mask, lora_a, lora_b = ctx.saved_tensors
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        adt = dyc.dtype
+        dx = da = db = None
+        dh = (dyc @ lora_b.to(adt)) * ctx.scale                      # (tokens, r)
         if ctx.needs_input_grad[3]:
-            dyc = dy if dy.is_contiguous() else dy.contiguous()
-            db = weight_grad(dyc, h2d.to(dy.dtype).contiguous(), torch.float32).mul_(ctx.scale).to(lora_b.dtype)
-        return dx, dh, None, db, None, None
+            db = weight_grad(dyc, h2d.contiguous(), torch.float32).mul_(ctx.scale).to(lora_b.dtype)
+        if ctx.needs_input_grad[2]:
+            da = weight_grad(dh.contiguous(), xd if xd.is_contiguous() else xd.contiguous(), torch.float32).to(lora_a.dtype)
+        if ctx.needs_input_grad[0]:
+            dx = dyc @ ctx.we[:, :ctx.in_f]                           # the plain input gradient: rows of the buffer, stride in + PAD
+            # + dropout'(dh A): one streaming pass over dx (omk_lora_add with the dropout mask) instead of a K = 8 GEMM into a
+            # second (tokens, in) tensor, the mask-and-scale pass and the add (126 -> 41 us per layer and task at 16 k tokens)
+            keep = 1.0 / (1.0 - ctx.p_drop) if mask is not None else 1.0
+            a_t = lora_a.to(adt).t().contiguous()                     # (in, r): the kernel's "B" operand
+            if LA.applies(dx, dh, a_t):
+                LA.lora_add_(dx, dh.contiguous(), a_t, keep, mask)
+            else:
+                upd = dh @ lora_a.to(adt)
+                dx += upd * (mask.to(adt) * keep) if mask is not None else upd
+        return dx, None, da, db, None, None, None
 
 
-def lora_ext_linear(module, x2d, h2d, weight, lora_b, scale, adt):
-    """x2d (tokens, in), h2d (tokens, r) -> (tokens, out) in `adt`; gradients to x2d, h2d and lora_b (the base weight's gradient, if
-    it trains, belongs to the caller: `linear._WGradFn`)."""
+def lora_ext_linear(module, x2d, weight, lora_a, lora_b, scale, adt, p_drop):
+    """x2d (tokens, in) -> (tokens, out) in `adt` = x W^T + scale * dropout_p(x) A^T B^T; gradients to x2d, lora_a, lora_b (the
+    base weight's gradient, if it trains, belongs to the caller: `linear._WGradFn`)."""
     we = extended_weight(module, weight, lora_b, adt)
-    return _LoraExtFn.apply(x2d.to(adt), h2d.to(adt), we, lora_b, scale, weight.shape[1])
+    return _LoraExtFn.apply(x2d.to(adt), we, lora_a, lora_b, scale, weight.shape[1], p_drop)

@@ -141,15 +141,16 @@ class TaskLoRALinear(nn.Linear):
             return linear(x, self.weight, self.bias)
         A = getattr(self, f"{self.task_types}_lora_A0")
         B = getattr(self, f"{self.task_types}_lora_B0")
-        h = linear(self.lora_dropout(x), A.weight) if os.environ.get("OMK_LORA_A_PLAIN") != "1" else A(self.lora_dropout(x))   # token-split dA
-        # ---- many tokens, 16-bit GEMMs: the rank joins the contraction dimension, base + LoRA are ONE GEMM (lora_ext.py)
+        # ---- many tokens, 16-bit GEMMs: the rank joins the contraction dimension, base + LoRA are ONE GEMM and one autograd node
         adt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         x2 = x.reshape(-1, x.shape[-1])
         if self.bias is None and os.environ.get("OMK_LORA_EXT", "1") != "0" and LE.applies(x2, self.weight, self.r, adt):
-            y = LE.lora_ext_linear(self, x2, h.reshape(-1, self.r), self.weight.detach(), B.weight, self.scaling, adt)
+            p_drop = self.lora_dropout.p if (self.training and isinstance(self.lora_dropout, nn.Dropout)) else 0.0
+            y = LE.lora_ext_linear(self, x2, self.weight.detach(), A.weight, B.weight, self.scaling, adt, p_drop)
             if torch.is_grad_enabled() and self.weight.requires_grad:
                 y = _WGradFn.apply(y, x2.detach(), self.weight, None)   # the base weight trains ('finetune'): its gradient node
             return y.view(*x.shape[:-1], y.shape[-1])
+        h = linear(self.lora_dropout(x), A.weight) if os.environ.get("OMK_LORA_A_PLAIN") != "1" else A(self.lora_dropout(x))   # token-split dA
         result = linear(x, self.weight, self.bias)   # F.linear; token-split weight gradient when the base weight trains
         # result + scaling * B(h) as ONE GEMM with a beta = 1 epilogue: the separate scale and add passes over the
         # (tokens, 8512) tensor cost two extra HBM round trips per call (8.7 % of the 1.3B training step)

@@ -69,3 +69,28 @@ def test_lora_ext_equals_streaming_add_path(monkeypatch):
     monkeypatch.setenv("OMK_LORA_EXT", "0")
     b = m(x)
     assert rel(a, b) < 5e-3
+
+
+def test_lora_ext_dropout_backward_uses_the_mask():
+    """With lora_dropout > 0 the A branch sees dropout(x): y and dx / dA / dB against the formula evaluated with the SAME mask
+    (same generator state), the masked in-place update of dx (omk_lora_add with a mask) included."""
+    torch.manual_seed(0)
+    m = TaskLoRALinear(64, 96, r=8, lora_dropout=0.25, dtype=torch.bfloat16)
+    torch.nn.init.normal_(m.mmu_lora_B0.weight, std=0.05)
+    m.task_types = "mmu"
+    m.train()
+    x = torch.randn(3, 200, 64, dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(3, 200, 96, dtype=torch.bfloat16)
+    torch.manual_seed(123)
+    y = m(x)
+    y.backward(g)
+    torch.manual_seed(123)
+    xd, mask = torch.ops.aten.native_dropout(x.detach().reshape(-1, 64), 0.25, True)
+    assert 0.6 < mask.float().mean() < 0.9
+    W, A, B = (t.detach().double().requires_grad_() for t in (m.weight, m.mmu_lora_A0.weight, m.mmu_lora_B0.weight))
+    x64 = x.detach().double().reshape(-1, 64).requires_grad_()
+    ref = x64 @ W.t() + m.scaling * ((x64 * mask.double() / 0.75) @ A.t()) @ B.t()
+    ref.backward(g.double().reshape(-1, 96))
+    assert rel(y.reshape(-1, 96), ref) < 4e-3
+    assert rel(x.grad.reshape(-1, 64), x64.grad) < 6e-3
+    assert rel(m.mmu_lora_A0.weight.grad, A.grad) < 1.5e-2 and rel(m.mmu_lora_B0.weight.grad, B.grad) < 1.5e-2

@@ -32,3 +32,18 @@ def test_lora_add_limits(dev):
     from omnimamba_amd import lora_add as LA
     assert not LA.applies(torch.randn(4, 96), torch.randn(4, 4), torch.randn(96, 4))       # rank 4: addmm
     assert not LA.applies(torch.randn(4, 98).bfloat16(), torch.randn(4, 8).bfloat16(), torch.randn(98, 8))
+
+
+@pytest.mark.parametrize("T,N,R,dtype", [(300, 2048, 8, torch.bfloat16), (70, 264, 16, torch.bfloat16), (33, 96, 8, torch.float32)])
+def test_lora_add_masked(dev, T, N, R, dtype):
+    """The masked form (dropout backward of the LoRA A branch): only elements whose mask byte is set receive the update."""
+    from omnimamba_amd import lora_add as LA
+    torch.manual_seed(1)
+    out, h = torch.randn(T, N).to(dtype), torch.randn(T, R).to(dtype)
+    Bw = (torch.randn(N, R) * 0.1).to(dtype)
+    mask = torch.rand(T, N) < 0.8
+    od = out.clone().to(dev)
+    LA.lora_add_(od, h.to(dev), Bw.to(dev), 1.25, mask.to(dev))
+    ref = out.double() + mask.double() * 1.25 * (h.double() @ Bw.double().t())
+    assert rel(od, ref) < (2e-6 if dtype == torch.float32 else 6e-3)
+    assert torch.equal(od.cpu()[~mask], out[~mask])          # untouched elements are bit-identical
