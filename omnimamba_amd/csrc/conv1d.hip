@@ -440,7 +440,9 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
   const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->dout, a.C) && cl_fast_ok(p->dx, a.C);
   dim3 block(256);
   if (fast) {
-    constexpr int TL = 32;
+    // strips of 64 tokens, 8 tokens in flight: 402 -> 373 us per call on the 1.3B slice against 32 / 4 (`OMK_CONV_BWD_VAR`: halo
+    // re-reads of W - 1 rows per strip and twice the loads in flight); 128-token strips gain nothing more
+    constexpr int TL = 64;
 #define CONV_BWD_V(T_, VEC_, TG_) do { const int CVB = (a.C / VEC_ + 63) / 64, NT4 = (a.L + 4 * TL - 1) / (4 * TL); \
       dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB)); \
       if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, VEC_, TL, 4, TG_>), grid, block, 0, stream, a); \
@@ -448,7 +450,23 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
       else OMK_LAUNCH((conv1d_bwd_cl_kernel<T_, VEC_, TL, 2, TG_>), grid, block, 0, stream, a); } while (0)
     // 2 channels per lane: 86 VGPRs / 5 waves per SIMD; the silu' recompute makes this kernel VALU- and latency-heavy
     // (4 channels: 154 VGPRs, 383 us; 2 channels: ~290 us on the 1.3B shape)
-    if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 4); else CONV_BWD_V(f16_t, 2, 4);
+    const char* var = getenv("OMK_CONV_BWD_VAR");   // developer A/B (bf16, W = 4): "<VEC><TL><TG>" digits, e.g. 2648 = VEC 2, TL 64, TG 8
+    if (var && *var && p->x.dtype == OMK_BF16 && a.W == 4) {
+#define CONV_BWD_X(VEC_, TL_, TG_) do { const int CVB = (a.C / VEC_ + 63) / 64, NT4 = (a.L + 4 * TL_ - 1) / (4 * TL_); \
+        dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB)); \
+        OMK_LAUNCH((conv1d_bwd_cl_kernel<bf16_t, VEC_, TL_, 4, TG_>), grid, block, 0, stream, a); } while (0)
+      const int v = atoi(var);
+      if (v == 2324) CONV_BWD_X(2, 32, 4);
+      else if (v == 2328) CONV_BWD_X(2, 32, 8);
+      else if (v == 2644) CONV_BWD_X(2, 64, 4);
+      else if (v == 2648) CONV_BWD_X(2, 64, 8);
+      else if (v == 21288) CONV_BWD_X(2, 128, 8);
+      else if (v == 4324) CONV_BWD_X(4, 32, 4);
+      else if (v == 4644) CONV_BWD_X(4, 64, 4);
+      else if (v == 1648) CONV_BWD_X(1, 64, 8);
+      else return fail(OMK_EINVAL, "OMK_CONV_BWD_VAR: unknown variant %d", v);
+#undef CONV_BWD_X
+    } else if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 8); else CONV_BWD_V(f16_t, 2, 8);
 #undef CONV_BWD_V
   } else {
     int64_t n = (int64_t)a.B * a.C;
