@@ -73,7 +73,7 @@ typedef struct {
   OmkTensor mean;          /* optional (rows) f32 */
   OmkTensor dx;            /* out (rows, cols) */
   OmkTensor dresidual_in;  /* optional out (rows, cols): same value as dx in the residual's dtype */
-  OmkTensor dweight;       /* out (cols) f32 */
+  OmkTensor dweight;       /* optional out (cols) f32; absent (frozen weight): no partial sums, no reduction launch */
   OmkTensor dbias;         /* optional out (cols) f32 */
   void* workspace;
   size_t workspace_bytes;
@@ -102,7 +102,7 @@ int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream);
 typedef struct {
   OmkTensor dy, x, z, weight; /* z optional */
   OmkTensor dx, dz;           /* out; dz optional */
-  OmkTensor dweight;          /* out (cols) f32 */
+  OmkTensor dweight;          /* optional out (cols) f32; absent (frozen weight): no partial sums, no reduction launch */
   void* workspace;
   size_t workspace_bytes;
   int64_t group_size;

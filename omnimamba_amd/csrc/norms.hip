@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
     if (col < a.cols) {
 #pragma unroll
       for (int i = 0; i < VEC; i++) {
-        a.dw_part[part * a.cols + col + i] = dwacc[c][i];
+        if (a.dw_part) a.dw_part[part * a.cols + col + i] = dwacc[c][i];
         if (a.db_part) a.db_part[part * a.cols + col + i] = dbacc[c][i];
       }
     }
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
     const int col = NORM_COL(c);
     if (col < gs) {
 #pragma unroll
-      for (int i = 0; i < VEC; i++) a.dw_part[part * a.cols + g0 + col + i] = dwacc[c][i];
+      for (int i = 0; i < VEC; i++)
+        if (a.dw_part) a.dw_part[part * a.cols + g0 + col + i] = dwacc[c][i];
     }
   }
 }
@@ -516,13 +517,13 @@ extern "C" size_t omk_add_norm_bwd_workspace_bytes(const OmkAddNormBwd* p) {
 }
 
 extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
-  OMK_REQUIRE(p && present(p->dy) && present(p->xsum) && present(p->weight) && present(p->rstd) && present(p->dx) && present(p->dweight),
-              "add_norm_bwd: dy, xsum, weight, rstd, dx, dweight required");
+  OMK_REQUIRE(p && present(p->dy) && present(p->xsum) && present(p->weight) && present(p->rstd) && present(p->dx),
+              "add_norm_bwd: dy, xsum, weight, rstd, dx required");
   const int64_t rows = p->dy.shape[0], cols = p->dy.shape[1];
   OMK_REQUIRE(p->dx.dtype == p->dy.dtype, "add_norm_bwd: dx dtype must equal dy dtype");
   OMK_REQUIRE(!present(p->dresidual_out) || p->dresidual_out.dtype == p->xsum.dtype, "add_norm_bwd: dresidual_out dtype must equal xsum dtype");
   OMK_REQUIRE(p->xsum.dtype == p->dy.dtype || p->xsum.dtype == OMK_F32, "add_norm_bwd: xsum dtype");
-  OMK_REQUIRE(p->dweight.dtype == OMK_F32, "add_norm_bwd: dweight must be f32");
+  OMK_REQUIRE(!present(p->dweight) || p->dweight.dtype == OMK_F32, "add_norm_bwd: dweight must be f32");
   if (rows == 0) return OMK_OK;
   VecPlan plan;
   if (!add_bwd_plan(p, &plan)) return fail(OMK_EUNSUPPORTED, "add_norm_bwd: cols too large");
@@ -532,7 +533,9 @@ extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
   a.dy = p->dy.data; a.dro = p->dresidual_out.data; a.xsum = p->xsum.data; a.w = p->weight.data;
   a.rstd = (const float*)p->rstd.data; a.mean = p->is_rms_norm ? nullptr : (const float*)p->mean.data;
   a.dx = p->dx.data; a.dri = p->dresidual_in.data;
-  a.dw_part = (float*)p->workspace; a.db_part = p->has_bias ? a.dw_part + (size_t)nparts * cols : nullptr;
+  // a frozen weight (dweight absent): no partial rows, no reduction launch
+  a.dw_part = present(p->dweight) ? (float*)p->workspace : nullptr;
+  a.db_part = (p->has_bias && present(p->dbias)) ? (float*)p->workspace + (size_t)nparts * cols : nullptr;
   a.dys = p->dy.stride[0]; a.dros = present(p->dresidual_out) ? p->dresidual_out.stride[0] : 0; a.xss = p->xsum.stride[0];
   a.dxs = p->dx.stride[0]; a.dris = present(p->dresidual_in) ? p->dresidual_in.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = 1; a.wdt = p->weight.dtype; a.rms = p->is_rms_norm;
@@ -548,8 +551,8 @@ extern "C" int omk_add_norm_bwd(const OmkAddNormBwd* p, omk_stream stream) {
     else { LAUNCH_B(TX, float, float); }
   });
 #undef LAUNCH_B
-  launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
-  if (p->has_bias && present(p->dbias)) launch_reduce(a.db_part, nparts, cols, (float*)p->dbias.data, stream);
+  if (a.dw_part) launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
+  if (a.db_part) launch_reduce(a.db_part, nparts, cols, (float*)p->dbias.data, stream);
   return finish_launch("add_norm_bwd");
 }
 
@@ -591,9 +594,9 @@ extern "C" size_t omk_norm_gated_bwd_workspace_bytes(const OmkNormGatedBwd* p) {
 }
 
 extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
-  OMK_REQUIRE(p && present(p->dy) && present(p->x) && present(p->weight) && present(p->dx) && present(p->dweight), "norm_gated_bwd: dy, x, weight, dx, dweight required");
+  OMK_REQUIRE(p && present(p->dy) && present(p->x) && present(p->weight) && present(p->dx), "norm_gated_bwd: dy, x, weight, dx required");
   const int64_t rows = p->x.shape[0], cols = p->x.shape[1];
-  OMK_REQUIRE(p->dweight.dtype == OMK_F32, "norm_gated_bwd: dweight must be f32");
+  OMK_REQUIRE(!present(p->dweight) || p->dweight.dtype == OMK_F32, "norm_gated_bwd: dweight must be f32");
   OMK_REQUIRE(p->dy.dtype == p->x.dtype && p->dx.dtype == p->x.dtype, "norm_gated_bwd: dtype mismatch");
   if (present(p->z)) OMK_REQUIRE(present(p->dz) && p->z.dtype == p->x.dtype && p->dz.dtype == p->x.dtype, "norm_gated_bwd: z/dz");
   if (rows == 0) return OMK_OK;
@@ -603,12 +606,12 @@ extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
   const int nparts = norm_parts(rows, ng, plan);
   NormBwdArgs a = {};
   a.dy = p->dy.data; a.x = p->x.data; a.z = p->z.data; a.w = p->weight.data; a.dx = p->dx.data; a.dz = p->dz.data;
-  a.dw_part = (float*)p->workspace;
+  a.dw_part = present(p->dweight) ? (float*)p->workspace : nullptr;   // frozen weight: no partial rows, no reduction launch
   a.dys = p->dy.stride[0]; a.xs = p->x.stride[0]; a.zs = present(p->z) ? p->z.stride[0] : 0; a.dxs = p->dx.stride[0];
   a.dzs = present(p->dz) ? p->dz.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = ng; a.wdt = p->weight.dtype; a.rms = 1; a.eps = p->eps; a.norm_before_gate = p->norm_before_gate;
   dim3 grid(norm_blocks(rows, ng, plan)), block(NORM_THREADS);
   OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_bwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
-  launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
+  if (a.dw_part) launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
   return finish_launch("norm_gated_bwd");
 }

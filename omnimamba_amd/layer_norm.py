@@ -69,8 +69,9 @@ class LayerNormFn(torch.autograd.Function):
         dres_in = None
         if ctx.has_residual and xsum.dtype != ctx.x_dtype:
             dres_in = torch.empty(rows, cols, dtype=xsum.dtype, device=dy.device)
-        dw = torch.zeros(cols, dtype=torch.float32, device=dy.device)
-        db = None if bias is None else torch.zeros(cols, dtype=torch.float32, device=dy.device)
+        # frozen norm weights (every RMSNorm in the 'align' stage): the kernel then writes no partial sums and the reduction is not launched
+        dw = torch.zeros(cols, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
+        db = None if (bias is None or not ctx.needs_input_grad[2]) else torch.zeros(cols, dtype=torch.float32, device=dy.device)
         if rows > 0:
             p = K.AddNormBwd(dy=K.T(dy2), dresidual_out=K.T(dres), xsum=K.T(xsum), weight=K.T(weight), rstd=K.T(rstd),
                              mean=K.T(mean), dx=K.T(dx), dresidual_in=K.T(dres_in), dweight=K.T(dw), dbias=K.T(db),
@@ -82,7 +83,7 @@ class LayerNormFn(torch.autograd.Function):
             dres_ret = dres_in.reshape(ctx.shape) if dres_in is not None else dx
         else:
             dres_ret = None
-        return (dx, dw.to(weight.dtype), None if bias is None else db.to(bias.dtype), dres_ret, None, None, None, None)
+        return (dx, None if dw is None else dw.to(weight.dtype), None if db is None else db.to(bias.dtype), dres_ret, None, None, None, None)
 
 
 def layer_norm_fn(x, weight, bias, residual=None, x1=None, weight1=None, bias1=None, eps=1e-6, dropout_p=0.0,

@@ -49,19 +49,19 @@ class NormGatedFn(torch.autograd.Function):
             dy2 = dy2.to(x2.dtype)
         dx = torch.empty_like(x2)
         dz = None if z2 is None else torch.empty_like(z2)
-        dw = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+        dw = torch.zeros(cols, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None   # frozen weight: no reduction
         if x2.shape[0] > 0:
             p = K.NormGatedBwd(dy=K.T(dy2), x=K.T(x2), z=K.T(z2), weight=K.T(weight), dx=K.T(dx), dz=K.T(dz),
                                dweight=K.T(dw), group_size=ctx.gs, eps=ctx.eps, norm_before_gate=int(ctx.nbg))
             ws = K.workspace(lib, "omk_norm_gated_bwd_workspace_bytes", p, dy2)  # noqa: F841
             K.run(lib, "omk_norm_gated_bwd", p, dy2)
         db = None
-        if bias is not None:
+        if bias is not None and ctx.needs_input_grad[2]:
             g = dy2.float()
             if z2 is not None and ctx.nbg:
                 g = g * torch.nn.functional.silu(z2.float())
             db = g.sum(0).to(bias.dtype)
-        return (dx.reshape(ctx.shape), dw.to(weight.dtype), db, None if dz is None else dz.reshape(ctx.shape),
+        return (dx.reshape(ctx.shape), None if dw is None else dw.to(weight.dtype), db, None if dz is None else dz.reshape(ctx.shape),
                 None, None, None)
 
 

@@ -19,7 +19,7 @@ from . import _prof
 from ._lib import get_lib, require_device
 from .causal_conv1d import causal_conv1d_fn
 from .layernorm_gated import rmsnorm_fn
-from .linear import weight_grad
+from .linear import frozen_cast, weight_grad
 
 _INF = float("inf")
 
@@ -204,14 +204,18 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         else:
             out_n = y.reshape(Bsz, L, d_ssm)
         if outproj_weight is not None:
-            w = outproj_weight.to(out_n.dtype)
+            w = outproj_weight if outproj_weight.dtype == out_n.dtype else frozen_cast(outproj_weight, out_n.dtype)   # cast once per weight version
             out = F.linear(out_n, w, None if outproj_bias is None else outproj_bias.to(out_n.dtype))
+            ctx.w_cast = w          # the 16-bit copy the input gradient reuses (saved_tensors hands back new objects: no cache hit there)
         else:
             out = out_n
         keep = os.environ.get("OMK_RECOMPUTE", "0") != "1"
+        # the norm output is only the operand of out_proj's WEIGHT gradient: a frozen out_proj ('align' stage) neither keeps it
+        # (134 MB per 16 k tokens and layer) nor forms that gradient (a 0.27 TFLOP GEMM per layer: 7 % of the stage-1 step)
+        need_wo = outproj_weight is not None and ctx.needs_input_grad[14]
         ctx.save_for_backward(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, y_pre, rmsnorm_weight, outproj_weight,
                               outproj_bias, initial_states, xBC_c if keep else None,
-                              out_n if (keep and use_norm and outproj_weight is not None) else None)
+                              out_n if (keep and use_norm and need_wo) else None)
         ctx.cfg = (H, P, G, N, chunk_size, dt_limit, activation, rmsnorm_eps, norm_before_gate, return_final_states)
         return (out, fin) if return_final_states else out
 
@@ -233,22 +237,24 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         d_outproj_w = d_outproj_b = None
         y2 = y_pre.reshape(Bsz, L, d_ssm)
         lib = get_lib()
-        if use_norm:
-            if on_saved is not None:
+        need_wo = outproj_w is not None and ctx.needs_input_grad[14]
+        on = None
+        if need_wo:
+            if not use_norm:
+                on = (y2.float() * F.silu(z.float())).to(adt)
+            elif on_saved is not None:
                 on = on_saved
-            elif outproj_w is not None:
+            else:
                 with torch.no_grad():
                     on = rmsnorm_fn(y2, norm_w, None, z=z, eps=eps, group_size=d_ssm // G, norm_before_gate=nbg)
-            else:
-                on = None
-        else:
-            on = (y2.float() * F.silu(z.float())).to(adt)
         if outproj_w is not None:
-            d_outn = dout @ outproj_w.to(adt)
-            do2, on2 = dout.reshape(-1, dout.shape[-1]), on.reshape(-1, d_ssm)
-            d_outproj_w = weight_grad(do2 if do2.is_contiguous() else do2.contiguous(), on2 if on2.is_contiguous() else on2.contiguous(),
-                                      outproj_w.dtype)
-            if outproj_b is not None:
+            w_c = getattr(ctx, "w_cast", None)
+            d_outn = dout @ (w_c if (w_c is not None and w_c.dtype == adt) else outproj_w.to(adt))
+            if need_wo:
+                do2, on2 = dout.reshape(-1, dout.shape[-1]), on.reshape(-1, d_ssm)
+                d_outproj_w = weight_grad(do2 if do2.is_contiguous() else do2.contiguous(), on2 if on2.is_contiguous() else on2.contiguous(),
+                                          outproj_w.dtype)
+            if outproj_b is not None and ctx.needs_input_grad[15]:
                 d_outproj_b = dout.reshape(-1, dout.shape[-1]).sum(0).to(outproj_b.dtype)
         else:
             d_outn = dout
@@ -265,12 +271,12 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
             if g_r.stride(-1) != 1:
                 g_r = g_r.contiguous()
             dy = torch.empty(Bsz, L, d_ssm, dtype=adt, device=dev)
-            gw = torch.zeros(d_ssm, dtype=torch.float32, device=dev)
+            gw = torch.zeros(d_ssm, dtype=torch.float32, device=dev) if ctx.needs_input_grad[12] else None   # frozen norm weight: no reduction
             pn = K.NormGatedBwd(dy=K.T(g_r), x=K.T(y_r), z=K.T(z_r), weight=K.T(norm_w), dx=K.T(dy.reshape(rows, d_ssm)),
                                 dz=K.T(dz_r), dweight=K.T(gw), group_size=d_ssm // G, eps=eps, norm_before_gate=int(nbg))
             wsn = K.workspace(lib, "omk_norm_gated_bwd_workspace_bytes", pn, g_r)  # noqa: F841
             K.run(lib, "omk_norm_gated_bwd", pn, g_r)
-            d_norm_w = gw.to(norm_w.dtype)
+            d_norm_w = None if gw is None else gw.to(norm_w.dtype)
         else:
             zf = z.float()
             dz.copy_((d_outn.float() * y2.float() * _silu_grad(zf)).to(adt))

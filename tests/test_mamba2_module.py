@@ -96,3 +96,24 @@ def test_recompute_flag_gives_identical_gradients(dev, monkeypatch):
             assert torch.equal(a, b)          # same kernels on the same values
         else:
             assert rel(a, b) < 1e-5           # GPU: weight gradients fold through fp32 atomics (order varies run to run)
+
+
+def test_frozen_out_proj_forms_no_weight_gradient(dev):
+    """A frozen out_proj (the reference's 'align' stage freezes every base projection) gets no gradient and keeps no norm
+    output; every other gradient is the one of the unfrozen module."""
+    m, _ = build(dev)
+    torch.manual_seed(2)
+    u = torch.randn(2, 37, 32)
+    g = torch.randn(2, 37, 32)
+    grads = {}
+    for frozen in (False, True):
+        m.zero_grad(set_to_none=True)
+        m.out_proj.weight.requires_grad_(not frozen)
+        ud = u.clone().to(dev).requires_grad_()
+        m(ud).backward(g.to(dev))
+        grads[frozen] = {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in m.named_parameters()}
+        grads[frozen]["u"] = ud.grad.cpu()
+    assert grads[True]["out_proj.weight"] is None and grads[False]["out_proj.weight"] is not None
+    for n, v in grads[False].items():
+        if n != "out_proj.weight":
+            assert rel(grads[True][n], v) < 1e-5, n      # (not bit-equal on the GPU: the conv weight gradient is summed with atomics)
