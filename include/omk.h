@@ -247,6 +247,19 @@ typedef struct {
 } OmkLoraAdd;
 int omk_lora_add(const OmkLoraAdd* p, omk_stream stream);
 
+/* ---- backward of the rank-r up-projection, both products in ONE pass over dy --------------------------------------------
+ * dh (T, r) += dy (T, N) lora_b (N, r)   and   dlora_b (N, r) += dy^T h (T, r)   (reference lora.py:263-279, backward of
+ * lora_B(.)).  As two library GEMMs each reads the (tokens, 8512) gradient once (279 MB at 16 k tokens: 69 + 59 us).
+ * bf16 dy / h, rank <= 8, 16-byte aligned rows; f32 outputs are ACCUMULATED into (atomics: the caller zeroes them).          */
+typedef struct {
+  OmkTensor dy;       /* (T, N) bf16 */
+  OmkTensor lora_b;   /* (N, r) f32 / bf16 / f16 */
+  OmkTensor h;        /* (T, r) bf16 */
+  OmkTensor dh;       /* out (T, r) f32, dense, accumulated */
+  OmkTensor dlora_b;  /* out (N, r) f32, dense, accumulated */
+} OmkLoraUpBwd;
+int omk_lora_up_bwd(const OmkLoraUpBwd* p, omk_stream stream);
+
 /* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------
  * upstream mamba_ssm.ops.triton.ssd_combined.mamba_chunk_scan_combined (+ the scan stage of
  * mamba_split_conv1d_scan_combined); reference reach: models/stage2/block.py:117 -> Mamba2.forward              */

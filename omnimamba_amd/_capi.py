@@ -71,6 +71,7 @@ NormLinear = _S("OmkNormLinear", [(n, _t) for n in ("x", "residual", "z", "norm_
                 + [("group_size", C.c_int64), ("conv_offset", C.c_int64), ("eps", _f), ("lora_scale", _f),
                    ("norm_before_gate", _i), ("conv_silu", _i)])
 LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b", "mask")] + [("scale", _f)])
+LoraUpBwd = _S("OmkLoraUpBwd", [(n, _t) for n in ("dy", "lora_b", "h", "dh", "dlora_b")])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
@@ -83,7 +84,7 @@ CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("
                                       ("ignore_index", _i64), ("write_grad", _i)])
 
 STRUCTS = {s.__name__: s for s in (CrossEntropy, OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
-                                   Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, NormLinear, LoraAdd, SsdFwd, SsdBwd)}
+                                   Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, NormLinear, LoraAdd, LoraUpBwd, SsdFwd, SsdBwd)}
 
 # every symbol include/omk.h declares
 SYMBOLS = [
@@ -91,7 +92,7 @@ SYMBOLS = [
     "omk_add_norm_fwd", "omk_add_norm_bwd_workspace_bytes", "omk_add_norm_bwd",
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
-    "omk_selective_state_update", "omk_norm_linear", "omk_lora_add",
+    "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
     "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
     "omk_cross_entropy",

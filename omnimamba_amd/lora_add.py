@@ -78,3 +78,24 @@ def lora_add_(out2d, h2d, lora_b, scale, mask=None):
 def lora_add(result2d, h2d, lora_b, scale):
     """result2d (tokens, out) + scale * h2d (tokens, r) @ lora_b (out, r)^T; overwrites result2d's storage."""
     return _LoraAdd.apply(result2d, h2d, lora_b, scale)
+
+
+def up_bwd_applies(dy2d: torch.Tensor, h2d: torch.Tensor, lora_b: torch.Tensor) -> bool:
+    try:
+        on_lib_device = dy2d.is_cuda != bool(get_lib().omk_is_emulated())
+    except RuntimeError:
+        return False
+    return (on_lib_device and dy2d.dim() == 2 and dy2d.dtype == torch.bfloat16 and h2d.dtype == torch.bfloat16 and h2d.shape[1] == 8
+            and dy2d.shape[1] % 8 == 0 and dy2d.stride(1) == 1 and h2d.stride(1) == 1 and lora_b.stride(1) == 1
+            and dy2d.data_ptr() % 16 == 0 and h2d.data_ptr() % 16 == 0 and (dy2d.stride(0) * 2) % 16 == 0 and (h2d.stride(0) * 2) % 16 == 0)
+
+
+def lora_up_bwd(dy2d, h2d, lora_b):
+    """(dy2d @ lora_b, dy2d^T @ h2d) as fp32 (tokens, r) and (out, r) from ONE pass over dy2d (omk_lora_up_bwd).  No autograd."""
+    lib = get_lib()
+    require_device(lib, dy2d, h2d, lora_b)
+    T, N, r = dy2d.shape[0], dy2d.shape[1], h2d.shape[1]
+    acc = torch.zeros((T + N) * r, dtype=torch.float32, device=dy2d.device)
+    dh, db = acc[:T * r].view(T, r), acc[T * r:].view(N, r)
+    K.run(lib, "omk_lora_up_bwd", K.LoraUpBwd(dy=K.T(dy2d), lora_b=K.T(lora_b), h=K.T(h2d), dh=K.T(dh), dlora_b=K.T(db)), dy2d)
+    return dh, db

@@ -15,6 +15,8 @@ dh = s dy B and dB = s dy^T h as skinny GEMMs, dW -- when the base weight trains
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -75,9 +77,16 @@ class _LoraExtFn(torch.autograd.Function):
         dyc = dy if dy.is_contiguous() else dy.contiguous()
         adt = dyc.dtype
         dx = da = db = None
-        dh = (dyc @ lora_b.to(adt)) * ctx.scale                      # (tokens, r)
-        if ctx.needs_input_grad[3]:
-            db = weight_grad(dyc, h2d.contiguous(), torch.float32).mul_(ctx.scale).to(lora_b.dtype)
+        if os.environ.get("OMK_LORA_UP_FUSED", "1") != "0" and LA.up_bwd_applies(dyc, h2d, lora_b):
+            # dh = dy B and dB = dy^T h from ONE pass over dy (omk_lora_up_bwd): as two library GEMMs each streams the 279 MB
+            dh32, db32 = LA.lora_up_bwd(dyc, h2d, lora_b)
+            dh = (dh32 * ctx.scale).to(adt)                           # (tokens, r)
+            if ctx.needs_input_grad[3]:
+                db = (db32 * ctx.scale).to(lora_b.dtype)
+        else:
+            dh = (dyc @ lora_b.to(adt)) * ctx.scale
+            if ctx.needs_input_grad[3]:
+                db = weight_grad(dyc, h2d.contiguous(), torch.float32).mul_(ctx.scale).to(lora_b.dtype)
         if ctx.needs_input_grad[2]:
             da = weight_grad(dh.contiguous(), xd if xd.is_contiguous() else xd.contiguous(), torch.float32).to(lora_a.dtype)
         if ctx.needs_input_grad[0]:

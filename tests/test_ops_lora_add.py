@@ -47,3 +47,17 @@ def test_lora_add_masked(dev, T, N, R, dtype):
     ref = out.double() + mask.double() * 1.25 * (h.double() @ Bw.double().t())
     assert rel(od, ref) < (2e-6 if dtype == torch.float32 else 6e-3)
     assert torch.equal(od.cpu()[~mask], out[~mask])          # untouched elements are bit-identical
+
+
+@pytest.mark.parametrize("T,N", [(300, 8512), (64, 256), (1000, 520)])
+def test_lora_up_bwd(dev, T, N):
+    """omk_lora_up_bwd: dh = dy B and dB = dy^T h from one pass over dy, vs fp64 (ragged token tail, partial last column block)."""
+    from omnimamba_amd import lora_add as LA
+    torch.manual_seed(3)
+    dy, h = torch.randn(T, N).bfloat16(), torch.randn(T, 8).bfloat16()
+    Bw = torch.randn(N, 8) * 0.1
+    assert LA.up_bwd_applies(dy.to(dev), h.to(dev), Bw.to(dev))
+    dh, db = LA.lora_up_bwd(dy.to(dev), h.to(dev), Bw.to(dev))
+    Bq = Bw.bfloat16().double()                      # the kernel holds lora_b as bf16 MFMA fragments
+    assert dh.dtype == torch.float32 and rel(dh, dy.double() @ Bq) < 1e-5
+    assert db.dtype == torch.float32 and rel(db, dy.double().t() @ h.double()) < 1e-5
