@@ -396,15 +396,19 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
   if ((int64_t)a.B * a.C * a.L == 0) return OMK_OK;
   const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->out, a.C);
   if (fast) {
-    constexpr int TL = 32;
     // 4 channels (8 bytes) per lane and 8 tokens per load group: 100 VGPRs / 4 waves per SIMD measured fastest on the
     // 1.3B shape (141 us vs 171 us for 8 channels per lane, which needs 158 VGPRs)
-#define CONV_FWD_V(T_, VEC_, TG_) do { int64_t n = (int64_t)a.B * ((a.L + TL - 1) / TL) * (a.C / VEC_); \
+#define CONV_FWD_V(T_, VEC_, TL_, TG_) do { int64_t n = (int64_t)a.B * ((a.L + TL_ - 1) / TL_) * (a.C / VEC_); \
       dim3 grid((unsigned)((n + 255) / 256)), block(256); \
-      if (a.W == 4) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL, 4, TG_>), grid, block, 0, stream, a); \
-      else if (a.W == 3) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL, 3, TG_>), grid, block, 0, stream, a); \
-      else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL, 2, TG_>), grid, block, 0, stream, a); } while (0)
-    if (p->x.dtype == OMK_BF16) CONV_FWD_V(bf16_t, 4, 8); else CONV_FWD_V(f16_t, 4, 8);
+      if (a.W == 4) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 4, TG_>), grid, block, 0, stream, a); \
+      else if (a.W == 3) OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 3, TG_>), grid, block, 0, stream, a); \
+      else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 2, TG_>), grid, block, 0, stream, a); } while (0)
+    const char* tle = getenv("OMK_CONV_FWD_TL");   // developer A/B of the tokens per thread (bf16)
+    const int tl = (tle && *tle) ? atoi(tle) : (a.L >= 1024 ? 64 : 32);   // 64: -4 % on the 1.3B slice (halo rows), 128: worse again
+    if (p->x.dtype == OMK_BF16) {
+      if (tl == 128) CONV_FWD_V(bf16_t, 4, 128, 8); else if (tl == 64) CONV_FWD_V(bf16_t, 4, 64, 8); else if (tl == 16) CONV_FWD_V(bf16_t, 4, 16, 8);
+      else CONV_FWD_V(bf16_t, 4, 32, 8);
+    } else CONV_FWD_V(f16_t, 4, 32, 8);
 #undef CONV_FWD_V
   } else {
     int64_t n = (int64_t)a.B * a.C * a.L;
