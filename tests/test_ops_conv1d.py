@@ -11,7 +11,7 @@ def rel(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("W", [2, 3, 4])
-@pytest.mark.parametrize("layout,C,L", [("cl", 16, 37), ("cl", 24, 140), ("cf", 6, 19)])
+@pytest.mark.parametrize("layout,C,L", [("cl", 16, 37), ("cl", 24, 140), ("cf", 6, 19), ("cl", 8, 1100)])   # 1100: the long-sequence strips
 def test_conv1d_fwd_bwd(dev, dtype, W, layout, C, L):
     from omnimamba_amd.causal_conv1d import causal_conv1d_fn
     torch.manual_seed(0)
