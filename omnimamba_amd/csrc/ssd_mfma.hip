@@ -968,6 +968,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (!stride_ok(g.K.sl) || !stride_ok(g.Q.sl) || !stride_ok(g.U.sl) || !stride_ok(g.osl) || (g.Z.p && !stride_ok(g.Z.sl))) return OMK_EUNSUPPORTED;
   if (dry) return OMK_OK;
+  if (ssd_v6_applies(g)) return ssd_v6_launch(g, stream);
   if (ssd_v5a_applies(g) && (!g.seg_ready || g.seg_fmt == 1)) return ssd_v5a_launch(g, stream);
   // one head (x one segment of the sequence) per workgroup, two workgroups per CU
   GScan a = g;

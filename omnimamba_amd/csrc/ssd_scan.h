@@ -94,6 +94,9 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 
 // split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the
 // state at the START of segment j (initial state included).  Shared by the scans whose state this is (y and dC; dx and dB).
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = nullptr);   // *seg_fmt: the order it left the states in
+// three workgroups per CU (ssd_v6.hip, round 2)
+bool ssd_v6_applies(const GScan& g);
+int ssd_v6_launch(const GScan& g, omk_stream stream);
 // the two-waves-per-head kernels of round 2 (ssd_v5.hip)
 bool ssd_v5a_applies(const GScan& g);
 int ssd_v5a_launch(const GScan& g, omk_stream stream);
