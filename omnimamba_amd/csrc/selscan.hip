@@ -158,17 +158,21 @@ __device__ __forceinline__ void wave_scan_affine(float& p, float& x) {
     if (lane_id() >= off) { x = fmaf(p, xs, x); p = p * ps; }
   }
 #else
-  // lanes without a source (start of a row / rows outside the row mask) receive the identity pair (1, 0)
-#define OMK_AFF_STEP(ctrl, rowmask) { \
-    const float ps = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, p), ctrl, rowmask, 0xf, false)); \
-    const float xs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rowmask, 0xf, false)); \
-    x = fmaf(p, xs, x); p = p * ps; }
-  OMK_AFF_STEP(0x111, 0xf)   // row_shr:1
-  OMK_AFF_STEP(0x112, 0xf)   // row_shr:2
-  OMK_AFF_STEP(0x114, 0xf)   // row_shr:4
-  OMK_AFF_STEP(0x118, 0xf)   // row_shr:8
-  OMK_AFF_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
-  OMK_AFF_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
+  // One step = v_fmac_f32_dpp (x += p * x_src) + v_mul_f32_dpp (p *= p_src), the DPP modifier on the shifted operand.  A lane
+  // without a source (start of a row, rows outside the row mask) is simply not written -- the identity pair for free; through
+  // __builtin_amdgcn_update_dpp the compiler built every step from two moves of the identity, two v_mov_dpp, a nop, the fmac and
+  // the mul (7 instructions x 6 steps of a VALU-bound loop).  Hand-placed wait states: a DPP read needs two after the VALU write
+  // of its source (x: mul + nop; p: nop + fmac); inline assembly gets no hazard recogniser.
+#define OMK_AFF_STEP(ctrl) \
+  "v_fmac_f32_dpp %0, %0, %1 " ctrl "\n\tv_mul_f32_dpp %1, %1, %1 " ctrl "\n\ts_nop 0\n\t"
+  asm volatile("s_nop 1\n\t"
+               OMK_AFF_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               OMK_AFF_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(x), "+v"(p));
 #undef OMK_AFF_STEP
 #endif
 }
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void selscan_fwd_chunked_kernel(SsArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // STATE_ONLY (first pass of the chunked backward): no C rows, no y, no output -- the state in front of every pass of 64 * SSC_LC
 // tokens goes to a.ckpt as (B, D, passes, N) f32
-template <class T, int SSC_LC, int NU, bool STATE_ONLY = false>   // NU: state indices per trip of the n loop (2: two independent scans interleave)
+template <class T, int SSC_LC, int NU, bool STATE_ONLY = false>   // NU = 2: the elementwise half of the n loop on packed pairs of adjacent tokens
 __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
   constexpr int VEC = 16 / sizeof(T), PPR = 64 * SSC_LC / VEC;   // 16-byte pieces per staged row
   __shared__ float scarry[8][64], sA2[8][64];
@@ -403,7 +407,57 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
     block_sync();   // rows staged
     const T* pB = sBC + lane * VEC;
     const T* pC = pB + (size_t)a.N * (64 * SSC_LC);
-#pragma unroll NU
+    if (NU == 2) {
+      // the elementwise half of the n loop on PACKED fp32 pairs of adjacent tokens (v_pk_mul_f32 / v_pk_fma_f32: two tokens per
+      // issue): delta A2, delta u B and the y accumulation.  The two recurrences (fold, sweep) are serial in the token index and the
+      // exponentials are not packable; the loop is VALU-bound, so instructions are time.
+      constexpr int HP = SSC_LC / 2;
+      f32x2 dl2[HP], u2[HP], y2[HP];
+#pragma unroll
+      for (int j = 0; j < HP; j++) { dl2[j] = f32x2{dl[2 * j], dl[2 * j + 1]}; u2[j] = f32x2{u[2 * j], u[2 * j + 1]}; y2[j] = f32x2{0.f, 0.f}; }
+      for (int n = 0; n < a.N; n++) {
+        const float A2 = sA2[wv][n];
+        const f32x2 A22 = {A2, A2};
+        f32x2 bt2[HP], C2[HP], av2[HP];
+#pragma unroll
+        for (int v = 0; v < SSC_LC / VEC; v++) {
+          float wb[VEC], wc[VEC];
+          load_vec<T, VEC>(pB + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wb);
+          if (!STATE_ONLY) load_vec<T, VEC>(pC + (size_t)n * (64 * SSC_LC) + v * 64 * VEC, wc);
+#pragma unroll
+          for (int e = 0; e < VEC; e += 2) {
+            bt2[(v * VEC + e) / 2] = f32x2{wb[e], wb[e + 1]};
+            C2[(v * VEC + e) / 2] = STATE_ONLY ? f32x2{0.f, 0.f} : f32x2{wc[e], wc[e + 1]};
+          }
+        }
+        float P = exp2_fast(sdl * A2), X = 0.f;
+#pragma unroll
+        for (int j = 0; j < HP; j++) {
+          const f32x2 e2 = dl2[j] * A22;
+          av2[j] = f32x2{exp2_fast(e2[0]), exp2_fast(e2[1])};
+          bt2[j] = bt2[j] * u2[j];                 // b_t = delta_t u_t B_t[n]
+          X = fmaf(av2[j][0], X, bt2[j][0]);
+          X = fmaf(av2[j][1], X, bt2[j][1]);
+        }
+        wave_scan_affine(P, X);
+        const float cin = carry[n];
+        const float xend = fmaf(P, cin, X);
+        float x = shfl_up(xend, 1);
+        if (lane == 0) x = cin;
+        const float cout = wave_read_lane(xend, 63);
+        if (!STATE_ONLY) {
+#pragma unroll
+          for (int j = 0; j < HP; j++) {
+            const float xa = fmaf(av2[j][0], x, bt2[j][0]);
+            x = fmaf(av2[j][1], xa, bt2[j][1]);
+            y2[j] = C2[j] * f32x2{xa, x} + y2[j];
+          }
+        }
+        if (lane == 0) carry[n] = cout;
+      }
+#pragma unroll
+      for (int j = 0; j < HP; j++) { y[2 * j] = y2[j][0]; y[2 * j + 1] = y2[j][1]; }
+    } else {
     for (int n = 0; n < a.N; n++) {
       const float A2 = sA2[wv][n];
       float Bv[SSC_LC], Cv[SSC_LC];
@@ -437,6 +491,7 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
         }
       }
       if (lane == 0) carry[n] = cout;
+    }
     }
     if (STATE_ONLY) continue;
     float ur[SSC_LC];
@@ -491,14 +546,15 @@ __device__ __forceinline__ void wave_scan_affine_rev(float& p, float& x) {
     if (lane_id() + off < 64) { x = fmaf(p, xs, x); p = p * ps; }
   }
 #else
-#define OMK_AFF_STEP(ctrl) { \
-    const float ps = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, p), ctrl, 0xf, 0xf, false)); \
-    const float xs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false)); \
-    x = fmaf(p, xs, x); p = p * ps; }
-  OMK_AFF_STEP(0x101)   // row_shl:1
-  OMK_AFF_STEP(0x102)   // row_shl:2
-  OMK_AFF_STEP(0x104)   // row_shl:4
-  OMK_AFF_STEP(0x108)   // row_shl:8
+  // (steps as in wave_scan_affine: the DPP modifier on the fmac / mul themselves, lanes without a source are not written)
+#define OMK_AFF_STEP(ctrl) \
+  "v_fmac_f32_dpp %0, %0, %1 " ctrl "\n\tv_mul_f32_dpp %1, %1, %1 " ctrl "\n\ts_nop 0\n\t"
+  asm volatile("s_nop 1\n\t"
+               OMK_AFF_STEP("row_shl:1 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shl:2 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shl:4 row_mask:0xf bank_mask:0xf")
+               OMK_AFF_STEP("row_shl:8 row_mask:0xf bank_mask:0xf")
+               : "+v"(x), "+v"(p));
 #undef OMK_AFF_STEP
   // lanes 16 / 32 / 48 hold the totals of rows 1 / 2 / 3; row r still needs rows r + 1 .. 3
   const float p1 = wave_read_lane(p, 16), x1 = wave_read_lane(x, 16), p2 = wave_read_lane(p, 32), x2 = wave_read_lane(x, 32);
@@ -950,7 +1006,7 @@ static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream, bool pass_ckpt =
         if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, LC_, NU_>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_fwd: cannot raise dynamic LDS to %zu", bc_bytes); \
         OMK_LAUNCH((selscan_fwd_shared_kernel<T, LC_, NU_>), grid, block, bc_bytes, stream, a); } while (0)
       const char* nue = getenv("OMK_SELSCAN_NU");
-      const bool nu2 = nue ? atoi(nue) == 2 : false;
+      const bool nu2 = nue ? atoi(nue) == 2 : true;   // packed token pairs in the n loop (OMK_SELSCAN_NU=1: the scalar form)
 #define SSC_ST(T) do { \
         if (OMK_SET_MAX_DYN_SMEM((selscan_fwd_shared_kernel<T, 8, 1, true>), bc_bytes)) return fail(OMK_ELAUNCH, "selective_scan_bwd: cannot raise dynamic LDS to %zu", bc_bytes); \
         OMK_LAUNCH((selscan_fwd_shared_kernel<T, 8, 1, true>), grid, block, bc_bytes, stream, a); } while (0)
