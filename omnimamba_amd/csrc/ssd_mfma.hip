@@ -106,56 +106,44 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh;
   const float* dtrow = a.dtp + ((int64_t)b * a.H + h) * a.L;
   const int ksl = (int)a.K.sl, qsl = (int)a.Q.sl, usl = (int)a.U.sl, osl = (int)a.osl;
-  const uint32_t koff0 = (uint32_t)(rowtok(rowk) * ksl + ck8), uoff0 = (uint32_t)(rowtok(rowu) * usl + cu8);
-  const uint32_t qoff0 = (uint32_t)(rowtok(16 * w + t16) * qsl + 8 * g16);
-  const int kstep = (rev ? -16 : 16) * ksl, ustep = (rev ? -32 : 32) * usl;
+  // Staging through BUFFER loads (ssd_tiles.h): lane offset + scalar offset + resource, the address is formed by the memory
+  // pipeline -- no 64-bit VALU adds, and rows behind the end of the sequence (ragged last chunk) come back as zeros by the
+  // range check, so neither clamped addresses nor selects.  Chunk row i <-> token tlo + (rev ? 63 - i : i); the lane part of the
+  // row goes to the lane offset, the per-load part (always >= 0) to the scalar offset.
+  const BufRes Kr = make_buf(Kb, (uint32_t)((int64_t)a.L * ksl * 2)), Qr = make_buf(Qb, (uint32_t)((int64_t)a.L * qsl * 2));
+  const BufRes Ur = make_buf(Ub, (uint32_t)((int64_t)a.L * usl * 2)), Dr = make_buf(dtrow, (uint32_t)((int64_t)a.L * 4));
+  const uint32_t kvo = 2u * (uint32_t)((rev ? 15 - rowk : rowk) * ksl + ck8), uvo = 2u * (uint32_t)((rev ? 31 - rowu : rowu) * usl + cu8);
+  const uint32_t qvo = 2u * (uint32_t)(rowtok(16 * w + t16) * qsl + 8 * g16);
+  const uint32_t dvo = 4u * (uint32_t)rowtok(lane), dvo_a = 4u * (uint32_t)(rowtok(lane) + (rev ? 1 : 0));
   u32x4 rk[4], ru[2], qf[4];
   float rdt = 0.f, rda = 0.f, rwv = 0.f;
   int stlo = 0;   // tlo of the chunk held in the staging registers
   // The loads of the next chunk are spread over the phases of the current one (a burst of ten 1 KB loads per wave
-  // stalls on the 64 B/clk address path): K after barrier X, Q fragments, U and dt after the intra phase.  They are
-  // branch-free on purpose: rows past the end of a ragged last chunk read the chunk's first row instead (the commit
-  // zeroes them).  With vector-memory instructions under control flow the compiler can no longer count what is in
-  // flight and falls back to s_waitcnt vmcnt(0) -- which also waits for the output stores of the previous chunk.
-  const int rtk_k = rowtok(rowk), rtk_u = rowtok(rowu), rtk_q = rowtok(16 * w + t16), rtk_l = rowtok(lane);
-  const int dk16 = rev ? -16 : 16, du32 = rev ? -32 : 32;
+  // stalls on the 64 B/clk address path): K after barrier X, Q fragments, U and dt after the intra phase.
   auto prefetch_k = [&]() {
-    const int lim = a.L - stlo;   // rows with rowtok < lim are in range
-    const uint16_t* Kc = Kb + (int64_t)stlo * ksl;
+    const uint32_t so = 2u * (uint32_t)(stlo * ksl);
 #pragma unroll
-    for (int r = 0; r < 4; r++) rk[r] = ld16(Kc + (rtk_k + dk16 * r < lim ? koff0 + (uint32_t)(r * kstep) : (uint32_t)ck8));
+    for (int r = 0; r < 4; r++) rk[r] = buf_ld16(Kr, kvo, so + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * ksl));
   };
   auto prefetch_q = [&]() {   // straight into the live fragment registers: issued after their last use of the chunk
-    const int lim = a.L - stlo;
-    const uint16_t* Qc = Qb + (int64_t)stlo * qsl;
-    const uint32_t qo = rtk_q < lim ? qoff0 : (uint32_t)(8 * g16);   // rows past the end: any in-range row, never stored
+    const uint32_t so = 2u * (uint32_t)(stlo * qsl);
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) qf[kk] = ld16(Qc + 32 * kk + qo);
+    for (int kk = 0; kk < 4; kk++) qf[kk] = buf_ld16(Qr, qvo, so + 64u * kk);
   };
   auto prefetch_u = [&]() {
-    const int lim = a.L - stlo;
-    const uint16_t* Uc = Ub + (int64_t)stlo * usl;
+    const uint32_t so = 2u * (uint32_t)(stlo * usl);
 #pragma unroll
-    for (int r = 0; r < 2; r++) ru[r] = ld16(Uc + (rtk_u + du32 * r < lim ? uoff0 + (uint32_t)(r * ustep) : (uint32_t)cu8));
+    for (int r = 0; r < 2; r++) ru[r] = buf_ld16(Ur, uvo, so + 2u * (uint32_t)((rev ? 32 * (1 - r) : 32 * r) * usl));
     // token scalars (consumed by wave 0, loaded by every wave to keep the instruction stream uniform): lanes = rows
-    const int t = stlo + rtk_l, ta = rev ? t + 1 : t;
-    rdt = dtrow[t < a.L ? t : 0];   // raw loads: the selects wait in scalars() so nothing stalls on them here
-    rda = dtrow[ta < a.L ? ta : 0];
+    rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)stlo);
+    rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)stlo);
   };
   const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
-  auto commit = [&](int buf) {
-    if (stlo + QC <= a.L) {
+  auto commit = [&](int buf) {   // rows past the end arrived as zeros
 #pragma unroll
-      for (int r = 0; r < 4; r++) st16(&sm.K[buf][o_ck + 16 * 128 * r], rk[r]);
+    for (int r = 0; r < 4; r++) st16(&sm.K[buf][o_ck + 16 * 128 * r], rk[r]);
 #pragma unroll
-      for (int r = 0; r < 2; r++) st16(&sm.U[buf][o_cu + 32 * 64 * r], ru[r]);
-    } else {
-      const u32x4 zero4 = {0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 4; r++) st16(&sm.K[buf][o_ck + 16 * 128 * r], stlo + rowtok(rowk + 16 * r) < a.L ? rk[r] : zero4);
-#pragma unroll
-      for (int r = 0; r < 2; r++) st16(&sm.U[buf][o_cu + 32 * 64 * r], stlo + rowtok(rowu + 32 * r) < a.L ? ru[r] : zero4);
-    }
+    for (int r = 0; r < 2; r++) st16(&sm.U[buf][o_cu + 32 * 64 * r], ru[r]);
   };
   const float Ah = a.A[h];
   const float Ah2 = Ah * LOG2E;
@@ -244,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const float Dh = (DFOLD && a.D) ? load_rt(a.D, (int64_t)h * a.Dsh, a.D_dt) : 0.f;
   block_sync();
   uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
+  const BufRes Or = make_buf(STATE ? nullptr : ob, STATE ? 0u : (uint32_t)((int64_t)a.L * osl * 2));
   uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
   const uint16_t* zb = (MODE == GS_Y && a.Z.p) ? (const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)h * a.Z.sh : nullptr;
   const int zsl = (int)a.Z.sl;
@@ -388,34 +377,32 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     commit(nxt);
     if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);
-    // ---- epilogue from the MFMA layout: 4 consecutive columns of one row per (lane, ut)
-    if (!STATE) {
-      const int trow = tlo + erow;
-      if (trow < a.L && !(abl & 16)) {
-        const float dts = MODE == GS_DX ? sm.dtl[cur][16 * w + t16] : 1.f;
-        uint16_t* oc = ob + (int64_t)tlo * osl;
+    // ---- epilogue from the MFMA layout: 4 consecutive columns of one row per (lane, ut); buffer stores drop rows >= L
+    if (!STATE && !(abl & 16)) {
+      const float dts = MODE == GS_DX ? sm.dtl[cur][16 * w + t16] : 1.f;
+      const uint32_t oso = 2u * (uint32_t)(tlo * osl);
+      const bool live = EXTRAS ? (tlo + erow < a.L) : true;      // the gate / pre-gate copy still go through plain pointers
 #pragma unroll
-        for (int ut = 0; ut < 4; ut++) {
-          f32x4 v = acc[ut];
-          if (!DFOLD) {
-            const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][o_xu[ut] + 16 * 64 * w]);
-            const f32x4 Du = *reinterpret_cast<const f32x4*>(&sm.Dv[16 * ut + 4 * g16]);   // D of columns 16 ut + 4 g16 + r
-            v = acc[ut] * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
-          }
-          if (MODE == GS_Y) {
-            if (EXTRAS && oxb) {
-              u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-              *reinterpret_cast<u32x2*>(oxb + (int64_t)tlo * osl + 16 * ut + eoff) = o;
-            }
-            if (EXTRAS && zb) {
-              const u32x2 zr = *reinterpret_cast<const u32x2*>(zb + (int64_t)tlo * zsl + 16 * ut + zoff);
-              v[0] *= silu_fast(bf_lo(zr[0])); v[1] *= silu_fast(bf_hi(zr[0]));
-              v[2] *= silu_fast(bf_lo(zr[1])); v[3] *= silu_fast(bf_hi(zr[1]));
-            }
-          }
-          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(oc + 16 * ut + eoff) = o;
+      for (int ut = 0; ut < 4; ut++) {
+        f32x4 v = acc[ut];
+        if (!DFOLD) {
+          const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][o_xu[ut] + 16 * 64 * w]);
+          const f32x4 Du = *reinterpret_cast<const f32x4*>(&sm.Dv[16 * ut + 4 * g16]);   // D of columns 16 ut + 4 g16 + r
+          v = acc[ut] * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
         }
+        if (MODE == GS_Y && EXTRAS && live) {
+          if (oxb) {
+            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(oxb + (int64_t)tlo * osl + 16 * ut + eoff) = o;
+          }
+          if (zb) {
+            const u32x2 zr = *reinterpret_cast<const u32x2*>(zb + (int64_t)tlo * zsl + 16 * ut + zoff);
+            v[0] *= silu_fast(bf_lo(zr[0])); v[1] *= silu_fast(bf_hi(zr[0]));
+            v[2] *= silu_fast(bf_lo(zr[1])); v[3] *= silu_fast(bf_hi(zr[1]));
+          }
+        }
+        const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        buf_st8(Or, o, 2u * eoff, oso + 32u * ut);
       }
     }
     PT3(6);
@@ -967,6 +954,11 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (g.outx && ((uintptr_t)g.outx & 15)) return OMK_EUNSUPPORTED;
   if (g.mode == GS_DX && g.dD) return OMK_EUNSUPPORTED;   // dD comes from the dB scan
   if (!stride_ok(g.K.sl) || !stride_ok(g.Q.sl) || !stride_ok(g.U.sl) || !stride_ok(g.osl) || (g.Z.p && !stride_ok(g.Z.sl))) return OMK_EUNSUPPORTED;
+  {   // the class A kernel addresses one (batch, head) slice through 32-bit buffer offsets
+    int64_t ms = g.K.sl > g.Q.sl ? g.K.sl : g.Q.sl;
+    ms = ms > g.U.sl ? ms : g.U.sl; ms = ms > g.osl ? ms : g.osl;
+    if ((int64_t)g.L * ms * 2 >= (int64_t)0xfffff000) return OMK_EUNSUPPORTED;
+  }
   if (dry) return OMK_OK;
   if (ssd_v6_applies(g)) return ssd_v6_launch(g, stream);
   if (ssd_v5a_applies(g) && (!g.seg_ready || g.seg_fmt == 1)) return ssd_v5a_launch(g, stream);

@@ -11,6 +11,53 @@ __device__ __forceinline__ s16x8 as_s16x8(u32x4 v) { return __builtin_bit_cast(s
 __device__ __forceinline__ float bf_lo(uint32_t v) { return bf16_to_f32((uint16_t)(v & 0xffffu)); }
 __device__ __forceinline__ float bf_hi(uint32_t v) { return bf16_to_f32((uint16_t)(v >> 16)); }
 
+// ---- buffer resources: a global range addressed as resource (SGPRs) + 32-bit lane offset + 32-bit scalar offset.  The address
+// is formed by the memory pipeline (no 64-bit VALU adds per load: the scan kernels are issue bound) and the range check comes
+// with it: a load that starts at or behind `nbytes` returns 0, a store there is dropped -- the rows behind the end of a ragged
+// last chunk need neither clamped addresses nor selects.
+struct BufRes {
+#ifdef OMK_EMU
+  const char* base; uint32_t nbytes;
+#else
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ BufRes make_buf(const void* p, uint32_t nbytes) {
+  BufRes b;
+#ifdef OMK_EMU
+  b.base = (const char*)p; b.nbytes = nbytes;
+#else
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)nbytes, 0x00020000);   // raw buffer, 32-bit data format
+#endif
+  return b;
+}
+__device__ __forceinline__ u32x4 buf_ld16(const BufRes& b, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o >= b.nbytes) return u32x4{0u, 0u, 0u, 0u};
+  return *reinterpret_cast<const u32x4*>(b.base + o);
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0);
+#endif
+}
+__device__ __forceinline__ float buf_ld_f32(const BufRes& b, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o >= b.nbytes) return 0.f;
+  return *reinterpret_cast<const float*>(b.base + o);
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0));
+#endif
+}
+__device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o < b.nbytes) *reinterpret_cast<u32x2*>(const_cast<char*>(b.base) + o) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
+#endif
+}
+
 // LDS layouts: unpadded rows, the 16-byte segment index XOR-ed with a function of the row (see ssd_mfma.hip, class A):
 //   128-column tiles (256 B rows): seg ^ swzK(row);  64-column tiles (128 B rows): seg ^ swzU(row), swzU = swzK & 7.
 __device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
