@@ -113,6 +113,24 @@ def selscan_cfg1(dev):
         out[f"hip_B{rep * Bsz}"] = {"value": round(rep * Bsz * L * Dm / (ms * 1e-3) / 1e6, 1), "unit": "M-elements/s", "launch_ms": round(ms, 4),
                                     "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # forward + backward through autograd (the backward alone = the difference; its Python wrapper costs ~0.2 ms at B = 2)
+        leaves = [t.detach().clone().requires_grad_() for t in g]
+        go = torch.randn_like(got)
+
+        def fb():
+            for t in leaves:
+                t.grad = None
+            selective_scan_fn(*leaves, True).backward(go)
+        for _ in range(3):
+            fb()
+        torch.cuda.synchronize()
+        n = 20
+        e0.record()
+        for _ in range(n):
+            fb()
+        e1.record()
+        torch.cuda.synchronize()
+        out[f"hip_B{rep * Bsz}"]["fwd_bwd_ms"] = round(e0.elapsed_time(e1) / n, 4)
     return out
 
 

@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256, OCC) void ssd_mfma_a6_kernel(GScan a) {
 
 // Developer switch while the variant is being measured: OMK_SSD_V6=1 routes the plain class A launches here.
 static int ssd_v6_mode() {
-  static const int on = [] { const char* e = getenv("OMK_SSD_V6"); return e ? atoi(e) : 0; }();
-  return on;
+  const char* e = getenv("OMK_SSD_V6");
+  return e ? atoi(e) : 0;
 }
 bool ssd_v6_applies(const GScan& g) {
   if (!ssd_v6_mode()) return false;
