@@ -805,19 +805,37 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
 #pragma unroll
       for (int ut = 0; ut < 8; ut++) acc[ut] *= dts;
     }
-    if (hh == 1) {
+    // the two heads of the pair swap HALF of their tiles (head 0 hands over columns 64 .. 127, head 1 columns 0 .. 63) and each adds
+    // and stores the half it kept: the same LDS bytes as handing all eight tiles to head 0, but the adds, conversions and stores
+    // are spread over all eight waves instead of four
+    {
+      float* xo = &sm.O[((hh * 4 + w) * 4 * 64 + lane) * 4];
+      if (hh == 0) {   // (wave-uniform branches: no run-time register indexing)
 #pragma unroll
-      for (int ut = 0; ut < 8; ut++) *reinterpret_cast<f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]) = acc[ut];
+        for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(xo + q * 256) = acc[4 + q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(xo + q * 256) = acc[q];
+      }
     }
     block_sync();   // E: exchange buffer complete; nobody reads this chunk's tiles / scalars any more
-    if (hh == 0 && trow < a.L && !(ablb & 32)) {
+    if (trow < a.L && !(ablb & 32)) {
+      const float* xi = &sm.O[(((hh ^ 1) * 4 + w) * 4 * 64 + lane) * 4];
       uint16_t* prow = part + (int64_t)trow * 128 + 4 * g16;
+      if (hh == 0) {
 #pragma unroll
-      for (int ut = 0; ut < 8; ut++) {
-        const f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm.O[((w * 8 + ut) * 64 + lane) * 4]);
-        const f32x4 sv = acc[ut] + o1;
-        const u32x2 pv = {pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3])};
-        *reinterpret_cast<u32x2*>(prow + 16 * ut) = pv;
+        for (int q = 0; q < 4; q++) {
+          const f32x4 sv = acc[q] + *reinterpret_cast<const f32x4*>(xi + q * 256);
+          const u32x2 pv = {pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3])};
+          *reinterpret_cast<u32x2*>(prow + 16 * q) = pv;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f32x4 sv = acc[4 + q] + *reinterpret_cast<const f32x4*>(xi + q * 256);
+          const u32x2 pv = {pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3])};
+          *reinterpret_cast<u32x2*>(prow + 16 * (4 + q)) = pv;
+        }
       }
     }
     if (want_bnd && is_restart(nC - cnext) && !(ablb & 8)) load_ckpt(cnext);
