@@ -77,6 +77,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #endif
 }
 
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2c_f32_bf16 on gfx950)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+#ifdef OMK_EMU
+  return c + bf16_to_f32((uint16_t)(a & 0xffffu)) * bf16_to_f32((uint16_t)(b & 0xffffu)) + bf16_to_f32((uint16_t)(a >> 16)) * bf16_to_f32((uint16_t)(b >> 16));
+#else
+  typedef __bf16 dot_bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dot_bf16x2, a), __builtin_bit_cast(dot_bf16x2, b), c, false);
+#endif
+}
+
 // ---- wave-level primitives (wave = 64 lanes on CDNA) --------------------------------------------------
 #ifdef OMK_EMU
 __device__ __forceinline__ int lane_id() { return emu::lane_id(); }

@@ -656,14 +656,15 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
       // exact restart value of the decay-gradient prefix at the boundary behind chunk id = nC - 1 - c:
       //   dl(first token of chunk id + 1) = exp(a_first(id+1)) * < g_first(id+1) (= accS now), h_last(id) (= dC-scan
       //   checkpoint of chunk id) >;  bnd[id + 1] holds the inner product
-      float dot = 0.f;
+      // (g enters as the bf16 pairs the Q . S product of this chunk reads anyway: one v_dot2c_f32_bf16 per pair instead of two
+      // unpacks and two FMAs; two running sums break the dependency chain)
+      float dot = 0.f, dot1 = 0.f;
 #pragma unroll
-      for (int ut = 0; ut < 8; ut++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const uint32_t hv = ckv[ut >> 1][2 * (ut & 1) + j];
-          dot += accS[ut][2 * j] * bf_lo(hv) + accS[ut][2 * j + 1] * bf_hi(hv);
-        }
+      for (int ut = 0; ut < 8; ut++) {
+        dot = dot2_bf16(pack_bf16x2(accS[ut][0], accS[ut][1]), ckv[ut >> 1][2 * (ut & 1)], dot);
+        dot1 = dot2_bf16(pack_bf16x2(accS[ut][2], accS[ut][3]), ckv[ut >> 1][2 * (ut & 1) + 1], dot1);
+      }
+      dot += dot1;
       dot = wave_sum(dot);
       if (lane == 0) sm.bred[wave] = dot;
     }
@@ -709,8 +710,11 @@ __global__ __launch_bounds__(512) void ssd_mfma_b3_kernel(GScan a) {
             if (MODE == GS_DB && DMODE != 0 && (j == 0 ? diag0 : diag1)) {   // the diagonal tile holds K rows 16 w + t16: dD += dy . x
 #pragma unroll
               for (int e2 = 0; e2 < 4; e2++) {
-                dDp[DMODE == 2 ? kq : 0][DMODE == 2 ? 2 * e2 : 0] += bf_lo(fa[e2]) * bf_lo(qf[kq][e2]);
-                dDp[DMODE == 2 ? kq : 0][DMODE == 2 ? 2 * e2 + 1 : 0] += bf_hi(fa[e2]) * bf_hi(qf[kq][e2]);
+                if (DMODE == 1) dDp[0][0] = dot2_bf16(fa[e2], qf[kq][e2], dDp[0][0]);   // one D per head: both products in one v_dot2c
+                else {
+                  dDp[kq][2 * e2] += bf_lo(fa[e2]) * bf_lo(qf[kq][e2]);
+                  dDp[kq][2 * e2 + 1] += bf_hi(fa[e2]) * bf_hi(qf[kq][e2]);
+                }
               }
             }
           }
