@@ -341,7 +341,7 @@ def main():
     extra_s = None if (args.no_selscan_cfg1 or world > 1 or rank != 0) else selscan_cfg1(dev)
     extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
     torch.cuda.reset_peak_memory_stats()
-    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=2, warmup=1, batch=2, seqlen=8192, stage2=True)
+    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=2, warmup=2, batch=2, seqlen=8192, stage2=True)   # two warm-up steps: the caching allocator settles in the second
     if rank == 0:
         out["train_1p3b"] = extra_t
         out["train_1p3b_stage2"] = extra_t2

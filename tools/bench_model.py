@@ -57,14 +57,15 @@ def bench_train(args, dev, rank, world):
     net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
     step = Stage2Step(model, tc, ddp_model=net)
     batch = synthetic_batch(cfg, args.batch, L, dev, torch.bfloat16, rank=rank, tasks=tasks)
+    losses = []
     for _ in range(args.warmup):
-        step(batch)
+        losses.append(step(batch))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(batch)
+        losses.append(step(batch))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -78,7 +79,8 @@ def bench_train(args, dev, rank, world):
         print(json.dumps({"workload": f"OmniMamba-1.3B step (stage {args.stage}), tasks {tasks} x L={L}", "n_gpus": world,
                           "batch_per_gpu": args.batch, "ms_per_step": round(dt * 1e3, 2),
                           "tokens_per_s": round(world * len(tasks) * args.batch * L / dt, 1), "trainable_params": trainable,
-                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "dtype": "bf16 autocast"}), flush=True)
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "dtype": "bf16 autocast",
+                          "losses": [round(float(x["loss"] if isinstance(x, dict) else x), 4) for x in losses]}), flush=True)
 
 
 def main():
