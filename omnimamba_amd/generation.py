@@ -165,6 +165,8 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     batch_size, seqlen_og = input_ids.shape
     dev = input_embeddings.device
     graph = None
+    if hasattr(model, "prepare_decode"):
+        model.prepare_decode(task)      # per-token-id tables of the embedding MLPs, built outside any graph capture
     if device_loop and cg and top_k == 1 and eos_token_id is None and teacher_outputs is None and vocab_size is None and trace is None:
         return _decode_device_loop(input_ids, input_embeddings, model, max_length, task)
     if cg:

@@ -90,7 +90,27 @@ class ImageTokenEmbeddings(nn.Module):
         self.project_in = FusedMLPProjector(d_model, d_model, device=device, dtype=dtype)
         self.token_dropout = nn.Dropout(token_drop)
 
+    # ---- decode: the module is a function of the token id alone, so one pass over the whole codebook (16 384 rows) replaces the
+    # three GEMVs over 151 MB of weights that every generated token would otherwise stream (1.3B size).  Built outside any graph
+    # capture by `prepare_decode()` (generation.decode calls it), refreshed when a parameter's version changes.
+    def _table_key(self):
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters())
+
+    @torch.no_grad()
+    def prepare_decode(self):
+        if os.environ.get("OMK_IMG_EMBED_TABLE", "1") == "0":
+            self._omk_tab = self._omk_tab_key = None
+            return
+        key = self._table_key()
+        if getattr(self, "_omk_tab_key", None) != key:
+            ids = torch.arange(self.word_embeddings.num_embeddings, device=self.word_embeddings.weight.device)
+            self._omk_tab, self._omk_tab_key = self.project_in(self.word_embeddings(ids)), key
+
     def forward(self, input_ids, position_ids=None):
+        tab = getattr(self, "_omk_tab", None)
+        if (tab is not None and input_ids.shape[-1] == 1 and not self.training and not torch.is_grad_enabled()
+                and self._omk_tab_key == self._table_key()):
+            return F.embedding(input_ids, tab)
         return self.project_in(self.token_dropout(self.word_embeddings(input_ids)))
 
 
@@ -320,6 +340,12 @@ class OmniMambaLM(nn.Module):
 
     def get_input_embeddings(self):
         return self.backbone.embedding
+
+    def prepare_decode(self, task="t2i"):
+        """Called by generation.decode before the first step (and before any graph capture): per-token-id table of the image-token
+        embedding MLP for the T2I loop (its inputs are sampled VQ ids)."""
+        if task == "t2i" and self.cfg.t2i_task:
+            self.backbone.img_embeddings.prepare_decode()
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.backbone.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

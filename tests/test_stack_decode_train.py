@@ -210,3 +210,27 @@ def test_ddp_gloo_two_ranks_equals_single_process():
     assert sorted(ref) == sorted(n for n, p in model.named_parameters() if p.requires_grad)   # nothing trainable is left unused
     for n in ref:
         assert rel(torch.from_numpy(got[n]), ref[n]) < 1e-4, n
+
+
+def test_image_token_embedding_table_for_decode():
+    """The image-token embedding is a function of the token id: at decode (one id per sequence, eval, no grad) a per-id table built
+    by prepare_decode() replaces the MLP; it equals the MLP, is ignored once a parameter changed, and never enters a state dict."""
+    from omnimamba_amd.stack import ImageTokenEmbeddings
+    torch.manual_seed(0)
+    m = ImageTokenEmbeddings(32, 50).eval()
+    ids = torch.randint(0, 50, (3, 1))
+    with torch.no_grad():
+        ref = m(ids)
+        m.prepare_decode()
+        assert m._omk_tab.shape == (50, 32)
+        got = m(ids)
+        assert torch.allclose(got, ref, atol=1e-6) and got.shape == ref.shape
+        long_ids = torch.randint(0, 50, (2, 5))
+        assert torch.allclose(m(long_ids), m.project_in(m.word_embeddings(long_ids)))       # prefill: the MLP
+        m.project_in.projector[0].weight.mul_(2.0)                                          # stale table: the MLP again
+        assert torch.allclose(m(ids), m.project_in(m.word_embeddings(ids)))
+        m.prepare_decode()
+        assert torch.allclose(m(ids), m.project_in(m.word_embeddings(ids)), atol=1e-6)
+    assert all("_omk" not in k for k in m.state_dict())
+    m.train()
+    assert m(ids).requires_grad                                                             # training: never the table
