@@ -120,12 +120,18 @@ class _WGradFn(torch.autograd.Function):
 def frozen_cast(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """`weight.to(dtype)` kept on the parameter object while its version stands: under autocast an fp32 master was cast again on
     every call -- 20 us and 105 MB of traffic per in_proj call.  A frozen weight (every base projection in the 'align' stage) is
-    cast once; a training one once per optimizer step instead of once per task forward (the version counter moves with the step)."""
+    cast once; a training one once per optimizer step instead of once per task forward (the version counter moves with the step).
+    The key is (storage address, autograd version): every in-place update torch itself makes (optimizers, `copy_`,
+    `load_state_dict`) moves the version.  In-place writes through `weight.data` do NOT -- code that updates parameters that way
+    must run with OMK_CAST_CACHE=0 (which also makes `lora_ext` rebuild its extended weight on every call)."""
+    if os.environ.get("OMK_CAST_CACHE", "1") == "0":
+        return weight.detach().to(dtype)
     c = getattr(weight, "_omk_cast", None)
-    if c is not None and c[0] == weight._version and c[1].dtype == dtype and c[1].device == weight.device:
+    key = (weight.data_ptr(), weight._version)
+    if c is not None and c[0] == key and c[1].dtype == dtype and c[1].device == weight.device:
         return c[1]
     t = weight.detach().to(dtype)
-    weight._omk_cast = (weight._version, t)
+    weight._omk_cast = (key, t)
     return t
 
 

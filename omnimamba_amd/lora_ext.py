@@ -41,7 +41,7 @@ def extended_weight(module, weight: torch.Tensor, lora_b: torch.Tensor, adt: tor
         if buf is None or buf.shape != (out_f, in_f + PAD) or buf.device != weight.device or buf.dtype != adt:
             buf = torch.zeros(out_f, in_f + PAD, dtype=adt, device=weight.device)
             module._omk_we, module._omk_we_key = buf, None
-        if module._omk_we_key != key:
+        if module._omk_we_key != key or os.environ.get("OMK_CAST_CACHE", "1") == "0":
             buf[:, :in_f].copy_(weight)
             module._omk_we_key = key
         buf[:, in_f:in_f + lora_b.shape[1]].copy_(lora_b)
