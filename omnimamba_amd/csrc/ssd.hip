@@ -139,12 +139,28 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
       const int t = a.reverse ? nl - 1 - tt : tt;
       const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
       float acc = 0.f;
+      if (k0 + GEN_NPT <= a.DK && (a.DK & 3) == 0) {
+        // the thread's 16 consecutive k as four 16-byte LDS reads per operand (row offsets are multiples of 16 bytes here; the
+        // element-wise form below costs 32 ds_read_b32 per token and thread, and this loop is LDS-bound)
+        const f32x4* kq = reinterpret_cast<const f32x4*>(sK + t * a.DK + k0);
+        const f32x4* qq = reinterpret_cast<const f32x4*>(sQ + t * a.DK + k0);
 #pragma unroll
-      for (int j = 0; j < GEN_NPT; j++) {
-        const int k = k0 + j;
-        if (k < a.DK) {
-          s[j] = s[j] * dec + wu * sK[t * a.DK + k];
-          acc += s[j] * sQ[t * a.DK + k];
+        for (int v = 0; v < GEN_NPT / 4; v++) {
+          const f32x4 kv = kq[v], qv = qq[v];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            s[4 * v + e] = s[4 * v + e] * dec + wu * kv[e];
+            acc += s[4 * v + e] * qv[e];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GEN_NPT; j++) {
+          const int k = k0 + j;
+          if (k < a.DK) {
+            s[j] = s[j] * dec + wu * sK[t * a.DK + k];
+            acc += s[j] * sQ[t * a.DK + k];
+          }
         }
       }
       for (int m = TK >> 1; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
