@@ -248,16 +248,19 @@ typedef struct {
 int omk_lora_add(const OmkLoraAdd* p, omk_stream stream);
 
 /* ---- backward of the rank-r up-projection, both products in ONE pass over dy --------------------------------------------
- * dh (T, r) += dy (T, N) lora_b (N, r)   and   dlora_b (N, r) += dy^T h (T, r)   (reference lora.py:263-279, backward of
+ * dh (T, r) = dy (T, N) lora_b (N, r)   and   dlora_b (N, r) = dy^T h (T, r)   (reference lora.py:263-279, backward of
  * lora_B(.)).  As two library GEMMs each reads the (tokens, 8512) gradient once (279 MB at 16 k tokens: 69 + 59 us).
- * bf16 dy / h, rank <= 8, 16-byte aligned rows; f32 outputs are ACCUMULATED into (atomics: the caller zeroes them).          */
+ * bf16 dy / h, rank 8, 16-byte aligned rows.  The kernel leaves PARTIAL sums -- dh per 256-column block of dy, dlora_b per token
+ * chunk -- that the caller adds up (two small reductions: deterministic, no atomics); omk_lora_up_bwd_parts gives the counts.   */
 typedef struct {
   OmkTensor dy;       /* (T, N) bf16 */
   OmkTensor lora_b;   /* (N, r) f32 / bf16 / f16 */
   OmkTensor h;        /* (T, r) bf16 */
-  OmkTensor dh;       /* out (T, r) f32, dense, accumulated */
-  OmkTensor dlora_b;  /* out (N, r) f32, dense, accumulated */
+  OmkTensor dh;       /* out (column_blocks, T, r) f32, dense: every element is written */
+  OmkTensor dlora_b;  /* out (token_chunks, N, r) f32, dense: every element is written */
 } OmkLoraUpBwd;
+/* column_blocks -> parts[0], token_chunks -> parts[1] for a (T, N) gradient */
+int omk_lora_up_bwd_parts(int64_t T, int64_t N, int32_t* parts);
 int omk_lora_up_bwd(const OmkLoraUpBwd* p, omk_stream stream);
 
 /* ---- Mamba-2 SSD chunked scan ----------------------------------------------------------------------------

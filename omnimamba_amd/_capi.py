@@ -95,7 +95,7 @@ SYMBOLS = [
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
     "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
-    "omk_cross_entropy",
+    "omk_cross_entropy", "omk_lora_up_bwd_parts",
 ]
 
 
@@ -111,6 +111,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
         if s.endswith("_workspace_bytes"):
             fn.restype = C.c_size_t
             fn.argtypes = [C.c_void_p]
+        elif s == "omk_lora_up_bwd_parts":
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
         elif s not in ("omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof"):
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_void_p]

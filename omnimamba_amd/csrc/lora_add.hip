@@ -69,12 +69,14 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
 // Backward of the up-projection: dh += dy B and dB += dy^T h from ONE read of dy.
 // Workgroup = 256 columns of dy x a chunk of tokens, walked in tiles of 64 tokens through LDS (rows padded by 16 bytes).
 //   dh   wave w, rows 16 w ..: D[token][r] = sum_n dy[token][n] B[n][r]: A = row reads of the tile, B = lora_b fragments kept in
-//        registers for the whole workgroup (its columns are fixed) -> fp32 atomics (one partial per column block and token)
+//        registers for the whole workgroup (its columns are fixed) -> one partial row per column block and token
 //   dB   wave w, columns 64 w ..: D[n][r] = sum_token dy[token][n] h[token][r]: A = the tile read TRANSPOSED (ds_read_b64_tr_b16),
-//        B = h^T from LDS; four 16 x 16 accumulators live across all tiles -> fp32 atomics once per workgroup
+//        B = h^T from LDS; four 16 x 16 accumulators live across all tiles -> one partial (N, r) slab per token chunk
+// The partials are plain stores (every workgroup owns its slots) and the caller adds them up: deterministic, and cheaper than the
+// 4.5 M fp32 atomics of the first version (16 of its 89 us).
 // Both MFMAs are 16x16x32 with the rank in the N dimension (8 of 16 columns used): the kernel is a pure stream over dy.
-// 16 k tokens x 8512: 89 us against 112 - 128 us for the two library GEMMs; the load / stage / barrier skeleton alone is 68 us
-// (4.1 TB/s), the 4.5 M fp32 atomics of dh 16 us (~300 G atomics/s), both MFMA parts together 3 us (OMK_LORA_UP_DBG).
+// 16 k tokens x 8512: 84 us (+ 9 us for the two reductions of the partials) against 112 - 128 us for the two library GEMMs; the
+// load / stage / barrier skeleton alone is 68 us (4.1 TB/s), both MFMA parts together 3 us (OMK_LORA_UP_DBG).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LU_TT = 64, LU_TN = 256, LU_LD = LU_TN + 8;
 struct LoraUpBwdArgs {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void lora_up_bwd_kernel(LoraUpBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int t = t0 + 16 * w + 4 * g16 + i;
-        if (t < te && !(a.dbg & 1)) atomic_add_f32(a.dh + (int64_t)t * a.R + t16, acch[i]);
+        if (t < te && !(a.dbg & 1)) a.dh[((int64_t)nb * a.T + t) * a.R + t16] = acch[i];
       }
     }
     // ---- dB: columns 64 w .. 64 w + 63, contraction over the 64 tokens of the tile
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void lora_up_bwd_kernel(LoraUpBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int n = n0 + 64 * w + 16 * ct + 4 * g16 + i;
-        if (n < a.N) atomic_add_f32(a.dB + (int64_t)n * a.R + t16, accB[ct][i]);
+        if (n < a.N) a.dB[((int64_t)tc * a.N + n) * a.R + t16] = accB[ct][i];
       }
   }
 }
@@ -209,29 +211,43 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
 }
 
 
+static void lora_up_plan(int64_t T, int64_t N, int* NB, int* tchunk, int* chunks) {
+  *NB = (int)((N + LU_TN - 1) / LU_TN);
+  // token chunks: enough workgroups for two to three per CU, at least four tiles each
+  int c = (768 + *NB - 1) / *NB;
+  const int max_chunks = (int)((T + 4 * LU_TT - 1) / (4 * LU_TT));
+  if (c > max_chunks) c = max_chunks;
+  if (c < 1) c = 1;
+  *tchunk = (int)(((T + c - 1) / c + LU_TT - 1) / LU_TT * LU_TT);
+  *chunks = (int)((T + *tchunk - 1) / *tchunk);
+}
+
+extern "C" int omk_lora_up_bwd_parts(int64_t T, int64_t N, int32_t* parts) {
+  OMK_REQUIRE(parts && T >= 0 && N >= 0, "lora_up_bwd_parts: bad arguments");
+  int NB = 0, tchunk = 0, chunks = 0;
+  if (T > 0 && N > 0) lora_up_plan(T, N, &NB, &tchunk, &chunks);
+  parts[0] = NB; parts[1] = chunks;
+  return OMK_OK;
+}
+
 extern "C" int omk_lora_up_bwd(const OmkLoraUpBwd* p, omk_stream stream) {
   OMK_REQUIRE(p && present(p->dy) && present(p->lora_b) && present(p->h) && present(p->dh) && present(p->dlora_b), "lora_up_bwd: dy, lora_b, h, dh, dlora_b required");
-  OMK_REQUIRE(p->dy.ndim == 2 && p->lora_b.ndim == 2 && p->h.ndim == 2 && p->dh.ndim == 2 && p->dlora_b.ndim == 2, "lora_up_bwd: 2-d tensors");
+  OMK_REQUIRE(p->dy.ndim == 2 && p->lora_b.ndim == 2 && p->h.ndim == 2 && p->dh.ndim == 3 && p->dlora_b.ndim == 3, "lora_up_bwd: dy, lora_b, h 2-d; dh, dlora_b 3-d partials");
   LoraUpBwdArgs a = {};
   a.T = (int)p->dy.shape[0]; a.N = (int)p->dy.shape[1]; a.R = (int)p->lora_b.shape[1];
-  OMK_REQUIRE(p->lora_b.shape[0] == a.N && p->h.shape[0] == a.T && p->h.shape[1] == a.R && p->dh.shape[0] == a.T && p->dh.shape[1] == a.R &&
-              p->dlora_b.shape[0] == a.N && p->dlora_b.shape[1] == a.R, "lora_up_bwd: shape mismatch");
-  OMK_REQUIRE(p->dh.dtype == OMK_F32 && p->dlora_b.dtype == OMK_F32 && is_dense(p->dh) && is_dense(p->dlora_b), "lora_up_bwd: dh, dlora_b must be dense f32");
   if (a.T == 0 || a.N == 0) return OMK_OK;
+  int chunks = 0;
+  lora_up_plan(a.T, a.N, &a.NB, &a.tchunk, &chunks);
+  OMK_REQUIRE(p->lora_b.shape[0] == a.N && p->h.shape[0] == a.T && p->h.shape[1] == a.R, "lora_up_bwd: shape mismatch");
+  OMK_REQUIRE(p->dh.shape[0] == a.NB && p->dh.shape[1] == a.T && p->dh.shape[2] == a.R && p->dlora_b.shape[0] == chunks && p->dlora_b.shape[1] == a.N &&
+              p->dlora_b.shape[2] == a.R, "lora_up_bwd: dh must be (column_blocks, T, r), dlora_b (token_chunks, N, r) -- see omk_lora_up_bwd_parts");
+  OMK_REQUIRE(p->dh.dtype == OMK_F32 && p->dlora_b.dtype == OMK_F32 && is_dense(p->dh) && is_dense(p->dlora_b), "lora_up_bwd: dh, dlora_b must be dense f32");
   if (p->dy.dtype != OMK_BF16 || p->h.dtype != OMK_BF16 || a.R != 8 || a.N % 8 != 0 || p->dy.stride[1] != 1 || p->h.stride[1] != 1 ||
       p->lora_b.stride[1] != 1 || !aligned16(p->dy) || !aligned16(p->h) || (p->dy.stride[0] * 2) % 16 != 0 || (p->h.stride[0] * 2) % 16 != 0)
     return fail(OMK_EUNSUPPORTED, "lora_up_bwd: bf16 dy / h with 16-byte aligned rows, rank 8, out_features a multiple of 8 (use two GEMMs otherwise)");
   a.dy = (const uint16_t*)p->dy.data; a.dys = p->dy.stride[0]; a.B = p->lora_b.data; a.bs = p->lora_b.stride[0]; a.bdt = p->lora_b.dtype;
   a.h = (const uint16_t*)p->h.data; a.hs = p->h.stride[0]; a.dh = (float*)p->dh.data; a.dB = (float*)p->dlora_b.data;
-  a.NB = (a.N + LU_TN - 1) / LU_TN;
   if (const char* e = getenv("OMK_LORA_UP_DBG")) a.dbg = atoi(e);
-  // token chunks: enough workgroups for two per CU, at least four tiles each
-  int chunks = (768 + a.NB - 1) / a.NB;
-  const int max_chunks = (a.T + 4 * LU_TT - 1) / (4 * LU_TT);
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
-  a.tchunk = ((a.T + chunks - 1) / chunks + LU_TT - 1) / LU_TT * LU_TT;
-  chunks = (a.T + a.tchunk - 1) / a.tchunk;
   dim3 grid((unsigned)((int64_t)a.NB * chunks)), block(256);
   OMK_LAUNCH(lora_up_bwd_kernel, grid, block, 0, stream, a);
   return finish_launch("lora_up_bwd");

@@ -91,11 +91,16 @@ def up_bwd_applies(dy2d: torch.Tensor, h2d: torch.Tensor, lora_b: torch.Tensor) 
 
 
 def lora_up_bwd(dy2d, h2d, lora_b):
-    """(dy2d @ lora_b, dy2d^T @ h2d) as fp32 (tokens, r) and (out, r) from ONE pass over dy2d (omk_lora_up_bwd).  No autograd."""
+    """(dy2d @ lora_b, dy2d^T @ h2d) as fp32 (tokens, r) and (out, r) from ONE pass over dy2d (omk_lora_up_bwd leaves per-column-
+    block / per-token-chunk partial sums, added up here: deterministic).  No autograd."""
+    import ctypes as C
     lib = get_lib()
     require_device(lib, dy2d, h2d, lora_b)
     T, N, r = dy2d.shape[0], dy2d.shape[1], h2d.shape[1]
-    acc = torch.zeros((T + N) * r, dtype=torch.float32, device=dy2d.device)
-    dh, db = acc[:T * r].view(T, r), acc[T * r:].view(N, r)
-    K.run(lib, "omk_lora_up_bwd", K.LoraUpBwd(dy=K.T(dy2d), lora_b=K.T(lora_b), h=K.T(h2d), dh=K.T(dh), dlora_b=K.T(db)), dy2d)
-    return dh, db
+    parts = (C.c_int32 * 2)()
+    K.check(lib, lib.omk_lora_up_bwd_parts(T, N, parts), "omk_lora_up_bwd_parts")
+    nb, nc = int(parts[0]), int(parts[1])
+    buf = torch.empty((nb * T + nc * N) * r, dtype=torch.float32, device=dy2d.device)
+    dh_p, db_p = buf[:nb * T * r].view(nb, T, r), buf[nb * T * r:].view(nc, N, r)
+    K.run(lib, "omk_lora_up_bwd", K.LoraUpBwd(dy=K.T(dy2d), lora_b=K.T(lora_b), h=K.T(h2d), dh=K.T(dh_p), dlora_b=K.T(db_p)), dy2d)
+    return dh_p.sum(0), db_p.sum(0)
