@@ -15,24 +15,42 @@ constexpr int NORM_THREADS = 256;
 constexpr int NORM_WAVES = NORM_THREADS / 64;
 constexpr int NORM_MAX_BLOCKS = 1024;
 
-template <int WPR> __device__ __forceinline__ float row_sum(float v, float* red, int wave) {
-  v = wave_sum(v);
-  if constexpr (WPR == 1) {
-    return v;
-  } else {
+// Row totals over the WPR waves of a row.  The exchange array is double buffered by the parity of the reduction count, so ONE
+// barrier per reduction is enough: a thread reaches the write of reduction k + 2 (same parity as k) only after the barrier of
+// k + 1, which every thread passes after its reads of k.  (Round 1: two barriers per reduction -- four per row in the gated
+// backward, whose two sums are one exchange now.)
+typedef float NormRed[NORM_WAVES][2];
+template <int WPR> __device__ __forceinline__ void row_sum2(float& v0, float& v1, NormRed* red, int wave, int& par) {
+  v0 = wave_sum(v0);
+  v1 = wave_sum(v1);
+  if constexpr (WPR != 1) {
+    static_assert(WPR == NORM_WAVES, "a row is one wave or the whole block");
+    if ((threadIdx.x & 63) == 0) { red[par][wave][0] = v0; red[par][wave][1] = v1; }
     block_sync();
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    block_sync();
-    return red[0] + red[1] + red[2] + red[3];
+    v0 = red[par][0][0] + red[par][1][0] + red[par][2][0] + red[par][3][0];
+    v1 = red[par][0][1] + red[par][1][1] + red[par][2][1] + red[par][3][1];
+    par ^= 1;
   }
+}
+template <int WPR> __device__ __forceinline__ float row_sum(float v, NormRed* red, int wave, int& par) {
+  v = wave_sum(v);
+  if constexpr (WPR != 1) {
+    static_assert(WPR == NORM_WAVES, "a row is one wave or the whole block");
+    if ((threadIdx.x & 63) == 0) red[par][wave][0] = v;
+    block_sync();
+    v = red[par][0][0] + red[par][1][0] + red[par][2][0] + red[par][3][0];
+    par ^= 1;
+  }
+  return v;
 }
 // element chunk c of this lane covers columns NORM_COL(c) .. + VEC of its row
 #define NORM_ROWMAP()                                                         \
-  __shared__ float red[NORM_WAVES];                                           \
+  __shared__ NormRed red[2];                                                  \
+  int rpar = 0;                                                               \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                 \
   constexpr int RPB = NORM_WAVES / WPR; /* rows per block */                  \
   const int wsub = wave % WPR, wrow = wave / WPR;                             \
-  (void)red
+  (void)red; (void)rpar
 #define NORM_COL(c) ((((c) * WPR + wsub) * 64 + lane) * VEC)
 
 template <class T, int VEC>
@@ -103,9 +121,9 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) 
     }
     float mu = 0.f, var;
     if (a.rms) {
-      var = row_sum<WPR>(s2, red, wave) * inv_n;
+      var = row_sum<WPR>(s2, red, wave, rpar) * inv_n;
     } else {
-      mu = row_sum<WPR>(s1, red, wave) * inv_n;
+      mu = row_sum<WPR>(s1, red, wave, rpar) * inv_n;
       float d2 = 0.f;
 #pragma unroll
       for (int c = 0; c < NCHUNK; c++) {
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) 
           for (int i = 0; i < VEC; i++) { float d = v[c][i] - mu; d2 += d * d; }
         }
       }
-      var = row_sum<WPR>(d2, red, wave) * inv_n;
+      var = row_sum<WPR>(d2, red, wave, rpar) * inv_n;
     }
     const float rstd = rsqrtf(var + a.eps);
     if (lane == 0 && wsub == 0 && rlive) {
@@ -188,8 +206,8 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_bwd_kernel(NormBwdArgs 
         for (int i = 0; i < VEC; i++) { xh[c][i] = 0.f; wdy[c][i] = 0.f; }
       }
     }
-    c1 = row_sum<WPR>(c1, red, wave) * inv_n;
-    c2 = a.rms ? 0.f : row_sum<WPR>(c2, red, wave) * inv_n;
+    c1 = row_sum<WPR>(c1, red, wave, rpar) * inv_n;
+    c2 = a.rms ? 0.f : row_sum<WPR>(c2, red, wave, rpar) * inv_n;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
       const int col = NORM_COL(c);
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
         for (int i = 0; i < VEC; i++) { v[c][i] = 0.f; sz[c][i] = 0.f; }
       }
     }
-    const float rstd = rsqrtf(row_sum<WPR>(s2, red, wave) * inv_n + a.eps);
+    const float rstd = rsqrtf(row_sum<WPR>(s2, red, wave, rpar) * inv_n + a.eps);
     if (lane == 0 && wsub == 0 && a.rstd && rlive) a.rstd[row * a.ngroups + grp] = rstd;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
@@ -347,7 +365,8 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
     const int64_t row = rlive ? rraw : a.rows - 1;
     // gv: the normalised quantity (x or x*silu(z)); zv: z, later (norm_before_gate) the finished dz; wdy: dy then w*dy'
     float xv[NCHUNK][VEC], zv[NCHUNK][VEC], gv[NCHUNK][VEC], wdy[NCHUNK][VEC];
-    float s2 = 0.f;
+    // both row sums in ONE exchange: sum g^2 (-> rstd) and sum g w dy' -- the second is c1 / rstd, it does not need rstd itself
+    float s2 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
       const int col = NORM_COL(c);
@@ -360,14 +379,17 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
           if (!z) zv[c][i] = 0.f;
           gv[c][i] = (z && !a.norm_before_gate) ? xv[c][i] * silu_fast(zv[c][i]) : xv[c][i];
           s2 += gv[c][i] * gv[c][i];
+          const float dyn = (z && a.norm_before_gate) ? wdy[c][i] * silu_fast(zv[c][i]) : wdy[c][i];   // what the norm sees
+          t2 += gv[c][i] * dyn * wreg[c][i];
         }
       } else {
 #pragma unroll
         for (int i = 0; i < VEC; i++) { xv[c][i] = 0.f; zv[c][i] = 0.f; gv[c][i] = 0.f; wdy[c][i] = 0.f; }
       }
     }
-    const float rstd = rsqrtf(row_sum<WPR>(s2, red, wave) * inv_n + a.eps);
-    float c1 = 0.f;
+    row_sum2<WPR>(s2, t2, red, wave, rpar);
+    const float rstd = rsqrtf(s2 * inv_n + a.eps);
+    const float c1 = rstd * t2 * inv_n;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
       const int col = NORM_COL(c);
@@ -385,12 +407,10 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
           }
           dwacc[c][i] += dyv * xhat;
           wdy[c][i] = dyv * w;
-          c1 += xhat * wdy[c][i];
           gv[c][i] = xhat;
         }
       }
     }
-    c1 = row_sum<WPR>(c1, red, wave) * inv_n;
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
       const int col = NORM_COL(c);
