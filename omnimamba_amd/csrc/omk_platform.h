@@ -101,6 +101,7 @@ template <class T> __device__ __forceinline__ T shfl_down(T v, int d) {
   return emu::shfl_generic(v, l + d < 64 ? l + d : l);
 }
 __device__ __forceinline__ void block_sync() { emu::block_barrier(); }
+__device__ __forceinline__ bool ballot_any(bool pred) { return emu::ballot(pred ? 1 : 0) != 0; }   // true in every lane when any lane's pred is
 __device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
   emu::Wave& w = emu::cur_wave();
   int l = emu::lane_id();
@@ -141,6 +142,7 @@ template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return __
 template <class T> __device__ __forceinline__ T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
 template <class T> __device__ __forceinline__ T shfl_down(T v, int d) { return __shfl_down(v, d, 64); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
+__device__ __forceinline__ bool ballot_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }   // wave-uniform
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);

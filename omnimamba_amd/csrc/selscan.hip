@@ -890,9 +890,17 @@ __global__ __launch_bounds__(1024) void selscan_bwd_chunked_kernel(SsBwdArgs q) 
         }
         if (nb0 + NB >= a.N) {
           // ---- per-token outputs of this channel: every state index is in
-          float u[LC], dr[LC];
-          ssc_load_row<T, LC>(urow, t0, a.L, u);     // second read of the pass: L1 / L2
-          ssc_load_row<T, LC>(drow, t0, a.L, dr);
+          // u and softplus'(raw delta) from what is still in registers instead of second reads of their rows (the counters show those
+          // coming from HBM, + 0.4 GB at batch 64): u = (delta u) / delta, sigmoid(raw) = 1 - exp(-softplus(raw)).  Only a token
+          // whose delta underflowed to exactly 0 has lost its u: then (rare, wave-uniform branch) the row is read again.
+          float u[LC];
+          bool lost = false;
+#pragma unroll
+          for (int i = 0; i < LC; i++) {
+            u[i] = dl[i] != 0.f ? dlu[i] * rcp_fast(dl[i]) : 0.f;       // (tokens past the end: delta = 0, u = 0)
+            lost = lost || (dl[i] == 0.f && t0 + i < a.L);
+          }
+          if (__builtin_expect(ballot_any(lost), 0)) ssc_load_row<T, LC>(urow, t0, a.L, u);
           if (zrow) {
             float zv[LC], go[LC];
             ssc_load_row<T, LC>(grow, t0, a.L, go);
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(1024) void selscan_bwd_chunked_kernel(SsBwdArgs q) 
           for (int i = 0; i < LC; i++) {
             dDl = fmaf(dy[i], u[i], dDl);
             ddl[i] = fmaf(gB[i], u[i], ddl[i]);
-            if (a.softplus) ddl[i] *= rcp_fast(1.f + exp2_fast(-(dr[i] + db) * LOG2E));
+            if (a.softplus) ddl[i] *= dl[i] < 1e-3f ? dl[i] * (1.f - 0.5f * dl[i]) : 1.f - exp2_fast(-dl[i] * LOG2E);   // sigmoid(raw) = 1 - exp(-softplus(raw))
             if (t0 + i >= a.L) ddl[i] = 0.f;
             ddbl += ddl[i];
             gB[i] = fmaf(gB[i], dl[i], Dv * dy[i]);   // du

@@ -109,3 +109,27 @@ def test_selective_scan_bwd_channel_tiles(dev, monkeypatch):
     O.selective_scan_ref(*dl, True, compute_dtype=torch.float64).backward(g.double())
     for a, b, c in zip(grads["1"], grads["2"], dl):
         assert rel(a, c.grad) < 2e-4 and rel(b, c.grad) < 2e-4 and rel(a, b) < 1e-5
+
+
+def test_selective_scan_bwd_delta_underflow(dev):
+    """Chunked backward: a token whose softplus(delta) underflows to exactly 0 has lost u = (delta u) / delta in registers -- the
+    kernel then reads the row again.  Gradients of such a batch against the fp64 oracle (ddelta there is gB u sigmoid(raw) ~ 0,
+    du = D dy)."""
+    from omnimamba_amd.selective_scan import selective_scan_fn
+    torch.manual_seed(5)
+    Bsz, Dm, L, N = 1, 8, 128, 8
+    u, z = torch.randn(Bsz, Dm, L), torch.randn(Bsz, Dm, L)
+    delta = torch.randn(Bsz, Dm, L) * 0.5
+    delta[:, :, 10:14] = -200.0                      # softplus -> 0 exactly in fp32
+    A, Bm, Cm = -(torch.rand(Dm, N) + 0.1), torch.randn(Bsz, N, L), torch.randn(Bsz, N, L)
+    D = torch.randn(Dm)
+    src = [u, delta, A, Bm, Cm, D, z, None]
+    leaves = [None if t is None else t.clone().to(dev).requires_grad_() for t in src]
+    g = torch.randn(Bsz, Dm, L)
+    selective_scan_fn(*leaves, True).backward(g.to(dev))
+    dl = [None if t is None else t.double().clone().requires_grad_() for t in src]
+    O.selective_scan_ref(*dl, True, compute_dtype=torch.float64).backward(g.double())
+    for name, a, b in zip(["u", "delta", "A", "B", "C", "D", "z"], leaves, dl):
+        if a is not None:
+            assert torch.isfinite(a.grad).all(), name
+            assert rel(a.grad, b.grad) < 2e-4, (name, rel(a.grad, b.grad))
