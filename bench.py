@@ -290,7 +290,7 @@ def main():
     rounds = 1
     if args.min_seconds > 0:
         probe = timed(args.steps)              # untimed for the result: sizes the timed region (same on every rank: MAX-reduced)
-        rounds = max(1, math.ceil(args.min_seconds / probe))
+        rounds = max(1, math.ceil(1.08 * args.min_seconds / probe))   # 8 % margin: the probe runs slower than the steady state
     nsteps = args.steps * rounds
     _prof.ENABLED = True
     _prof.reset()
