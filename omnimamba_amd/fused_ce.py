@@ -54,6 +54,8 @@ class _FusedLinearCE(torch.autograd.Function):
         h = hidden2d.to(adt)
         h = h if h.is_contiguous() else h.contiguous()
         w = weight.to(adt)
+        if labels1d.dtype != torch.int64:
+            raise TypeError(f"fused_linear_cross_entropy: labels must be int64 (the kernel reads 8-byte ids), got {labels1d.dtype}")
         labels1d = labels1d.contiguous()
         T, V = h.shape[0], w.shape[0]
         counted = (labels1d != IGNORE_ID).sum().to(torch.float32)
@@ -84,7 +86,10 @@ class _FusedLinearCE(torch.autograd.Function):
 
 
 def fused_linear_cross_entropy(hidden2d, weight, labels1d):
-    """mean over labels != -100 of CE(hidden2d @ weight^T, labels1d) without materialising the (tokens, vocab) logits."""
+    """mean over labels != -100 of CE(hidden2d @ weight^T, labels1d) without materialising the (tokens, vocab) logits.
+    Edge behaviour that differs from torch.nn.CrossEntropyLoss: when EVERY label is -100 the result is 0 (torch: NaN); labels
+    outside [0, V) other than -100 contribute zero loss and gradient but are counted in the mean (torch raises) -- callers
+    validate their label range (the reference only ever produces ids < V and -100, omnimamba.py:190-218)."""
     return _FusedLinearCE.apply(hidden2d, weight, labels1d)
 
 

@@ -127,7 +127,10 @@ def frozen_cast(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if os.environ.get("OMK_CAST_CACHE", "1") == "0":
         return weight.detach().to(dtype)
     c = getattr(weight, "_omk_cast", None)
-    key = (weight.data_ptr(), weight._version)
+    try:
+        key = (weight.data_ptr(), weight._version)
+    except RuntimeError:   # inference tensors (a model built under torch.inference_mode) carry no version counter: no cache
+        return weight.detach().to(dtype)
     if c is not None and c[0] == key and c[1].dtype == dtype and c[1].device == weight.device:
         return c[1]
     t = weight.detach().to(dtype)

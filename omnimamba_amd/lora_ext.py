@@ -35,13 +35,16 @@ def applies(x2d: torch.Tensor, weight: torch.Tensor, rank: int, adt: torch.dtype
 def extended_weight(module, weight: torch.Tensor, lora_b: torch.Tensor, adt: torch.dtype) -> torch.Tensor:
     """[W | B | 0] as (out, in + PAD) in `adt`, cached on `module` (not a registered buffer: it never enters a state_dict)."""
     out_f, in_f = weight.shape
-    key = (weight.data_ptr(), weight._version, weight.device, adt)
+    try:
+        key = (weight.data_ptr(), weight._version, weight.device, adt)
+    except RuntimeError:   # inference tensors have no version counter: rebuild every call
+        key = None
     buf = getattr(module, "_omk_we", None)
     with torch.no_grad():
         if buf is None or buf.shape != (out_f, in_f + PAD) or buf.device != weight.device or buf.dtype != adt:
             buf = torch.zeros(out_f, in_f + PAD, dtype=adt, device=weight.device)
             module._omk_we, module._omk_we_key = buf, None
-        if module._omk_we_key != key or os.environ.get("OMK_CAST_CACHE", "1") == "0":
+        if key is None or module._omk_we_key != key or os.environ.get("OMK_CAST_CACHE", "1") == "0":
             buf[:, :in_f].copy_(weight)
             module._omk_we_key = key
         buf[:, in_f:in_f + lora_b.shape[1]].copy_(lora_b)

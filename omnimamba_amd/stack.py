@@ -104,7 +104,15 @@ class ImageTokenEmbeddings(nn.Module):
         key = self._table_key()
         if getattr(self, "_omk_tab_key", None) != key:
             ids = torch.arange(self.word_embeddings.num_embeddings, device=self.word_embeddings.weight.device)
-            self._omk_tab, self._omk_tab_key = self.project_in(self.word_embeddings(ids)), key
+            new = self.project_in(self.word_embeddings(ids))
+            tab = getattr(self, "_omk_tab", None)
+            # refresh IN PLACE: a captured decode graph (kept in model._decoding_cache across calls) has this tensor's address baked
+            # into its F.embedding node; only a shape / dtype / device change reallocates (and such a change invalidates the graph too)
+            if tab is not None and tab.shape == new.shape and tab.dtype == new.dtype and tab.device == new.device:
+                tab.copy_(new)
+            else:
+                self._omk_tab = new
+            self._omk_tab_key = key
 
     def forward(self, input_ids, position_ids=None):
         tab = getattr(self, "_omk_tab", None)
@@ -165,7 +173,9 @@ class TaskLoRALinear(nn.Linear):
         adt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         x2 = x.reshape(-1, x.shape[-1])
         if self.bias is None and os.environ.get("OMK_LORA_EXT", "1") != "0" and LE.applies(x2, self.weight, self.r, adt):
-            p_drop = self.lora_dropout.p if (self.training and isinstance(self.lora_dropout, nn.Dropout)) else 0.0
+            # the dropout module's own mode decides (stage 'align' leaves in_proj in eval() and re-enables train() on the
+            # modules named *lora*, reference omnimamba.py:137-151; lora.py:270-274 calls self.lora_dropout(x) unconditionally)
+            p_drop = self.lora_dropout.p if (isinstance(self.lora_dropout, nn.Dropout) and self.lora_dropout.training) else 0.0
             y = LE.lora_ext_linear(self, x2, self.weight.detach(), A.weight, B.weight, self.scaling, adt, p_drop)
             if torch.is_grad_enabled() and self.weight.requires_grad:
                 y = _WGradFn.apply(y, x2.detach(), self.weight, None)   # the base weight trains ('finetune'): its gradient node

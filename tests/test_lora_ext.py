@@ -94,3 +94,30 @@ def test_lora_ext_dropout_backward_uses_the_mask():
     assert rel(y.reshape(-1, 96), ref) < 4e-3
     assert rel(x.grad.reshape(-1, 64), x64.grad) < 6e-3
     assert rel(m.mmu_lora_A0.weight.grad, A.grad) < 1.5e-2 and rel(m.mmu_lora_B0.weight.grad, B.grad) < 1.5e-2
+
+
+def test_align_stage_applies_lora_dropout_on_both_paths(monkeypatch):
+    """Stage 'align' leaves the in_proj module in eval() and re-enables train() only on the modules named *lora*
+    (reference omnimamba.py:137-151), so the dropout module's own mode -- not in_proj.training -- must decide: the reference
+    (lora.py:270-274) calls self.lora_dropout(x) unconditionally.  Both the one-GEMM path and the streaming path drop."""
+    torch.manual_seed(0)
+    m = TaskLoRALinear(64, 96, r=8, lora_dropout=0.5, dtype=torch.bfloat16)
+    torch.nn.init.normal_(m.mmu_lora_B0.weight, std=0.05)
+    m.task_types = "mmu"
+    m.eval()
+    for n, sub in m.named_modules():
+        if "lora" in n.lower():
+            sub.train()
+    assert not m.training and m.lora_dropout.training
+    x = torch.randn(1, 600, 64, dtype=torch.bfloat16)
+    for ext in ("1", "0"):
+        monkeypatch.setenv("OMK_LORA_EXT", ext)
+        torch.manual_seed(5)
+        a = m(x)
+        torch.manual_seed(6)
+        b = m(x)
+        assert rel(a, b) > 1e-3, f"OMK_LORA_EXT={ext}: two different dropout masks must give different outputs"
+    m.lora_dropout.eval()
+    for ext in ("1", "0"):
+        monkeypatch.setenv("OMK_LORA_EXT", ext)
+        assert rel(m(x), m(x)) == 0.0
