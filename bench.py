@@ -22,6 +22,8 @@ actually timed, `steps_requested` is K.
                             every parameter trains (5.9 GB of fp32 gradients all-reduced per step when N > 1)
   selscan_cfg1              BASELINE configs[0]: Mamba-1 selective_scan at B2 L1024 D768 N16 fp32 -- HIP kernel next
                             to the CPU selective_scan_ref restatement on the host cores
+  scan_target               the north-star target shape: the scan alone at L = 8192, d_model 2048, B = 8 and B = 1
+  decode_1p3b               BASELINE configs[2]: 1.3B T2I greedy decode, 72-token prompt + 256 tokens: time to first token, ms/token
 """
 import argparse
 import json
@@ -134,7 +136,7 @@ def selscan_cfg1(dev):
     return out
 
 
-def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048, stage2=False):
+def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage2=False):
     """BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU pretrain step on synthetic image features + text ids, L = 2048:
     images_feat (B, 729, 2176) -> projector, text ids of length L - 733, labels = ids; stage 'align' with only the MMU
     task configured (projector + MMU LoRA adapters train); bf16 autocast, AdamW, clip 1.0.
@@ -157,9 +159,13 @@ def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048, stage2
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # per-step HIP events on the current stream (rank 0's own steps; the headline figure is the barrier-bracketed wall time)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         step(data)
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -169,9 +175,11 @@ def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048, stage2
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     loss = sum(float(step.last[t]) for t in tasks)
     assert math.isfinite(loss)
     out = {"tokens_per_s": round(world * len(tasks) * batch * seqlen * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+           "ms_per_step_min": round(per[0], 2), "ms_per_step_median": round(per[len(per) // 2], 2), "ms_per_step_max": round(per[-1], 2),
            "warmup": warmup, "loss": round(loss, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
            "config": {"workload": "OmniMamba-1.3B stage-2 unified fine-tune step, T2I + MMU (BASELINE.json configs[4])" if stage2 else
                                   "OmniMamba-1.3B stage-1 MMU pretrain step (BASELINE.json configs[3])", "n_layer": cfg.n_layer,
@@ -180,6 +188,76 @@ def train_1p3b(dev, rank, world, steps=4, warmup=2, batch=8, seqlen=2048, stage2
                       "params": sum(p.numel() for p in model.parameters()), "dtype": "bf16 autocast, fp32 masters",
                       "parallelism": f"dp{world}" if world > 1 else "single"}}
     del step, net, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def scan_target(dev):
+    """The north-star target shape: the Mamba-2 chunked scan (omk_ssd_scan_fwd through mamba_chunk_scan_combined) at L = 8192,
+    d_model 2048 (H 64, P 64, N 128, one group), bf16, B = 8 and B = 1; HIP events on the launch stream, algorithmic bytes of
+    SURVEY.md section 8d (17 024 B per token)."""
+    from omnimamba_amd.ssd_combined import mamba_chunk_scan_combined
+    out = {}
+    L = 8192
+    for Bsz in (8, 1):
+        torch.manual_seed(0)
+        x = torch.randn(Bsz, L, H, HEADDIM, device=dev, dtype=torch.bfloat16)
+        dt = (torch.randn(Bsz, L, H, device=dev) * 0.5).bfloat16()
+        A = -(torch.rand(H, device=dev) * 15 + 1)
+        Bm, Cm = (torch.randn(Bsz, L, 1, D_STATE, device=dev, dtype=torch.bfloat16) for _ in range(2))
+        D, dtb = torch.ones(H, device=dev), torch.randn(H, device=dev) * 0.5 - 2
+        run = lambda: mamba_chunk_scan_combined(x, dt, A, Bm, Cm, 256, D=D, dt_bias=dtb, dt_softplus=True)
+        with torch.no_grad():
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 40
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        nb = Bsz * L * SCAN_FWD_BYTES_PER_TOK
+        out[f"B{Bsz}_L{L}"] = {"launch_ms": round(ms, 4), "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
+                               "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "M_elements_per_s": round(Bsz * L * D_SCAN / (ms * 1e-3) / 1e6, 1)}
+    return out
+
+
+def decode_1p3b(dev):
+    """BASELINE configs[2]: OmniMamba-1.3B T2I autoregressive decode -- 72-token prompt, 256 greedy image tokens, batch 1, fp32
+    weights (the reference's inference default, scripts/inference_t2i.py:21-26), hipGraph replay of the single-token step.
+    time_to_first_token = prefill of the prompt + the first sampled id (one host sync); ms_per_token = the 256-token loop."""
+    from omnimamba_amd.generation import decode
+    from omnimamba_amd.stack import OmniMambaLM, StackConfig
+    torch.manual_seed(0)
+    cfg = StackConfig.omnimamba_1_3b()
+    model = OmniMambaLM(cfg, device=dev, dtype=torch.float32).eval()
+    P, new = 72, 256
+    ids = torch.zeros(1, P, dtype=torch.long, device=dev)
+    emb = torch.randn(1, P, cfg.d_model, device=dev) * 0.02 + model.backbone.pos_embed[:, :P]
+    decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=True)            # warm-up: captures the graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    decode(ids, emb, model, P + 1, top_k=1, task="t2i", cg=True)
+    torch.cuda.synchronize()
+    ttft = time.perf_counter() - t0
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        seq = decode(ids, emb, model, P + new, top_k=1, task="t2i", cg=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert seq.shape == (1, P + new)
+    n_param = sum(p.numel() for p in model.parameters())
+    ms_tok = (best - ttft) / (new - 1) * 1e3
+    out = {"workload": "OmniMamba-1.3B T2I greedy decode (BASELINE.json configs[2])", "batch": 1, "prompt": P, "new_tokens": new,
+           "time_to_first_token_ms": round(ttft * 1e3, 3), "ms_per_token": round(ms_tok, 4), "tokens_per_s": round(1e3 / ms_tok, 1),
+           "total_ms": round(best * 1e3, 2), "weights_GBs": round(n_param * 4 / (ms_tok * 1e-3) / 1e9, 1),
+           "frac_of_hbm_peak": round(n_param * 4 / (ms_tok * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "params": n_param, "dtype": "f32"}
+    del model
     torch.cuda.empty_cache()
     return out
 
@@ -204,6 +282,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-1p3b", action="store_true")
     ap.add_argument("--no-selscan-cfg1", action="store_true")
+    ap.add_argument("--no-scan-target", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the CPU launch test passes gloo)")
     ap.add_argument("--dry-launch", action="store_true", help="only initialise the process group and report ranks (CPU test of the launch path)")
     args = ap.parse_args()
@@ -339,13 +419,17 @@ def main():
     del model, block, u, dy
     torch.cuda.empty_cache()
     extra_s = None if (args.no_selscan_cfg1 or world > 1 or rank != 0) else selscan_cfg1(dev)
+    extra_tg = None if (args.no_scan_target or world > 1 or rank != 0) else scan_target(dev)
+    extra_d = None if (args.no_decode or world > 1 or rank != 0) else decode_1p3b(dev)
     extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
     torch.cuda.reset_peak_memory_stats()
-    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=2, warmup=2, batch=2, seqlen=8192, stage2=True)   # two warm-up steps: the caching allocator settles in the second
+    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=5, warmup=2, batch=2, seqlen=8192, stage2=True)   # two warm-up steps: the caching allocator settles in the second
     if rank == 0:
         out["train_1p3b"] = extra_t
         out["train_1p3b_stage2"] = extra_t2
         out["selscan_cfg1"] = extra_s
+        out["scan_target"] = extra_tg
+        out["decode_1p3b"] = extra_d
         out["cpu_baseline"] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -17,12 +17,16 @@
 // dB, U shared by the group and 128 wide).  Earlier designs of this round (two heads per workgroup with G and O through
 // LDS; 32x32 output tiles; strips split into intra / state waves) were measured slower and live in the git history --
 // DESIGN.md section 4 has the numbers.
+#include <cstdlib>
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
 
 namespace omk {
 
 constexpr int QC = 64;     // chunk length (tokens)
+#ifndef OMK_SSD_KHILO_DEFAULT
+#define OMK_SSD_KHILO_DEFAULT 0   // decided by measurement (profiles/r03_khilo.txt); OMK_SSD_KHILO=0/1 overrides at run time
+#endif
 #ifndef OMK_SSD_BWD_HILO
 #define OMK_SSD_BWD_HILO 0   // 1: the dx scan also splits M into bf16 hi + lo (the forward and the dB / dC scans always do)
 #endif
@@ -77,7 +81,10 @@ static_assert(sizeof(SmemA3) <= 80 * 1024, "two workgroups must fit the 160 KB o
 // nseg workgroups per head) starts every segment from the fold of the earlier segments' states.
 // DFOLD (forward, one D per head): D x_l rides on the diagonal of M (M_ll += D, kept to 16 bits by the hi + lo split)
 // instead of an epilogue that re-reads x and D from LDS.
-template <int MODE, bool EXTRAS, bool STATE, bool DFOLD = false>
+// KHILO (forward, OMK_SSD_KHILO): the w_l K_l operand of the state update enters as a bf16 hi + lo pair (8 more 32x32x16 MFMAs per
+// wave and chunk, no LDS): the carried state -- and with it final_states -- is then exact to fp32 accumulation instead of carrying
+// one bf16 rounding per chunk (1.7e-3 -> 1e-5 on the final state; y of slow-decay heads 1.4e-3 -> 1.0e-3).
+template <int MODE, bool EXTRAS, bool STATE, bool DFOLD = false, bool KHILO = false>
 __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA3& sm = *reinterpret_cast<SmemA3*>(smem_raw);
@@ -351,13 +358,14 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
         const int lb = 16 * ls + 8 * h32;
         const f32x4 s0v = *reinterpret_cast<const f32x4*>(&sm.ws[cur][lb]);
         const f32x4 s1v = *reinterpret_cast<const f32x4*>(&sm.ws[cur][lb + 4]);
-        u32x4 kp;
+        u32x4 kp, kl = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) {
           const f32x2 kv = {bf16_to_f32((uint16_t)fk[2 * e2]), bf16_to_f32((uint16_t)fk[2 * e2 + 1])};
           const f32x2 sv = e2 < 2 ? f32x2{s0v[2 * e2], s0v[2 * e2 + 1]} : f32x2{s1v[2 * e2 - 4], s1v[2 * e2 - 3]};
           const f32x2 pr = kv * sv;
           kp[e2] = pack_bf16x2(pr[0], pr[1]);
+          if (KHILO) kl[e2] = pack_bf16x2(pr[0] - bf_lo(kp[e2]), pr[1] - bf_hi(kp[e2]));
         }
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
             fu[0] = u0[0]; fu[1] = u0[1]; fu[2] = u0[2]; fu[3] = u0[3]; fu[4] = u1[0]; fu[5] = u1[1]; fu[6] = u1[2]; fu[7] = u1[3];
           }
           accS[ut] = mfma32x32x16_bf16(as_s16x8(kp), fu, accS[ut]);
+          if (KHILO) accS[ut] = mfma32x32x16_bf16(as_s16x8(kl), fu, accS[ut]);
         }
       }
     }
@@ -948,10 +957,6 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
 }
 
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
-  if (ssd_v5a_applies(g)) {
-    if (seg_fmt) *seg_fmt = 1;
-    return ssd_v5a_prepare_segments(g, stream);
-  }
   if (seg_fmt) *seg_fmt = 0;
   GScan a = g;
   const SegPlan sp = ssd_segments(a.B * a.H, a.L);
@@ -983,16 +988,18 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   }
   if (dry) return OMK_OK;
   if (ssd_v6_applies(g)) return ssd_v6_launch(g, stream);
-  if (ssd_v5a_applies(g) && (!g.seg_ready || g.seg_fmt == 1)) return ssd_v5a_launch(g, stream);
   // one head (x one segment of the sequence) per workgroup, two workgroups per CU
   GScan a = g;
   const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
   a.nseg = sp.nseg; a.cps = sp.cps;
   dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
   const size_t smem = sizeof(SmemA3);
+#define OMK_A3K(MODE_, EX_, ST_, DF_, KH_, GRID_) do { \
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), GRID_, block, smem, stream, a); } while (0)
+  static const bool khilo = [] { const char* e = getenv("OMK_SSD_KHILO"); return e ? e[0] == '1' : OMK_SSD_KHILO_DEFAULT != 0; }();
 #define OMK_A3(MODE_, EX_, ST_, DF_, GRID_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_>), GRID_, block, smem, stream, a); } while (0)
+    if (MODE_ == GS_Y && khilo) OMK_A3K(MODE_, EX_, ST_, DF_, (MODE_ == GS_Y), GRID_); else OMK_A3K(MODE_, EX_, ST_, DF_, false, GRID_); } while (0)
   if (a.nseg > 1 && !a.seg_ready) {
     int rc = ssd_mfma_prepare_segments(g, stream);
     if (rc) return rc;
@@ -1002,6 +1009,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   else if (a.mode == GS_Y) { if (dfold) OMK_A3(GS_Y, false, false, true, grid); else OMK_A3(GS_Y, false, false, false, grid); }
   else OMK_A3(GS_DX, false, false, false, grid);
 #undef OMK_A3
+#undef OMK_A3K
   return OMK_OK;
 }
 

@@ -50,7 +50,7 @@ struct GScan {
   // order) and its total log2 decay in seg[BH * nseg * SEG_STATE + bh * nseg + s]; the scan proper folds them.
   float* seg; int nseg, cps;
   int seg_ready;                                                 // seg already holds the folded START states (slot j - 1 = segment j)
-  int seg_fmt;                                                   // element order of seg: 0 = ssd_mfma_a3 accumulator order, 1 = logical [u][k] of the class A state (ssd_v5)
+  int seg_fmt;                                                   // element order of seg: 0 = ssd_mfma_a3 accumulator order, 1 = logical [u][k] of the class A state
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
@@ -94,13 +94,9 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 
 // split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the
 // state at the START of segment j (initial state included).  Shared by the scans whose state this is (y and dC; dx and dB).
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = nullptr);   // *seg_fmt: the order it left the states in
-// three workgroups per CU (ssd_v6.hip, round 2)
+// the hi + lo ("precise") forward scan (ssd_v6.hip): OMK_SSD_PRECISE=1
 bool ssd_v6_applies(const GScan& g);
 int ssd_v6_launch(const GScan& g, omk_stream stream);
-// the two-waves-per-head kernels of round 2 (ssd_v5.hip)
-bool ssd_v5a_applies(const GScan& g);
-int ssd_v5a_launch(const GScan& g, omk_stream stream);
-int ssd_v5a_prepare_segments(const GScan& g, omk_stream stream);
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
 }  // namespace omk

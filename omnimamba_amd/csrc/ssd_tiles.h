@@ -1,4 +1,4 @@
-// ssd_tiles.h -- LDS tile helpers shared by the MFMA scan kernels (ssd_mfma.hip, ssd_v5.hip): 16-byte accessors and the
+// ssd_tiles.h -- LDS tile helpers shared by the MFMA scan kernels (ssd_mfma.hip, ssd_v6.hip, ssd_cp.hip): 16-byte accessors and the
 // XOR swizzles that keep every access pattern of those kernels bank-conflict free on gfx950.
 #pragma once
 #include "omk_common.h"

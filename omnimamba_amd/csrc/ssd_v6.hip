@@ -1,24 +1,19 @@
-// ssd_v6.hip -- the row-strip scan of ssd_mfma.hip (class A: y and dx) re-ordered so that THREE workgroups fit a CU.
+// ssd_v6.hip -- the PRECISE forward scan: the row-strip kernel of ssd_mfma.hip (class A, y) with the two bf16 roundings that set
+// its error floor -- the copy of the carried state that feeds Q . S_in and the w_l K_l operand of the state update -- entering the
+// MFMAs as hi + lo pairs (OMK_SSD_PRECISE=1).
 //
-// The round-1 kernel (ssd_mfma_a3_kernel) sits at two workgroups per CU: 67 KB of LDS (K and U tiles double buffered) and
-// 242 VGPRs.  Its counters (profiles/r01_pmc_ssd_fwd_v5.txt) show the SIMDs issuing 57 % of the cycles with 43 % of the wave
-// cycles in s_waitcnt -- the two co-resident workgroups wait at the same time too often.  This variant buys the third one:
-//   * K is SINGLE buffered (51 KB of LDS): the next chunk's K tile is committed after the barrier that ends the state update,
-//     and the Q . S_in product of the NEXT chunk runs between that barrier and the second one -- still two barriers per chunk:
-//         intra(c) -> store O(c) -> [loads of chunk c + 1] -> state update(c) -> publish S -> barrier A
-//                  -> commit K(c + 1) -> acc = Q(c + 1) . S -> barrier B
-//   * the staging loads are issued AFTER the intra phase (its register peak), the budget is 168 VGPRs (launch bounds 256 x 3).
-// Same arithmetic, same lane layouts, same LDS swizzles as the a3 kernel; no segment / state-only / gate variants (those stay on a3).
+// The second 16 KB state tile needs LDS the default kernel does not have at two workgroups per CU, so this variant keeps K SINGLE
+// buffered: the next chunk's K tile is committed after the barrier that ends the state update and the Q . S_in product of the NEXT
+// chunk runs between that barrier and the second one (still two barriers per chunk):
+//     intra(c) -> store O(c) -> state update(c) -> publish S -> barrier A -> commit K(c + 1) -> acc = Q(c + 1) . S -> barrier B
+// Same lane layouts and LDS swizzles as ssd_mfma_a3_kernel; no segment / state-only / gate variants (those stay on a3).
 //
-// MEASURED NEGATIVE (profiles/r02_scan_v6_variants.txt, B 8 x L 4096, scan + dt preparation as tools/bench_scan.py times it):
-//   a3 (two per CU, double-buffered K)                          269 - 273 us
-//   this order, two per CU, loads before the intra phase        281 us     (OMK_SSD_V6=4)
-//   this order, two per CU, loads after the intra phase         291 us     (OMK_SSD_V6=2)
-//   this order, THREE per CU, loads after the intra phase       311 us     (OMK_SSD_V6=1; kernel alone 297 vs 240 us)
-//   three per CU with early loads (35 spilled registers)        397 us     (OMK_SSD_V6=3)
-// The third workgroup makes the CU SLOWER: what two co-resident workgroups leave idle is not there to be filled by a third --
-// the issue slots, LDS and MFMA pipes the three share (and the clock, which already drops from 2.35 to 2.03 GHz with two) are the
-// limit, not exposed latency.  Kept as an opt-in variant (OMK_SSD_V6) so that the measurement can be repeated; a3 stays the path.
+// Round 2 measured this loop order WITHOUT the hi + lo operands as a way to three workgroups per CU: slower in every variant
+// (281 - 397 us against 269 - 273 us, profiles/r02_scan_v6_variants.txt) -- what two co-resident workgroups leave idle is not
+// there to be filled by a third.  Those variants were removed in round 3; the numbers stay in profiles/ and DESIGN.md section 4.7.
+// Cost of PRECISE: + 27 % scan time (272 -> 345 us, profiles/r02_scan_precise.txt); arithmetic error of y at the production shape
+// 1.3e-3 -> 3e-6 on slow-decay heads, final state < 1e-3.  The default path rounds exactly where upstream's kernels round
+// (tests/test_ops_ssd.py::test_default_forward_is_no_worse_than_upstream_rounding).
 #include <cstdlib>
 
 #include "ssd_scan.h"
@@ -36,8 +31,6 @@ struct SmemA6 {
   float Dv[64];
   uint16_t Slo[64 * 128];    // PRECISE only: S_in - bf16(S_in).  LAST member: the other variants are launched without it (51 KB)
 };
-constexpr size_t SMEM_A6_PLAIN = sizeof(SmemA6) - sizeof(uint16_t) * 64 * 128;
-static_assert(SMEM_A6_PLAIN <= 53 * 1024, "three workgroups must fit the 160 KB of a CU");
 static_assert(sizeof(SmemA6) <= 80 * 1024, "PRECISE: two workgroups must fit the 160 KB of a CU");
 
 // PRECISE (forward only): the two bf16 roundings that set the error floor of the scan -- the copy of the carried state that feeds
@@ -350,21 +343,14 @@ __global__ __launch_bounds__(256, OCC) void ssd_mfma_a6_kernel(GScan a) {
   }
 }
 
-// Developer switch while the variant is being measured: OMK_SSD_V6=1 routes the plain class A launches here.
-static int ssd_v6_mode() {
-  const char* e = getenv("OMK_SSD_V6");
-  return e ? atoi(e) : 0;
-}
 static bool ssd_precise() {
   const char* e = getenv("OMK_SSD_PRECISE");
   return e && e[0] == '1';
 }
 bool ssd_v6_applies(const GScan& g) {
-  if (!ssd_v6_mode() && !(ssd_precise() && g.mode == GS_Y)) return false;
-  if (g.mode != GS_Y && g.mode != GS_DX) return false;
+  if (!(ssd_precise() && g.mode == GS_Y)) return false;
   if (g.Z.p || g.outx || g.prof) return false;                   // gate / pre-gate copy stay on a3
   if (g.seg && ssd_segments(g.B * g.H, g.L).nseg > 1) return false;   // so do split sequences
-  if (g.mode == GS_DX && g.dD) return false;
   return true;
 }
 
@@ -372,25 +358,12 @@ int ssd_v6_launch(const GScan& g, omk_stream stream) {
   GScan a = g;
   a.nseg = 1; a.cps = (a.L + QC6 - 1) / QC6;
   dim3 grid((unsigned)(a.B * a.H)), block(256);
-  size_t smem = SMEM_A6_PLAIN;
-#define OMK_A6_(MODE_, DF_, OCC_, EARLY_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a6_kernel<MODE_, DF_, OCC_, EARLY_>), smem)) return fail(OMK_ELAUNCH, "ssd_v6: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_mfma_a6_kernel<MODE_, DF_, OCC_, EARLY_>), grid, block, smem, stream, a); } while (0)
-  const int var = ssd_v6_mode();   // 1: 3 per CU, late loads; 2: 2 per CU, late; 3: 3 per CU, early; 4: 2 per CU, early
-#define OMK_A6(MODE_, DF_) do { if (var == 2) OMK_A6_(MODE_, DF_, 2, false); else if (var == 3) OMK_A6_(MODE_, DF_, 3, true); \
-    else if (var == 4) OMK_A6_(MODE_, DF_, 2, true); else OMK_A6_(MODE_, DF_, 3, false); } while (0)
-  const bool dfold = !a.D || a.Dsp == 0;
-  if (a.mode == GS_Y && ssd_precise()) {
-    smem = sizeof(SmemA6);
+  const size_t smem = sizeof(SmemA6);
 #define OMK_A6P(DF_) do { \
-      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a6_kernel<GS_Y, DF_, 2, true, true>), smem)) return fail(OMK_ELAUNCH, "ssd_v6: cannot raise dynamic LDS to %zu", smem); \
-      OMK_LAUNCH((ssd_mfma_a6_kernel<GS_Y, DF_, 2, true, true>), grid, block, smem, stream, a); } while (0)
-    if (dfold) OMK_A6P(true); else OMK_A6P(false);
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a6_kernel<GS_Y, DF_, 2, true, true>), smem)) return fail(OMK_ELAUNCH, "ssd_v6: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_mfma_a6_kernel<GS_Y, DF_, 2, true, true>), grid, block, smem, stream, a); } while (0)
+  if (!a.D || a.Dsp == 0) OMK_A6P(true); else OMK_A6P(false);
 #undef OMK_A6P
-  } else if (a.mode == GS_Y) { if (dfold) OMK_A6(GS_Y, true); else OMK_A6(GS_Y, false); }
-  else OMK_A6(GS_DX, false);
-#undef OMK_A6
-#undef OMK_A6_
   return OMK_OK;
 }
 

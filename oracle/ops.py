@@ -193,15 +193,26 @@ def ssd_ref_sequential(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_sta
 
 def ssd_ref_chunked(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, initial_states=None,
                     dt_softplus=False, dt_limit=(0.0, float("inf")), return_final_states=False,
-                    compute_dtype=torch.float32):
+                    compute_dtype=torch.float32, emulate_upstream_rounding=False, round_output=True):
     """Chunked (SSD) form of the same recurrence -- the fast CPU baseline.
 
     Per chunk (local l, a_l = dt'_l A, cs_l = sum_{j<=l} a_j):
       y_l   = exp(cs_l) C_l.s_in + sum_{s<=l} (C_l.B_s) exp(cs_l - cs_s) dt'_s x_s + D x_l
       s_out = exp(cs_Q-1) s_in + sum_l exp(cs_Q-1 - cs_l) dt'_l x_l (x) B_l
     Tail positions (>= L) contribute dt' = 0.
+
+    emulate_upstream_rounding: with 16-bit activations the published mamba_ssm==2.2.2 pipeline
+    ([UPSTREAM-RECALLED], absent from /root/reference) rounds three MFMA / tl.dot operands to the activation dtype:
+      (i)   the decayed, dt-scaled, masked C.B^T tile ("cb.to(x dtype)" in _chunk_scan_fwd) before it multiplies x,
+      (ii)  the scaled B rows exp(cs_end - cs_l) dt'_l B_l ("b.to(x dtype)" in _chunk_state_fwd) before the chunk-state product,
+      (iii) the chunk-START states handed to the scan (_state_passing_fwd(..., out_dtype=C.dtype)) before C . s_in;
+    the carried state itself, all accumulations and the decay factors stay fp32.  The flag reproduces exactly these three
+    roundings (activation dtype = x.dtype) on top of `compute_dtype` arithmetic; False = no intermediate rounding.
+    round_output=False returns y in compute_dtype (the arithmetic result before the final cast to x.dtype).
     """
     cd = compute_dtype
+    adt = x.dtype
+    rnd = (lambda t: t.to(adt).to(cd)) if (emulate_upstream_rounding and adt in (torch.bfloat16, torch.float16)) else (lambda t: t)
     Bsz, L, H, P = x.shape
     G, N = B.shape[2], B.shape[3]
     Q = chunk_size
@@ -224,16 +235,16 @@ def ssd_ref_chunked(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, in
     seg = cs.permute(0, 1, 3, 2)[..., :, None] - cs.permute(0, 1, 3, 2)[..., None, :]   # cs_l - cs_s
     mask = torch.tril(torch.ones(Q, Q, dtype=torch.bool))
     decay = torch.where(mask, torch.exp(torch.where(mask, seg, torch.zeros_like(seg))), torch.zeros_like(seg))
-    M = CB * decay * dtf.permute(0, 1, 3, 2)[..., None, :]
+    M = rnd(CB * decay * dtf.permute(0, 1, 3, 2)[..., None, :])                       # (i)
     y = torch.einsum("bchls,bcshp->bclhp", M, xf)
     # chunk states
     w = torch.exp(cs[:, :, -1:, :] - cs) * dtf                                 # (B,nC,Q,H)
     Bh = Bf.repeat_interleave(rep, dim=3)
     Ch = Cf.repeat_interleave(rep, dim=3)
-    S_loc = torch.einsum("bclh,bclhp,bclhn->bchpn", w, xf, Bh)
+    S_loc = torch.einsum("bclhp,bclhn->bchpn", xf, rnd(w[..., None] * Bh))            # (ii)
     s = torch.zeros(Bsz, H, P, N, dtype=cd) if initial_states is None else initial_states.to(cd).clone()
     for c in range(nC):
-        y[:, c] = y[:, c] + torch.exp(cs[:, c])[..., None] * torch.einsum("blhn,bhpn->blhp", Ch[:, c], s)
+        y[:, c] = y[:, c] + torch.exp(cs[:, c])[..., None] * torch.einsum("blhn,bhpn->blhp", Ch[:, c], rnd(s))   # (iii)
         s = torch.exp(cs[:, c, -1])[..., None, None] * s + S_loc[:, c]
     y = y.reshape(Bsz, nC * Q, H, P)[:, :L]
     xo = x.to(cd)
@@ -242,7 +253,8 @@ def ssd_ref_chunked(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, in
         y = y + xo * (Df[None, None, :, None] if Df.dim() == 1 else Df[None, None])
     if z is not None:
         y = y * _silu(z.to(cd))
-    y = y.to(x.dtype)
+    if round_output:
+        y = y.to(x.dtype)
     return (y, s) if return_final_states else y
 
 

@@ -187,56 +187,6 @@ def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
             assert e < tol[n], (n, e)
 
 
-@pytest.mark.parametrize("L,minc", [(200, None), (330, 2)])
-def test_ssd_v5_two_waves_per_head_kernel(dev, monkeypatch, L, minc):
-    """ssd_v5.hip (two independent waves per head, 32x32x16 MFMAs, state never in LDS): selectable with OMK_SSD_V5=1, measured
-    slower than the default strips on the MI355X; kept correct: forward (D per head and per column, z gate, initial and final
-    state, split sequence) and the dx scan of the backward against the oracle."""
-    monkeypatch.setenv("OMK_SSD_V5", "1")
-    if minc:
-        monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
-    import omnimamba_amd.ssd_combined as S
-    H, P, N, G = 4, 64, 128, 2
-    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=11)
-    for Dv in (D, torch.randn(H, P)):
-        y, yx, fin = S.ssd_scan_fwd(x.to(dev), dt.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), D=Dv.to(dev), z=z.to(dev), dt_bias=dtb.to(dev),
-                                    initial_states=init.to(dev), dt_softplus=True, return_final_states=True, want_out_x=True)
-        y0, f0 = O.ssd_ref_chunked(x.float(), dt.float(), A, Bm.float(), Cm.float(), 64, D=Dv, z=z.float(), dt_bias=dtb, initial_states=init,
-                                   dt_softplus=True, return_final_states=True)
-        assert rel(y, y0) < 2.5e-3 and rel(fin, f0) < 2.5e-3
-    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
-    yy = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6], dt_softplus=True)
-    gy = torch.randn(yy.shape).bfloat16()
-    yy.backward(gy.to(dev))
-    ref = [t.double().clone().requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
-    O.ssd_ref_sequential(ref[0], ref[1], ref[2], ref[3], ref[4], D=ref[5], dt_bias=ref[6], dt_softplus=True, compute_dtype=torch.float64).backward(gy.double())
-    assert rel(leaves[0].grad, ref[0].grad) < 5e-3 and rel(leaves[3].grad, ref[3].grad) < 5e-3 and rel(leaves[4].grad, ref[4].grad) < 5e-3
-
-
-@pytest.mark.parametrize("variant", ["1", "4"])
-def test_ssd_v6_three_workgroups_per_cu_kernel(dev, monkeypatch, variant):
-    """ssd_v6.hip (the row-strip scan with K single buffered and Q . S between the two barriers: three workgroups per CU;
-    OMK_SSD_V6=1..4 selects occupancy / load placement), measured slower than the default on the MI355X; kept correct: forward
-    with D per head and per column, initial and final state, ragged last chunk, and the dx scan against the oracle."""
-    monkeypatch.setenv("OMK_SSD_V6", variant)
-    import omnimamba_amd.ssd_combined as S
-    H, P, N, G = 4, 64, 128, 2
-    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, 200, H, P, N, G, torch.bfloat16, seed=12)
-    for Dv in (D, torch.randn(H, P)):
-        y, yx, fin = S.ssd_scan_fwd(x.to(dev), dt.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), D=Dv.to(dev), dt_bias=dtb.to(dev),
-                                    initial_states=init.to(dev), dt_softplus=True, return_final_states=True)
-        y0, f0 = O.ssd_ref_chunked(x.float(), dt.float(), A, Bm.float(), Cm.float(), 64, D=Dv, dt_bias=dtb, initial_states=init,
-                                   dt_softplus=True, return_final_states=True)
-        assert rel(y, y0) < 2.5e-3 and rel(fin, f0) < 2.5e-3
-    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
-    yy = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6], dt_softplus=True)
-    gy = torch.randn(yy.shape).bfloat16()
-    yy.backward(gy.to(dev))
-    ref = [t.double().clone().requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb)]
-    O.ssd_ref_sequential(ref[0], ref[1], ref[2], ref[3], ref[4], D=ref[5], dt_bias=ref[6], dt_softplus=True, compute_dtype=torch.float64).backward(gy.double())
-    assert rel(leaves[0].grad, ref[0].grad) < 5e-3
-
-
 @pytest.mark.parametrize("L,H,G", [(200, 2, 1), (330, 4, 2)])
 def test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states(dev, monkeypatch, L, H, G):
     """OMK_SSD_PRECISE=1 (ssd_v6.hip, PRECISE): the bf16 copy of the carried state and the w_l K_l operand of the state update

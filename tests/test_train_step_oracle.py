@@ -1,0 +1,145 @@
+"""the Stage-2 training step (reference /root/reference/trainer.py:113-127: loss = t2i loss + mmu loss
+from two forwards, ONE backward) against a step composed from the CPU oracle.
+
+  * `Stage2Step` on a 2-layer stack, both tasks, every parameter training (stage 'finetune'), non-zero LoRA B matrices: the
+    total loss and EVERY parameter gradient == autograd of an independent composition of oracle.add_norm_ref +
+    oracle.mamba2_forward_ref (LoRA merged into the in_proj weight: W + scaling * B A, reference lora.py:263-279) + torch
+    embeddings / MLPs / cross-entropy on the materialised logits.  Runs on the emulated kernels here and on the MI355X (-m gpu).
+  * -m gpu only: torch.distributed with backend "nccl" (= RCCL) at world size 1 -- init_process_group, wrap_ddp (bucketed
+    all-reduce with gradient_as_bucket_view), one step of the same toy model: gradients == the unwrapped step.
+"""
+import copy
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle as O
+from test_stack_decode_train import TINY_SPECIAL, rel, tiny_cfg
+
+
+def _model(dev, stage="finetune"):
+    from omnimamba_amd.omni import OmniMambaPath
+    torch.manual_seed(0)
+    m = OmniMambaPath(tiny_cfg(), stage=stage, special_ids=TINY_SPECIAL)
+    with torch.no_grad():     # adapters must contribute: B is zero-initialised by the reference (lora.py:217-225)
+        for n, p in m.named_parameters():
+            if "lora_B0" in n:
+                p.normal_(std=0.05)
+    return m.to(dev)
+
+
+def _batch(cfg, dev):
+    from omnimamba_amd.train import synthetic_batch
+    return synthetic_batch(cfg, 2, 20, dev, torch.float32, rank=0, caption_len=7)
+
+
+def _oracle_loss(P, cfg, batch, task):
+    """The same step from the oracle: P maps parameter names (OmniMambaPath.named_parameters, tied heads share their table) to
+    fp32 CPU leaves."""
+    pre = "llm_backbone.mamba."
+    bb = pre + "backbone."
+
+    def mlp3(x, base):     # FusedMLPProjector: Linear -> GELU -> Linear -> GELU -> Linear
+        h = F.gelu(F.linear(x, P[base + "0.weight"], P[base + "0.bias"]))
+        h = F.gelu(F.linear(h, P[base + "2.weight"], P[base + "2.bias"]))
+        return F.linear(h, P[base + "4.weight"], P[base + "4.bias"])
+
+    emb_tab = P[bb + "embedding.weight"]
+    ign = lambda n, b: torch.full((b, n), -100, dtype=torch.long)
+    if task == "t2i":
+        f = batch["t2i_flow"]
+        img_ids, cap = f["inputs"].cpu(), f["caption_ids"].cpu()
+        img = mlp3(F.embedding(img_ids, P[bb + "img_embeddings.word_embeddings.weight"]), bb + "img_embeddings.project_in.projector.")
+        txt = F.embedding(cap, emb_tab)
+        txt = F.linear(F.gelu(F.linear(txt, P[bb + "caption_embed.cap_proj.fc1.weight"]), approximate="tanh"), P[bb + "caption_embed.cap_proj.fc2.weight"])
+        emb = torch.cat((txt[:, :-1], img, txt[:, -1:]), 1)
+        emb = emb + P[bb + "pos_embed"][:, : emb.shape[1]]
+        labels = torch.cat([ign(cap.shape[1] - 1, cap.shape[0]), img_ids, ign(1, cap.shape[0])], 1)
+        head = P[bb + "img_embeddings.word_embeddings.weight"]
+    else:
+        f = batch["mmu_flow"]
+        ids0 = f["input_ids"].cpu()
+        sp = lambda k: torch.full((ids0.shape[0], 1), TINY_SPECIAL[k], dtype=torch.long)
+        ids = torch.cat([sp("<|mmu|>"), sp("<|soi|>"), sp("<|eoi|>"), sp("<|sot|>"), ids0], 1)
+        txt = F.embedding(ids, emb_tab)
+        img = mlp3(f["images_feat"].cpu().float(), "projector.projector.")
+        emb = torch.cat((txt[:, :2], img, txt[:, 2:]), 1)
+        emb = emb + P[bb + "mmu_pos_embed"][:, : emb.shape[1]]
+        labels = torch.cat([ign(2, ids.shape[0]), ign(img.shape[1], ids.shape[0]), ign(2, ids.shape[0]), f["labels"].cpu()], 1)
+        head = emb_tab
+    h, res = emb, None
+    sc = cfg.lora_alpha / cfg.lora_r
+    for i in range(cfg.n_layer):
+        lp = f"{bb}layers.{i}."
+        y, res = O.add_norm_ref(h, P[lp + "norm.weight"], None, residual=res, eps=cfg.norm_epsilon, prenorm=True, residual_in_fp32=True, is_rms_norm=True)
+        w_eff = P[lp + "mixer.in_proj.weight"] + sc * P[lp + f"mixer.in_proj.{task}_lora_B0.weight"] @ P[lp + f"mixer.in_proj.{task}_lora_A0.weight"]
+        mp = O.Mamba2RefParams(in_proj_weight=w_eff, conv_weight=P[lp + "mixer.conv1d.weight"].squeeze(1), conv_bias=P[lp + "mixer.conv1d.bias"],
+                               dt_bias=P[lp + "mixer.dt_bias"], A_log=P[lp + "mixer.A_log"], D=P[lp + "mixer.D"], norm_weight=P[lp + "mixer.norm.weight"],
+                               out_proj_weight=P[lp + "mixer.out_proj.weight"], headdim=cfg.ssm_cfg["headdim"], d_state=cfg.ssm_cfg["d_state"],
+                               chunk_size=cfg.ssm_cfg["chunk_size"])
+        h = O.mamba2_forward_ref(mp, y)
+    hf = O.add_norm_ref(h, P[bb + "norm_f.weight"], None, residual=res, eps=cfg.norm_epsilon, prenorm=False, residual_in_fp32=True, is_rms_norm=True)
+    logits = F.linear(hf[:, :-1], head)
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), labels[:, 1:].reshape(-1), ignore_index=-100)
+
+
+def test_stage2_step_loss_and_gradients_match_oracle_composition(dev):
+    from omnimamba_amd.train import Stage2Step, TrainConfig
+    model = _model(dev)
+    cfg = model.cfg
+    batch = _batch(cfg, dev)
+    # lr 0 and no clipping: Stage2Step leaves the raw gradients of its one backward in .grad and the weights where they were
+    step = Stage2Step(model, TrainConfig(lr=0.0, clip=0.0, amp_dtype=torch.float32))
+    total = step(batch)
+    names = [n for n, _ in model.named_parameters()]
+    P = {n: p.detach().cpu().float().clone().requires_grad_() for n, p in model.named_parameters()}
+    ref = _oracle_loss(P, cfg, batch, "t2i") + _oracle_loss(P, cfg, batch, "mmu")
+    ref.backward()
+    assert abs(total.item() - ref.item()) < 2e-5 * abs(ref.item()), (total.item(), ref.item())
+    for task in ("t2i", "mmu"):
+        assert abs(step.last[task].item() - _oracle_loss(P, cfg, batch, task).item()) < 2e-5 * abs(ref.item())
+    checked = 0
+    for n, p in model.named_parameters():
+        assert p.requires_grad and p.grad is not None, n
+        assert P[n].grad is not None, n
+        assert rel(p.grad, P[n].grad) < 3e-4, (n, rel(p.grad, P[n].grad))
+        checked += 1
+    assert checked == len(names) and checked > 40
+
+
+@pytest.mark.gpu
+def test_nccl_backend_world_size_one_ddp_step_equals_unwrapped():
+    """First execution of the RCCL path the multi-GPU bench relies on: backend 'nccl', DDP bucket all-reduce, world size 1."""
+    import torch.distributed as dist
+    from omnimamba_amd.train import Stage2Step, TrainConfig, wrap_ddp
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        t = torch.ones(1 << 20, device=dev)
+        dist.all_reduce(t)                      # RCCL all-reduce executes
+        torch.cuda.synchronize()
+        assert t.sum().item() == float(1 << 20)
+        model = _model(dev)
+        plain = copy.deepcopy(model)
+        batch = _batch(model.cfg, dev)
+        tc = TrainConfig(lr=0.0, clip=0.0, amp_dtype=torch.bfloat16, bucket_cap_mb=1)
+        net = wrap_ddp(model, tc, device_ids=[0])
+        a = Stage2Step(model, tc, ddp_model=net)(batch)
+        b = Stage2Step(plain, tc)(batch)
+        torch.cuda.synchronize()
+        assert abs(a.item() - b.item()) < 1e-6 * abs(b.item()) + 1e-7
+        for (n, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):
+            assert p.grad is not None and q.grad is not None, n
+            assert torch.equal(p.grad, q.grad) or rel(p.grad, q.grad) < 1e-6, n
+    finally:
+        if created:
+            dist.destroy_process_group()
