@@ -243,6 +243,7 @@ struct FinishArgs {
   const float* bnd;   // optional (B, H, nT + 1): < g, h > at the boundary behind tile ti (MFMA path): dl restarts from exp(a) * bnd
   int B, H, L, P, N;
   int ckpt_every;   // bnd is valid at tile boundaries j with j % ckpt_every == 0 and at the end of the sequence
+  int bnd_is_q;     // chunk-parallel backward (ssd_cp.hip): bnd[j] already IS dl at token 64 j (the decay of that token included)
 };
 __global__ __launch_bounds__(64) void ssd_bwd_finish_kernel(FinishArgs a) {
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, lane = threadIdx.x;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(1024) void ssd_bwd_finish_par_kernel(FinishArgs a) 
   for (int run = wave; run < nR; run += 16) {
     const int t_hi = ((run + 1) * cke < nT ? (run + 1) * cke : nT) - 1;   // last tile of the run
     const int tn = (t_hi + 1) * 64;   // bnd holds < g, h > at the boundary; apply the decay of the first token behind it
-    float carry = a.bnd[(int64_t)bh * (nT + 1) + t_hi + 1] * (tn < a.L ? expf(a.dtp[base + tn] * Ah) : 1.f);
+    float carry = a.bnd[(int64_t)bh * (nT + 1) + t_hi + 1] * ((tn < a.L && !a.bnd_is_q) ? expf(a.dtp[base + tn] * Ah) : 1.f);
     for (int ti = t_hi; ti >= run * cke; ti--) {
       const int t = ti * 64 + lane;
       const bool ok = t < a.L;
@@ -435,20 +436,32 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   return finish_launch("ssd_scan_fwd");
 }
 
-struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg, *segf; size_t total; };
-static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, bool need_part) {
-  BwdWs w; size_t off = 0; char* c = (char*)base;
+// backward paths: 0 generic fp32 VALU scans, 1 sequential MFMA scans with head-pair partials (round 1 / 2), 2 chunk-parallel dB / dC
+// (ssd_cp.hip) behind the dx scan
+enum { BWD_GENERIC = 0, BWD_MFMA = 1, BWD_CP = 2 };
+struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg, *segf, *pB, *pC; uint16_t *Sf, *Sg; int nhs; size_t total; };
+static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, int path) {
+  BwdWs w = {}; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
   const size_t bhl = (size_t)B * H * L * 4, blgn = (size_t)B * L * G * N * 4;
-  w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl); w.dB32 = take(blgn); w.dC32 = take(blgn);
+  bool need_part = path == BWD_MFMA; const bool mfma = path != BWD_GENERIC;
+  w.dtp = take(bhl); w.dsoft = take(bhl); w.e = take(bhl); w.wsum = take(bhl);
+  if (path != BWD_CP) { w.dB32 = take(blgn); w.dC32 = take(blgn); }
   w.sfin = need_sfin ? take((size_t)B * H * P * N * 4) : nullptr;
   w.part = need_part ? take((size_t)B * (H / 2) * L * 128 * 2) : nullptr;   // bf16 head-pair partial tiles
   const size_t nC = (size_t)(L + 63) / 64;
   w.ckpt = need_part ? take((size_t)B * (H / 2) * nC * (8 * 2 * 8 * 64) * 4) : nullptr;
-  w.bnd = need_part ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
+  w.bnd = mfma ? take((size_t)B * H * (nC + 1) * 4) : nullptr;
+  if (path == BWD_CP) {   // window states (16 KB bf16 images) of both directions, fp32 partials of the head subsets
+    const size_t nW = (size_t)(L + 127) / 128;
+    w.Sf = (uint16_t*)take((size_t)B * H * nW * 16384);
+    w.Sg = (uint16_t*)take((size_t)B * H * nW * 16384);
+    w.nhs = ssd_cp_heads_split(B, L, H, G);
+    w.pB = take((size_t)w.nhs * blgn); w.pC = take((size_t)w.nhs * blgn);
+  }
   // split sequences: start states of the segments -- adjoint state (dx and dB scans) and forward state (dC scan)
-  w.seg = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
-  w.segf = need_part && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
+  w.seg = mfma && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
+  w.segf = mfma && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
   w.total = off;
   return w;
 }
@@ -517,10 +530,25 @@ static bool bwd_mfma_applies(const OmkSsdBwd* p, const SsdDims& d) {
   return ssd_mfma_launch(gdc, nullptr, 1) == OMK_OK && ssd_mfma_launch(gdx, nullptr, 1) == OMK_OK && ssd_mfma_launch(gdb, nullptr, 1) == OMK_OK;
 }
 
+// the chunk-parallel form: bf16 block shape (the MFMA scans apply), one D per head, rows addressable through 32-bit buffer offsets
+static bool bwd_cp_applies(const OmkSsdBwd* p, const SsdDims& d) {
+  if (const char* e = getenv("OMK_SSD_BWD_CP")) if (e[0] == '0') return false;
+  if (present(p->D) && p->D.ndim != 1) return false;
+  if (p->x.dtype != OMK_BF16 || d.P != 64 || d.N != 128) return false;
+  const int64_t lim = (int64_t)0xfffff000;
+  if ((int64_t)d.L * p->x.stride[1] * 2 >= lim || (int64_t)d.L * p->dout.stride[1] * 2 >= lim || (int64_t)d.L * p->Bm.stride[1] * 2 >= lim ||
+      (int64_t)d.L * p->Cm.stride[1] * 2 >= lim) return false;
+  return true;
+}
+static int bwd_path(const OmkSsdBwd* p, const SsdDims& d) {
+  if (!bwd_mfma_applies(p, d)) return BWD_GENERIC;
+  return bwd_cp_applies(p, d) ? BWD_CP : BWD_MFMA;
+}
+
 extern "C" size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p) {
   if (!p) return 0;
   SsdDims d = {(int)p->x.shape[0], (int)p->x.shape[1], (int)p->x.shape[2], (int)p->x.shape[3], (int)p->Bm.shape[2], (int)p->Bm.shape[3]};
-  return bwd_ws_layout(nullptr, d.B, d.L, d.H, d.P, d.G, d.N, present(p->dfinal_states), bwd_mfma_applies(p, d)).total;
+  return bwd_ws_layout(nullptr, d.B, d.L, d.H, d.P, d.G, d.N, present(p->dfinal_states), bwd_path(p, d)).total;
 }
 
 extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
@@ -541,8 +569,9 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_bwd_workspace_bytes(p), "ssd_scan_bwd: workspace too small");
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
   const bool has_dfin = present(p->dfinal_states);
-  const bool mfma = bwd_mfma_applies(p, d);
-  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, mfma);
+  const int path = bwd_path(p, d);
+  const bool mfma = path != BWD_GENERIC, cp = path == BWD_CP;
+  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, path);
   const int64_t bhl = (int64_t)d.B * d.H * d.L, blgn = (int64_t)d.B * d.L * d.G * d.N;
   if (!mfma) { launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream); }
   launch_zero((float*)p->dA.data, d.H, stream);
@@ -570,7 +599,35 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     gdx.seg_ready = 1; gdx.seg_fmt = fmt_a;
     gdb.seg = w.seg; gdb.seg_ready = 1; gdb.seg_fmt = fmt_a;
   }
-  if (mfma) {
+  if (cp) {
+    // chunk-parallel: a state-only forward pass and the dx scan leave the window-boundary states of both directions behind;
+    // ssd_cp.hip forms dB, dC, the token scalars, the restart values of the decay gradient and dD window by window
+    const int nW = (d.L + 127) / 128;
+    GScan gf = {};
+    gf.mode = GS_Y; gf.dtp = w.dtp; gf.A = A; gf.B = d.B; gf.H = d.H; gf.G = d.G; gf.L = d.L; gf.DU = d.P; gf.DK = d.N;
+    gf.U = make_src(p->x, false); gf.K = make_src(p->Bm, true); gf.Q = make_src(p->Cm, true); gf.reverse = 0; gf.w_is_dt = 1;
+    if (present(p->initial_states)) {
+      gf.init = p->initial_states.data; gf.init_dt = p->initial_states.dtype;
+      gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
+    }
+    if (gdc.seg_ready) { gf.seg = w.segf; gf.seg_ready = 1; gf.seg_fmt = gdc.seg_fmt; }
+    gf.dump = w.Sf; gf.dump_nw = nW;
+    if ((rc = ssd_mfma_state_dump(gf, stream))) return rc;
+    gdx.dump = w.Sg; gdx.dump_nw = nW;
+    if ((rc = ssd_mfma_launch(gdx, stream))) return rc;
+    CpArgs c = {};
+    c.X = (const uint16_t*)p->x.data; c.xsb = p->x.stride[0]; c.xsl = p->x.stride[1]; c.xsh = p->x.stride[2];
+    c.DY = (const uint16_t*)p->dout.data; c.ysb = p->dout.stride[0]; c.ysl = p->dout.stride[1]; c.ysh = p->dout.stride[2];
+    c.Bm = (const uint16_t*)p->Bm.data; c.bsb = p->Bm.stride[0]; c.bsl = p->Bm.stride[1]; c.bsg = p->Bm.stride[2];
+    c.Cm = (const uint16_t*)p->Cm.data; c.csb = p->Cm.stride[0]; c.csl = p->Cm.stride[1]; c.csg = p->Cm.stride[2];
+    c.dtp = w.dtp; c.A = A; c.Sf = w.Sf; c.Sg = w.Sg; c.e = w.e; c.wsum = w.wsum; c.bnd = w.bnd;
+    if (present(p->dD)) { c.dD = (float*)p->dD.data; c.dDsh = p->dD.stride[0]; }
+    c.pB = w.pB; c.pC = w.pC;
+    c.dB = p->dB.data; c.dbsb = p->dB.stride[0]; c.dbsl = p->dB.stride[1]; c.dbsg = p->dB.stride[2]; c.dB_dt = p->dB.dtype;
+    c.dC = p->dC.data; c.dcsb = p->dC.stride[0]; c.dcsl = p->dC.stride[1]; c.dcsg = p->dC.stride[2]; c.dC_dt = p->dC.dtype;
+    c.B = d.B; c.L = d.L; c.H = d.H; c.G = d.G; c.nW = nW; c.nhs = w.nhs;
+    if ((rc = ssd_cp_launch(c, stream))) return rc;
+  } else if (mfma) {
     if ((rc = ssd_mfma_launch(gdc, stream))) return rc;   // forward in time: e_t, state checkpoints, dC partials
     ssd_reduce_partials(w.part, p->dC.data, p->dC.stride[0], p->dC.stride[1], p->dC.stride[2], p->dC.dtype, d.B, d.L, d.G, d.H, stream);
     if ((rc = ssd_mfma_launch(gdb, stream))) return rc;
@@ -590,7 +647,8 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     }
     f.ddt = p->ddt.data; f.dsb = p->ddt.stride[0]; f.dsl = p->ddt.stride[1]; f.dsh = p->ddt.stride[2]; f.ddt_dt = p->ddt.dtype;
     f.bnd = mfma ? w.bnd : nullptr;
-    f.ckpt_every = mfma ? ssd_ckpt_every() : 1;
+    f.ckpt_every = cp ? 1 : (mfma ? ssd_ckpt_every() : 1);
+    f.bnd_is_q = cp ? 1 : 0;
     f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
     if (f.bnd && !f.dfin) {
       dim3 grid((unsigned)(d.B * d.H)), block(1024);

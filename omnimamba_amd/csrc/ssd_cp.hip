@@ -1,0 +1,383 @@
+// ssd_cp.hip -- chunk-parallel half of the SSD backward (round 3): dB, dC, the token scalars of the decay gradient and dD from
+// window-boundary states, with the sum over the heads of a group formed ON CHIP.
+//
+// Why.  The sequential backward scans of ssd_mfma.hip give every head its own workgroup, so dB / dC (sums over the 64 heads that
+// share B and C) left the chip as per-head-pair partial tiles (2 x 268 MB written, 2 x 268 MB read back at B 8, L 4096) and the
+// decay gradient needed a forward-state checkpoint per chunk (537 MB written, 537 MB read): 3.94 GB of HBM traffic for 0.85 GB of
+// algorithmic bytes (profiles/r02_pmc_ssd_final.txt).  Here ONE workgroup owns a 128-token window of one (batch, group) and walks
+// the heads of the group, so the head sum lives in MFMA accumulators and dB / dC are written once.  What a head needs from outside
+// its window are two 64 x 128 states -- the forward state S_in in front of the window and the adjoint state Gn behind it -- which
+// the class A scans leave behind as bf16 images (GScan::dump): the dx scan (which runs anyway) dumps Gn, one state-only forward
+// pass dumps S_in.
+//
+// Per head h and window (local tokens m, s; c = log2 of the cumulative decay inside the window; a_t = exp(dt'_t A)):
+//   Z[m][s]   = dy_m . x_s                      (s <= m)        16x16x32 MFMAs, contraction over headdim
+//   T[m][s]   = Z[m][s] 2^(c_m - c_s)                              fp32, from exact bf16 products
+//   W[m][s]  += dt_s T[m][s]                     summed over the heads in registers;  dC += W B,  dB += W^T C  at the very end
+//   e_m       = 2^c_m C_m . (dy_m S_in)  +  sum_s dt_s T[m][s] (C_m . B_s)          = dy_m . (C_m s_m)
+//   w_s       = dec 2^(c_end - c_s) B_s . (x_s Gn)  +  sum_m T[m][s] (C_m . B_s)    = x_s . (g_s B_s)
+//   dC^T[n][m] += 2^c_m (S_in^T dy_m)[n]         32x32x16 MFMAs, bf16 state images as A operand through transpose reads
+//   dB^T[n][s] += dt_s dec 2^(c_end - c_s) (Gn^T x_s)[n]
+// e and w are the token scalars of ssd_bwd_finish_par_kernel (ssd.hip): dl_t = sum_{j >= t} (e_j - dt_j w_j) restarted at every
+// 64-token boundary from the exact value q = < g, a s > the window can form by itself:
+//   q(end of window)  = 2^c_end < Gn, S_in > + sum_s dt_s w_inter[s]
+//   q(token 64)       = 2^c_end < Gn, S_in > + sum_{s < 64} dt_s w_inter[s] + sum_{m >= 64} e_inter[m] + sum_{m >= 64 > s} dt_s T (C . B)
+// Off-diagonal tiles take the decay as a row factor times a column factor around the tile boundary (both <= 1: no overflow, and an
+// underflow only where the exact product underflows too); diagonal tiles evaluate exp2 per element under the causal mask.
+#include <cstdlib>
+
+#include "ssd_scan.h"
+#include "ssd_tiles.h"
+
+namespace omk {
+
+constexpr int TW = 128;   // window (tokens)
+
+struct SmemCp {
+  uint16_t X[TW * 64];      // [t][p], ux3 swizzle          (X | DY hold W as a 128 x 128 bf16 tile after the head loop)
+  uint16_t DY[TW * 64];
+  uint16_t S[64 * 128];     // forward state in front of the window, raw kx3 image [p][n]
+  uint16_t Gt[64 * 128];    // adjoint state behind the window (before the decay of the first token behind it)
+  uint16_t Bm[TW * 128];    // [t][n], kx3 swizzle
+  uint16_t Cm[TW * 128];
+  float c2[2][TW], alpha[2][TW], dts[2][TW], ecm[2][TW], wsc0[2][TW], wsc[2][TW];   // per head, double buffered
+  float el[2][TW], wl[2][TW];
+  float misc[2][8];         // 0 <Graw, S_in>, 1 sum dt w_inter, 2 the same for s < 64, 3 sum_{m >= 64} e_inter, 4 cross block, 5 dD, 6 c_end, 7 dec
+};
+static_assert(sizeof(SmemCp) <= 160 * 1024, "one workgroup per CU");
+
+__global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
+  OMK_DYN_SMEM(smem_raw);
+  SmemCp& sm = *reinterpret_cast<SmemCp*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = uniform_i(tid >> 6);
+  const int t16 = lane & 15, g16 = lane >> 4, l31 = lane & 31, h32 = lane >> 5;
+  int vid = blockIdx.x;
+  const int hs = vid % a.nhs; vid /= a.nhs;
+  const int win = vid % a.nW; vid /= a.nW;
+  const int g = vid % a.G, b = vid / a.G;
+  const int hpg = a.H / a.G, hps = hpg / a.nhs;
+  const int hbeg = g * hpg + hs * hps;
+  const int t0 = win * TW;
+  const int nT = (a.L + 63) / 64;
+
+  // ---- zero the accumulating scalars (both buffers)
+  if (tid < 2 * TW) { (&sm.el[0][0])[tid] = 0.f; (&sm.wl[0][0])[tid] = 0.f; }
+  if (tid < 16) (&sm.misc[0][0])[tid] = 0.f;
+  // ---- the window's B / C rows (shared by every head of the group)
+  {
+    const uint16_t* Bb = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
+    const uint16_t* Cb = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
+    const BufRes Br = make_buf(Bb, (uint32_t)((int64_t)a.L * a.bsl * 2)), Cr = make_buf(Cb, (uint32_t)((int64_t)a.L * a.csl * 2));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int q = tid + 512 * i, row = q >> 4, seg = q & 15;
+      st16(&sm.Bm[kx3(row, seg * 8)], buf_ld16(Br, 2u * (uint32_t)((t0 + row) * (int)a.bsl + seg * 8), 0u));
+      st16(&sm.Cm[kx3(row, seg * 8)], buf_ld16(Cr, 2u * (uint32_t)((t0 + row) * (int)a.csl + seg * 8), 0u));
+    }
+  }
+  // ---- per-head staging: x, dy rows (two 16-byte segments per thread each), the two state images (two each)
+  u32x4 rx[2], ry[2], rs[2], rg[2];
+  float rd0 = 0.f, rd1 = 0.f, rdn = 0.f;
+  auto issue_loads = [&](int h) {
+    const uint16_t* Xb = a.X + (int64_t)b * a.xsb + (int64_t)h * a.xsh;
+    const uint16_t* Yb = a.DY + (int64_t)b * a.ysb + (int64_t)h * a.ysh;
+    const BufRes Xr = make_buf(Xb, (uint32_t)((int64_t)a.L * a.xsl * 2)), Yr = make_buf(Yb, (uint32_t)((int64_t)a.L * a.ysl * 2));
+    const int64_t slot = (((int64_t)b * a.H + h) * a.nW + win) << 13;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int q = tid + 512 * i, row = q >> 3, seg = q & 7;
+      rx[i] = buf_ld16(Xr, 2u * (uint32_t)((t0 + row) * (int)a.xsl + seg * 8), 0u);
+      ry[i] = buf_ld16(Yr, 2u * (uint32_t)((t0 + row) * (int)a.ysl + seg * 8), 0u);
+      rs[i] = ld16(a.Sf + slot + q * 8);
+      rg[i] = ld16(a.Sg + slot + q * 8);
+    }
+    if (w == 0) {   // dt' of the window's tokens and of the first token behind it (zeros past the end of the sequence)
+      const BufRes Dr = make_buf(a.dtp + ((int64_t)b * a.H + h) * a.L, (uint32_t)((int64_t)a.L * 4));
+      rd0 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + lane), 0u);
+      rd1 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + 64 + lane), 0u);
+      rdn = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + TW), 0u);
+    }
+  };
+  auto commit = [&](int sb) {   // registers -> LDS; dD and < Graw, S_in > fall out of the staged registers
+    float dd = 0.f, gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int q = tid + 512 * i, row = q >> 3, seg = q & 7;
+      st16(&sm.X[ux3(row, seg * 8)], rx[i]);
+      st16(&sm.DY[ux3(row, seg * 8)], ry[i]);
+      st16(&sm.S[q * 8], rs[i]);
+      st16(&sm.Gt[q * 8], rg[i]);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { dd = dot2_bf16(rx[i][e], ry[i][e], dd); gs = dot2_bf16(rs[i][e], rg[i][e], gs); }
+    }
+    dd = wave_sum(dd); gs = wave_sum(gs);
+    if (lane == 0) { lds_add_f32(&sm.misc[sb][5], dd); lds_add_f32(&sm.misc[sb][0], gs); }
+  };
+  auto scalars = [&](int h, int sb) {   // wave 0; lanes = tokens 0 .. 63 and 64 .. 127 of the window
+    const float Ah2 = a.A[h] * LOG2E;
+    const float c0 = wave_incl_scan_add(rd0 * Ah2);
+    const float tot0 = wave_read_lane(c0, 63);
+    const float c1 = wave_incl_scan_add(rd1 * Ah2) + tot0;
+    const float cend = wave_read_lane(c1, 63);
+    // row factor of the off-diagonal tiles: decay from the end of the previous 16-token block
+    const int src = (lane & ~15) - 1;
+    const float p0 = shfl(c0, src < 0 ? 0 : src), p1 = shfl(c1, src < 0 ? 0 : src);
+    const float ref0 = lane < 16 ? 0.f : p0, ref1 = lane < 16 ? tot0 : p1;
+    const float dec = exp2_fast(rdn * Ah2);
+    sm.c2[sb][lane] = c0; sm.c2[sb][64 + lane] = c1;
+    sm.alpha[sb][lane] = exp2_fast(c0 - ref0); sm.alpha[sb][64 + lane] = exp2_fast(c1 - ref1);
+    sm.dts[sb][lane] = rd0; sm.dts[sb][64 + lane] = rd1;
+    sm.ecm[sb][lane] = exp2_fast(c0); sm.ecm[sb][64 + lane] = exp2_fast(c1);
+    const float k0 = dec * exp2_fast(cend - c0), k1 = dec * exp2_fast(cend - c1);
+    sm.wsc0[sb][lane] = k0; sm.wsc0[sb][64 + lane] = k1;
+    sm.wsc[sb][lane] = rd0 * k0; sm.wsc[sb][64 + lane] = rd1 * k1;
+    if (lane == 0) { sm.misc[sb][6] = cend; sm.misc[sb][7] = dec; }
+  };
+
+  // ---- Phase A tiles of this wave: 36 lower-triangular 16 x 16 tiles (m block, s block), tile index w + 8 t
+  int tmb[5], tsb[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    const int i = w + 8 * t;
+    int mb = 0;
+    while ((mb + 1) * (mb + 2) / 2 <= i) mb++;
+    tmb[t] = i < 36 ? mb : -1;
+    tsb[t] = i - mb * (mb + 1) / 2;
+  }
+  f32x4 Wt[5], g1[5];
+  f32x16 dCt[2], dBt[2];
+#pragma unroll
+  for (int t = 0; t < 5; t++) { Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dCt[j][r] = 0.f; dBt[j][r] = 0.f; }
+
+  block_sync();   // zeros and B / C rows visible
+  issue_loads(hbeg);
+  commit(0);
+  if (w == 0) scalars(hbeg, 0);
+  // G1[m][s] = C_m . B_s of this wave's tiles (the same for every head)
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    if (tmb[t] < 0) continue;
+    const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+      g1[t] = mfma16x16x32_bf16(as_s16x8(ld16(&sm.Cm[kx3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.Bm[kx3(s0 + t16, 32 * ks + 8 * g16)])), g1[t]);
+  }
+  block_sync();   // head 0 staged
+
+  const int mbB = w & 3, nh = w >> 2;
+  const int mrow = 32 * mbB + l31;
+  for (int hi = 0; hi < hps; hi++) {
+    const int h = hbeg + hi, sb = hi & 1;
+    const bool more = hi + 1 < hps;
+    if (more) issue_loads(h + 1);
+    // ---- Phase A: intra-window terms
+    float qm = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      if (tmb[t] < 0) continue;
+      const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+        z = mfma16x16x32_bf16(as_s16x8(ld16(&sm.DY[ux3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.X[ux3(s0 + t16, 32 * ks + 8 * g16)])), z);
+      // z[r] = dy_m . x_s, m = m0 + 4 g16 + r, s = s0 + t16
+      const float css = sm.c2[sb][s0 + t16], dss = sm.dts[sb][s0 + t16];
+      f32x4 t2;
+      if (m0 != s0) {
+        const float beta = exp2_fast(sm.c2[sb][m0 - 1] - css);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(&sm.alpha[sb][m0 + 4 * g16]);
+        t2 = z * al * beta;
+      } else {
+        const f32x4 cm = *reinterpret_cast<const f32x4*>(&sm.c2[sb][m0 + 4 * g16]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float arg = cm[r] - css;
+          t2[r] = (4 * g16 + r >= t16) ? z[r] * exp2_fast(arg < 0.f ? arg : 0.f) : 0.f;
+        }
+      }
+      Wt[t] += t2 * dss;
+      const f32x4 d = t2 * g1[t];
+      float col = (d[0] + d[1]) + (d[2] + d[3]);            // w_intra: sum over m
+      col += shfl_xor(col, 16);
+      col += shfl_xor(col, 32);
+      if (g16 == 0) lds_add_f32(&sm.wl[sb][s0 + t16], col);
+      float rv[4] = {d[0] * dss, d[1] * dss, d[2] * dss, d[3] * dss};   // e_intra: sum over s of dt_s T (C . B)
+      if (m0 >= 64 && s0 < 64) qm += (rv[0] + rv[1]) + (rv[2] + rv[3]);
+      WaveMultiSum<4, 8>::run(rv, lane);                     // lane keeps row r = (t16 >> 2) & 3, summed over its 16 lanes
+      if ((t16 & 3) == 0) lds_add_f32(&sm.el[sb][m0 + 4 * g16 + ((t16 >> 2) & 3)], rv[0]);
+    }
+    // ---- Phase B: inter-window terms; this wave owns rows n of two 32-blocks (2 nh, 2 nh + 1) x tokens 32 mbB ..
+    float ep = 0.f, wp = 0.f;
+    const float ecm_m = sm.ecm[sb][mrow], wsc_s = sm.wsc[sb][mrow], wsc0_s = sm.wsc0[sb][mrow], dts_s = sm.dts[sb][mrow];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int nb = 2 * nh + j;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+        acc = mfma32x32x16_bf16(tr_frag3<true>(sm.S, 16 * ks, 32 * nb, lane), as_s16x8(ld16(&sm.DY[ux3(mrow, 16 * ks + 8 * h32)])), acc);
+      // acc[r] = (S_in^T dy_m)[n], n = 32 nb + 8 (r >> 2) + 4 h32 + (r & 3), m = mrow
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32x2 cv = *reinterpret_cast<const u32x2*>(&sm.Cm[kx3(mrow, 32 * nb + 8 * q + 4 * h32)]);
+        const float c4[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ep += acc[4 * q + i] * c4[i]; dCt[j][4 * q + i] += ecm_m * acc[4 * q + i]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+        acc = mfma32x32x16_bf16(tr_frag3<true>(sm.Gt, 16 * ks, 32 * nb, lane), as_s16x8(ld16(&sm.X[ux3(mrow, 16 * ks + 8 * h32)])), acc);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32x2 bv = *reinterpret_cast<const u32x2*>(&sm.Bm[kx3(mrow, 32 * nb + 8 * q + 4 * h32)]);
+        const float b4[4] = {bf_lo(bv[0]), bf_hi(bv[0]), bf_lo(bv[1]), bf_hi(bv[1])};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
+      }
+    }
+    ep += shfl_xor(ep, 32);
+    wp += shfl_xor(wp, 32);
+    {
+      const float ei = h32 == 0 ? ecm_m * ep : 0.f, wi = h32 == 0 ? wsc0_s * wp : 0.f;   // this wave's n half
+      if (h32 == 0) { lds_add_f32(&sm.el[sb][mrow], ei); lds_add_f32(&sm.wl[sb][mrow], wi); }
+      const float dtw = dts_s * wi;
+      const float s_all = wave_sum(dtw), s_eh = wave_sum(ei), s_qm = wave_sum(qm);
+      if (lane == 0) {
+        lds_add_f32(&sm.misc[sb][1], s_all);
+        if (mbB < 2) lds_add_f32(&sm.misc[sb][2], s_all);
+        else lds_add_f32(&sm.misc[sb][3], s_eh);
+        lds_add_f32(&sm.misc[sb][4], s_qm);
+      }
+    }
+    if (w == 0 && more) scalars(h + 1, sb ^ 1);
+    block_sync();   // every read of this head's tiles and every add into its scalars is done
+    // ---- token scalars, restart values and dD of this head; next head's tiles
+    {
+      const int64_t bh = (int64_t)b * a.H + h;
+      if (tid < TW) {
+        const float ev = sm.el[sb][tid], wv = sm.wl[sb][tid];
+        sm.el[sb][tid] = 0.f; sm.wl[sb][tid] = 0.f;
+        if (t0 + tid < a.L) { a.e[bh * a.L + t0 + tid] = ev; a.wsum[bh * a.L + t0 + tid] = wv; }
+      } else if (tid == TW) {
+        const float qb = exp2_fast(sm.misc[sb][6]) * sm.misc[sb][7] * sm.misc[sb][0];
+        const float q_end = qb + sm.misc[sb][1];
+        const float q_mid = qb + sm.misc[sb][2] + sm.misc[sb][3] + sm.misc[sb][4];
+        if (2 * win + 1 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 1] = q_mid;
+        if (2 * win + 2 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 2] = q_end;
+        if (a.dD) atomic_add_f32(a.dD + (int64_t)h * a.dDsh, sm.misc[sb][5]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) sm.misc[sb][i] = 0.f;
+      }
+    }
+    if (more) commit(sb ^ 1);
+    block_sync();   // next head staged
+  }
+
+  // ---- W (sum over the heads, fp32 registers) -> bf16 tile [m][s] in LDS;  dC^T += B^T W^T,  dB^T += C^T W
+  // (W as a bf16 hi + lo pair: one rounding of W would sit on top of the output rounding of dB / dC -- 1.7e-3 -> 2.3e-3 measured)
+  uint16_t* Wl = sm.X;        // 32 KB: X | DY
+  uint16_t* Wlo = sm.S;       // 32 KB: S | Gt
+  {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { st16(&Wl[(tid + 512 * i) * 8], zero4); st16(&Wlo[(tid + 512 * i) * 8], zero4); }
+  }
+  block_sync();
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    if (tmb[t] < 0) continue;
+    const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint16_t hi = f32_to_bf16(Wt[t][r]);
+      Wl[kx3(m0 + 4 * g16 + r, s0 + t16)] = hi;
+      Wlo[kx3(m0 + 4 * g16 + r, s0 + t16)] = f32_to_bf16(Wt[t][r] - bf16_to_f32(hi));
+    }
+  }
+  block_sync();
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int nb = 2 * nh + j;
+    for (int ks = 0; ks <= 2 * mbB + 1; ks++) {   // s <= m: s blocks up to the end of this m block
+      const s16x8 fb = tr_frag3<true>(sm.Bm, 16 * ks, 32 * nb, lane);
+      dCt[j] = mfma32x32x16_bf16(fb, as_s16x8(ld16(&Wl[kx3(mrow, 16 * ks + 8 * h32)])), dCt[j]);
+      dCt[j] = mfma32x32x16_bf16(fb, as_s16x8(ld16(&Wlo[kx3(mrow, 16 * ks + 8 * h32)])), dCt[j]);
+    }
+    for (int ks = 2 * mbB; ks < 8; ks++) {        // m >= s: m blocks from this s block on
+      const s16x8 fc = tr_frag3<true>(sm.Cm, 16 * ks, 32 * nb, lane);
+      dBt[j] = mfma32x32x16_bf16(fc, tr_frag3<true>(Wl, 16 * ks, 32 * mbB, lane), dBt[j]);
+      dBt[j] = mfma32x32x16_bf16(fc, tr_frag3<true>(Wlo, 16 * ks, 32 * mbB, lane), dBt[j]);
+    }
+  }
+  // ---- fp32 partials of this head subset: [hs][b][t][g][n]
+  if (t0 + mrow < a.L) {
+    const int64_t row = ((((int64_t)hs * a.B + b) * a.L + t0 + mrow) * a.G + g) * 128;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int n = 32 * (2 * nh + j) + 8 * q + 4 * h32;
+        *reinterpret_cast<f32x4*>(a.pC + row + n) = f32x4{dCt[j][4 * q], dCt[j][4 * q + 1], dCt[j][4 * q + 2], dCt[j][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(a.pB + row + n) = f32x4{dBt[j][4 * q], dBt[j][4 * q + 1], dBt[j][4 * q + 2], dBt[j][4 * q + 3]};
+      }
+  }
+}
+
+// out[b][t][g][n] = sum over the head subsets of part[hs][b][t][g][n], in the gradient's dtype; one thread = 8 consecutive n
+__global__ void ssd_cp_fold_kernel(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int nhs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * L * G * 16;
+  if (i >= total) return;
+  const int n8 = (int)(i % 16) * 8;
+  const int64_t blg = i / 16;
+  const int g = (int)(blg % G), t = (int)((blg / G) % L), b = (int)(blg / ((int64_t)G * L));
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nhs; s++) {
+    const float* p = part + ((int64_t)s * B * L * G + blg) * 128 + n8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { acc[e] += v0[e]; acc[4 + e] += v1[e]; }
+  }
+  const int64_t o = (int64_t)b * osb + (int64_t)t * osl + (int64_t)g * osg + n8;
+  if (out_dt == OMK_BF16 && ((o & 7) == 0) && (((uintptr_t)out & 15) == 0)) {
+    u32x4 pv;
+#pragma unroll
+    for (int e = 0; e < 4; e++) pv[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+    st16((uint16_t*)out + o, pv);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) store_rt(out, o + e, out_dt, acc[e]);
+  }
+}
+
+// few windows (short batch x sequence): split the heads of a group over several workgroups so that the chip fills
+int ssd_cp_heads_split(int B, int L, int H, int G) {
+  const int nW = (L + TW - 1) / TW, hpg = H / G;
+  const int64_t base = (int64_t)B * G * nW;
+  int nhs = 1;
+  while (base * nhs < 256 && hpg % (nhs * 2) == 0 && hpg / (nhs * 2) >= 4) nhs *= 2;
+  return nhs;
+}
+
+int ssd_cp_launch(const CpArgs& a, omk_stream stream) {
+  const size_t smem = sizeof(SmemCp);
+  if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
+  dim3 grid((unsigned)((int64_t)a.B * a.G * a.nW * a.nhs)), block(512);
+  OMK_LAUNCH(ssd_cp_kernel, grid, block, smem, stream, a);
+  const int64_t total = (int64_t)a.B * a.L * a.G * 16;
+  dim3 fgrid((unsigned)((total + 255) / 256)), fblock(256);
+  OMK_LAUNCH(ssd_cp_fold_kernel, fgrid, fblock, 0, stream, (const float*)a.pC, a.dC, a.dcsb, a.dcsl, a.dcsg, a.dC_dt, a.B, a.L, a.G, a.nhs);
+  OMK_LAUNCH(ssd_cp_fold_kernel, fgrid, fblock, 0, stream, (const float*)a.pB, a.dB, a.dbsb, a.dbsl, a.dbsg, a.dB_dt, a.B, a.L, a.G, a.nhs);
+  return OMK_OK;
+}
+
+}  // namespace omk

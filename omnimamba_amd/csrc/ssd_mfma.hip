@@ -54,18 +54,6 @@ constexpr int QC = 64;     // chunk length (tokens)
 //   64-column tiles (128 B rows, two rows per 256 B bank row): seg ^ swzU(row) with swzU = swzK & 7 -- searched the same
 //     way over every pattern the class A / class B kernels use on them (8 rows x 2 segments, 4 rows x 4 segments,
 //     16 rows x 1 segment, the ds_read_b128 row reads, rows {0-3, 8-11} x 2 segments).
-// 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
-// rows r0 + 8 h32 + 4 m + {0..3}, column c0 + (lane & 31)
-template <bool KT>
-__device__ __forceinline__ s16x8 tr_frag3(const uint16_t* tile, int r0, int c0, int lane) {
-  const int t16 = lane & 15, g16 = lane >> 4, h32 = lane >> 5;
-  const int row = r0 + 8 * h32 + (t16 >> 2), col = c0 + 16 * (g16 & 1) + 4 * (t16 & 3);
-  const s16x4 a = lds_read_tr16_b64(tile + (KT ? kx3(row, col) : ux3(row, col)));
-  const s16x4 b = lds_read_tr16_b64(tile + (KT ? kx3(row + 4, col) : ux3(row + 4, col)));
-  s16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
-}
 struct SmemA3 {
   uint16_t K[2][QC * 128];
   uint16_t U[2][QC * 64];
@@ -96,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   int vid = blockIdx.x;
   if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   // workgroup order (b, segment, h): the heads of one (batch, segment) share B / C rows and an XCD
-  const int nwseg = STATE ? a.nseg - 1 : a.nseg;
+  // spass: the state-only pass that dumps window states starts like a scan (every segment, folded start states) and leaves no
+  // segment state behind
+  const bool spass = STATE && a.dump != nullptr;
+  const int nwseg = (STATE && !spass) ? a.nseg - 1 : a.nseg;
   const int h = vid % a.H, seg = (vid / a.H) % nwseg, b = vid / (a.H * nwseg);
   const int g = h / (a.H / a.G);
   const int nC = (a.L + QC - 1) / QC;
@@ -198,14 +189,14 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   const int64_t bh = (int64_t)b * a.H + h;
   // accumulator order of the segment states: element (w, ut, r, lane) at ((2 w + ut) * 16 + r) * 64 + lane
   const int segoff = (2 * w * 16) * 64 + lane;
-  if (!STATE && seg > 0) {   // folded by ssd_seg_fold_kernel: slot seg - 1 = state at the start of this segment
+  if ((!STATE || spass) && seg > 0) {   // folded by ssd_seg_fold_kernel: slot seg - 1 = state at the start of this segment
     const float* sp = a.seg + (bh * a.nseg + seg - 1) * SEG_STATE + segoff;
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
 #pragma unroll
       for (int r = 0; r < 16; r++) accS[ut][r] = sp[(ut * 16 + r) * 64];
   }
-  if (a.init && !STATE && seg == 0) {
+  if (a.init && (!STATE || spass) && seg == 0) {
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
 #pragma unroll
@@ -232,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   prefetch_u();
   commit(0);
   if (w == 0) scalars(0, true);
+  if (spass) publish_state();
   if (!STATE) {
     publish_state();
     if (!DFOLD && tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
@@ -263,6 +255,16 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     const int tlo = chunk_lo(c);
     const int cnext = c + 1 < c1 ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
     PT3(0);
+    if (a.dump) {   // window-boundary image of the state in front of this chunk (sm.S, published before the last barrier)
+      const int cid = rev ? nC - 1 - c : c;
+      const bool here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
+      if (here) {
+        uint16_t* dp = a.dump + ((bh * a.dump_nw + (cid >> 1)) << 13);
+#pragma unroll
+        for (int i = 0; i < 4; i++) st16(dp + (tid + 256 * i) * 8, ld16(&sm.S[(tid + 256 * i) * 8]));
+        if (STATE) block_sync();   // (the scan proper has barrier X between these reads and the next publish)
+      }
+    }
     // ---- (1) O = exp2(cs_l) * (Q . S_in): A = Q fragments (registers), B = S_in[k][u] as [u][k] bf16 rows
     f32x4 acc[4];
 #pragma unroll
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     }
     PT3(4);
     // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
-    if (!STATE && !(abl & 8)) publish_state();
+    if ((!STATE || spass) && !(abl & 8)) publish_state();
     commit(nxt);
     if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   if (prof && lane == 0)
     for (int i = 0; i < 12; i++) a.prof[w * 12 + i] = pt[i];
 #endif
+  if (spass) return;
   if (STATE) {
     float* sp = a.seg + (bh * a.nseg + seg) * SEG_STATE + segoff;
 #pragma unroll
@@ -959,6 +962,7 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
   if (seg_fmt) *seg_fmt = 0;
   GScan a = g;
+  a.dump = nullptr;   // the zero-start pass is not the one that dumps window states
   const SegPlan sp = ssd_segments(a.B * a.H, a.L);
   a.nseg = sp.nseg; a.cps = sp.cps;
   if (!a.seg || a.nseg < 2) return OMK_OK;
@@ -969,6 +973,18 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
   OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), sgrid, block, smem, stream, a);
   dim3 fgrid((unsigned)((int64_t)a.B * a.H * (SEG_STATE / 256)));
   OMK_LAUNCH(ssd_seg_fold_kernel, fgrid, block, 0, stream, a);
+  return OMK_OK;
+}
+
+int ssd_mfma_state_dump(const GScan& g, omk_stream stream) {
+  if (!g.dump || g.DU != 64 || g.DK != 128) return OMK_EUNSUPPORTED;
+  GScan a = g;
+  const SegPlan sp = (a.seg && a.seg_ready) ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
+  const size_t smem = sizeof(SmemA3);
+  if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+  OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), grid, block, smem, stream, a);
   return OMK_OK;
 }
 

@@ -51,6 +51,11 @@ struct GScan {
   float* seg; int nseg, cps;
   int seg_ready;                                                 // seg already holds the folded START states (slot j - 1 = segment j)
   int seg_fmt;                                                   // element order of seg: 0 = ssd_mfma_a3 accumulator order, 1 = logical [u][k] of the class A state
+  // class A (MFMA): bf16 images of the carried state at the 128-token window boundaries, for the chunk-parallel backward
+  // (ssd_cp.hip): slot (b * H + h) * dump_nw + w holds the state in front of window w in scan direction -- forward: the state
+  // BEFORE token 128 w; reverse: the adjoint state at the first token BEHIND window w (dfinal_states for the last one) -- as
+  // the raw 16 KB LDS image [u][k] (kx3 swizzle, ssd_tiles.h) the kernel publishes for its own Q . S product.
+  uint16_t* dump; int dump_nw;
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
@@ -97,6 +102,23 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = 
 // the hi + lo ("precise") forward scan (ssd_v6.hip): OMK_SSD_PRECISE=1
 bool ssd_v6_applies(const GScan& g);
 int ssd_v6_launch(const GScan& g, omk_stream stream);
+// state-only pass over the whole sequence that leaves the window-boundary states in g.dump (class A descriptor, no output)
+int ssd_mfma_state_dump(const GScan& g, omk_stream stream);
+// chunk-parallel dB / dC / token scalars from the dumped states (ssd_cp.hip)
+struct CpArgs {
+  const uint16_t *X, *DY; int64_t xsb, xsl, xsh, ysb, ysl, ysh;   // (B, L, H, 64) bf16
+  const uint16_t *Bm, *Cm; int64_t bsb, bsl, bsg, csb, csl, csg;  // (B, L, G, 128) bf16
+  const float* dtp; const float* A;                               // (B, H, L) dt', (H)
+  const uint16_t *Sf, *Sg;                                        // window states (GScan::dump images), forward / adjoint
+  float *e, *wsum;                                                // (B, H, L) token scalars
+  float* bnd;                                                     // (B, H, nT + 1): decay-gradient restart value q at token 64 j
+  float* dD; int64_t dDsh;                                        // optional, one D per head
+  float *pB, *pC;                                                 // fp32 partials [nhs][B][L][G][128]
+  void *dB, *dC; int64_t dbsb, dbsl, dbsg, dcsb, dcsl, dcsg; int dB_dt, dC_dt;
+  int B, L, H, G, nW, nhs;
+};
+int ssd_cp_heads_split(int B, int L, int H, int G);
+int ssd_cp_launch(const CpArgs& a, omk_stream stream);
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
 }  // namespace omk

@@ -65,4 +65,17 @@ __device__ __forceinline__ int swzU(int r) { return swzK(r) & 7; }
 __device__ __forceinline__ int kx3(int row, int col) { return row * 128 + ((((col >> 3) ^ swzK(row)) << 3) | (col & 7)); }
 __device__ __forceinline__ int ux3(int row, int col) { return row * 64 + ((((col >> 3) ^ swzU(row)) << 3) | (col & 7)); }
 
+// 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
+// rows r0 + 8 h32 + 4 m + {0..3}, column c0 + (lane & 31)
+template <bool KT>
+__device__ __forceinline__ s16x8 tr_frag3(const uint16_t* tile, int r0, int c0, int lane) {
+  const int t16 = lane & 15, g16 = lane >> 4, h32 = lane >> 5;
+  const int row = r0 + 8 * h32 + (t16 >> 2), col = c0 + 16 * (g16 & 1) + 4 * (t16 & 3);
+  const s16x4 a = lds_read_tr16_b64(tile + (KT ? kx3(row, col) : ux3(row, col)));
+  const s16x4 b = lds_read_tr16_b64(tile + (KT ? kx3(row + 4, col) : ux3(row + 4, col)));
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
 }  // namespace omk
