@@ -221,6 +221,20 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
 #else
 #define OMK_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
+// Sum of each of 4 per-lane values over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15); every lane of the row gets the
+// totals.  GPU: four row rotations per value with the DPP modifier on the add (no LDS crossbar round trips).
+__device__ __forceinline__ void row16_sum4(float (&v)[4]) {
+#ifdef OMK_EMU
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[i] += shfl_xor(v[i], 8); v[i] += shfl_xor(v[i], 4); v[i] += shfl_xor(v[i], 2); v[i] += shfl_xor(v[i], 1); }
+#else
+#define OMK_DPP_ROR(n) \
+  _Pragma("unroll") for (int i = 0; i < 4; i++) \
+    v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x120 + (n), 0xf, 0xf, false))
+  OMK_DPP_ROR(8); OMK_DPP_ROR(4); OMK_DPP_ROR(2); OMK_DPP_ROR(1);
+#undef OMK_DPP_ROR
+#endif
+}
 // float sums take the DPP path (8 VALU ops instead of six ds_bpermute round trips); every lane gets the total
 __device__ __forceinline__ float wave_sum(float v) { return wave_read_lane(wave_incl_scan_add(v), 63); }
 #ifdef OMK_EMU

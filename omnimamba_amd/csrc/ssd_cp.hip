@@ -42,6 +42,7 @@ struct SmemCp {
   uint16_t Cm[TW * 128];
   float c2[2][TW], alpha[2][TW], dts[2][TW], ecm[2][TW], wsc0[2][TW], wsc[2][TW];   // per head, double buffered
   float el[2][TW], wl[2][TW];
+  float g5[4][64 * 4], w5[4][64 * 4];   // G1 and the W accumulator of the fifth tile of the even waves (lane-linear float4): register diet
   float misc[2][8];         // 0 <Graw, S_in>, 1 sum dt w_inter, 2 the same for s < 64, 3 sum_{m >= 64} e_inter, 4 cross block, 5 dD, 6 c_end, 7 dec
 };
 static_assert(sizeof(SmemCp) <= 160 * 1024, "one workgroup per CU");
@@ -79,31 +80,44 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   // ---- per-head staging: x, dy rows (two 16-byte segments per thread each), the two state images (two each)
   u32x4 rx[2], ry[2], rs[2], rg[2];
   float rd0 = 0.f, rd1 = 0.f, rdn = 0.f;
-  auto issue_loads = [&](int h) {
+  constexpr int SW = 7;   // the wave that prepares the per-head scalars: it owns four Phase A tiles, the even waves five
+  auto issue_xy = [&](int h) {
     const uint16_t* Xb = a.X + (int64_t)b * a.xsb + (int64_t)h * a.xsh;
     const uint16_t* Yb = a.DY + (int64_t)b * a.ysb + (int64_t)h * a.ysh;
     const BufRes Xr = make_buf(Xb, (uint32_t)((int64_t)a.L * a.xsl * 2)), Yr = make_buf(Yb, (uint32_t)((int64_t)a.L * a.ysl * 2));
-    const int64_t slot = (((int64_t)b * a.H + h) * a.nW + win) << 13;
+    int tq = tid;
+    OMK_OPAQUE(tq);   // lane offsets are rebuilt per call: hoisted out of the head loop they would sit in registers across it
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int q = tid + 512 * i, row = q >> 3, seg = q & 7;
+      const int q = tq + 512 * i, row = q >> 3, seg = q & 7;
       rx[i] = buf_ld16(Xr, 2u * (uint32_t)((t0 + row) * (int)a.xsl + seg * 8), 0u);
       ry[i] = buf_ld16(Yr, 2u * (uint32_t)((t0 + row) * (int)a.ysl + seg * 8), 0u);
-      rs[i] = ld16(a.Sf + slot + q * 8);
-      rg[i] = ld16(a.Sg + slot + q * 8);
     }
-    if (w == 0) {   // dt' of the window's tokens and of the first token behind it (zeros past the end of the sequence)
+    if (w == SW) {   // dt' of the window's tokens and of the first token behind it (zeros past the end of the sequence)
       const BufRes Dr = make_buf(a.dtp + ((int64_t)b * a.H + h) * a.L, (uint32_t)((int64_t)a.L * 4));
       rd0 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + lane), 0u);
       rd1 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + 64 + lane), 0u);
       rdn = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + TW), 0u);
     }
   };
-  auto commit = [&](int sb) {   // registers -> LDS; dD and < Graw, S_in > fall out of the staged registers
-    float dd = 0.f, gs = 0.f;
+  auto issue_sg = [&](int h) {   // the two state images: issued behind Phase B (the register peak), in flight during Phase A
+    const int64_t slot = (a.ablate & 4) ? 0 : ((((int64_t)b * a.nW + win) * a.H + h) << 13);
+    const BufRes Fr = make_buf(a.Sf + slot, 16384u), Gr = make_buf(a.Sg + slot, 16384u);
+    int tq = tid;
+    OMK_OPAQUE(tq);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int q = tid + 512 * i, row = q >> 3, seg = q & 7;
+      rs[i] = buf_ld16(Fr, 16u * (uint32_t)(tq + 512 * i), 0u);
+      rg[i] = buf_ld16(Gr, 16u * (uint32_t)(tq + 512 * i), 0u);
+    }
+  };
+  auto commit = [&](int sb) {   // registers -> LDS; dD and < Graw, S_in > fall out of the staged registers
+    float dd = 0.f, gs = 0.f;
+    int tq = tid;
+    OMK_OPAQUE(tq);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int q = tq + 512 * i, row = q >> 3, seg = q & 7;
       st16(&sm.X[ux3(row, seg * 8)], rx[i]);
       st16(&sm.DY[ux3(row, seg * 8)], ry[i]);
       st16(&sm.S[q * 8], rs[i]);
@@ -135,37 +149,48 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     if (lane == 0) { sm.misc[sb][6] = cend; sm.misc[sb][7] = dec; }
   };
 
-  // ---- Phase A tiles of this wave: 36 lower-triangular 16 x 16 tiles (m block, s block), tile index w + 8 t
-  int tmb[5], tsb[5];
+  // ---- Phase A tiles of this wave: the 36 lower-triangular 16 x 16 tiles (m block, s block).  Row strips i and 7 - i hold
+  // 9 tiles together; waves 2 p and 2 p + 1 share the pair (p, 7 - p): the even wave takes five tiles of strip 7 - p, the odd one
+  // the rest of it and strip p -- four or five tiles per wave, at most two strips, so the row sums of a strip stay in registers
+  int tmb[5], tsb[5], tsl[5];
+  {
+    const int p = w >> 1, q = w & 1, big = 7 - p;
 #pragma unroll
-  for (int t = 0; t < 5; t++) {
-    const int i = w + 8 * t;
-    int mb = 0;
-    while ((mb + 1) * (mb + 2) / 2 <= i) mb++;
-    tmb[t] = i < 36 ? mb : -1;
-    tsb[t] = i - mb * (mb + 1) / 2;
+    for (int t = 0; t < 5; t++) {
+      if (q == 0) { tmb[t] = big; tsb[t] = t; tsl[t] = 0; }
+      else if (t < 3 - p) { tmb[t] = big; tsb[t] = 5 + t; tsl[t] = 0; }
+      else if (t < 4) { tmb[t] = p; tsb[t] = t - (3 - p); tsl[t] = 1; }
+      else { tmb[t] = -1; tsb[t] = 0; tsl[t] = 0; }
+    }
   }
-  f32x4 Wt[5], g1[5];
+  const int strip0 = 7 - (w >> 1), strip1 = w >> 1;
+  const bool has0 = !((w & 1) && (w >> 1) == 3), has1 = (w & 1) != 0;
+  f32x4 Wt[4], g1[4];   // tiles 0 .. 3; the fifth tile of the even waves keeps both in LDS (sm.w5 / sm.g5)
   f32x16 dCt[2], dBt[2];
 #pragma unroll
-  for (int t = 0; t < 5; t++) { Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int t = 0; t < 4; t++) { Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (!(w & 1)) *reinterpret_cast<f32x4*>(&sm.w5[w >> 1][4 * lane]) = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dCt[j][r] = 0.f; dBt[j][r] = 0.f; }
 
   block_sync();   // zeros and B / C rows visible
-  issue_loads(hbeg);
+  issue_xy(hbeg);
+  issue_sg(hbeg);
   commit(0);
-  if (w == 0) scalars(hbeg, 0);
+  if (w == SW) scalars(hbeg, 0);
   // G1[m][s] = C_m . B_s of this wave's tiles (the same for every head)
 #pragma unroll
   for (int t = 0; t < 5; t++) {
     if (tmb[t] < 0) continue;
     const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
+    f32x4 gg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
-      g1[t] = mfma16x16x32_bf16(as_s16x8(ld16(&sm.Cm[kx3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.Bm[kx3(s0 + t16, 32 * ks + 8 * g16)])), g1[t]);
+      gg = mfma16x16x32_bf16(as_s16x8(ld16(&sm.Cm[kx3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.Bm[kx3(s0 + t16, 32 * ks + 8 * g16)])), gg);
+    if (t < 4) g1[t < 4 ? t : 0] = gg;
+    else *reinterpret_cast<f32x4*>(&sm.g5[w >> 1][4 * lane]) = gg;
   }
   block_sync();   // head 0 staged
 
@@ -174,17 +199,64 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   for (int hi = 0; hi < hps; hi++) {
     const int h = hbeg + hi, sb = hi & 1;
     const bool more = hi + 1 < hps;
-    if (more) issue_loads(h + 1);
+    // (lane bases of the swizzled tiles; tile row blocks, k steps and column blocks enter as uniform adds / XORs on top of them)
+    int oA = ux3(t16, 8 * g16), oB = ux3(mrow, 8 * h32);
+    int oT0 = kx3(8 * h32 + (t16 >> 2), 16 * (g16 & 1) + 4 * (t16 & 3)), oT1 = kx3(8 * h32 + (t16 >> 2) + 4, 16 * (g16 & 1) + 4 * (t16 & 3));
+    int oC = kx3(mrow, 4 * h32);
+    OMK_OPAQUE(oA); OMK_OPAQUE(oB); OMK_OPAQUE(oT0); OMK_OPAQUE(oT1); OMK_OPAQUE(oC);
+    // ---- Phase B: inter-window terms; this wave owns rows n of two 32-blocks (2 nh, 2 nh + 1) x tokens 32 mbB ..
+    float ep = 0.f, wp = 0.f;
+    const float ecm_m = sm.ecm[sb][mrow], wsc_s = sm.wsc[sb][mrow], wsc0_s = sm.wsc0[sb][mrow], dts_s = sm.dts[sb][mrow];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (a.ablate & 2) continue;
+      const int nbx = 32 * (2 * nh + j);   // column block of the state images: an XOR on the swizzled segment index
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const s16x4 f0 = lds_read_tr16_b64(&sm.S[(oT0 + 2048 * ks) ^ nbx]), f1 = lds_read_tr16_b64(&sm.S[(oT1 + 2048 * ks) ^ nbx]);
+        const s16x8 fa = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        acc = mfma32x32x16_bf16(fa, as_s16x8(ld16(&sm.DY[oB ^ (16 * ks)])), acc);
+      }
+      // acc[r] = (S_in^T dy_m)[n], n = 32 nb + 8 (r >> 2) + 4 h32 + (r & 3), m = mrow
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32x2 cv = *reinterpret_cast<const u32x2*>(&sm.Cm[oC ^ nbx ^ (8 * q)]);
+        const float c4[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ep += acc[4 * q + i] * c4[i]; dCt[j][4 * q + i] += ecm_m * acc[4 * q + i]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const s16x4 f0 = lds_read_tr16_b64(&sm.Gt[(oT0 + 2048 * ks) ^ nbx]), f1 = lds_read_tr16_b64(&sm.Gt[(oT1 + 2048 * ks) ^ nbx]);
+        const s16x8 fa = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        acc = mfma32x32x16_bf16(fa, as_s16x8(ld16(&sm.X[oB ^ (16 * ks)])), acc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32x2 bv = *reinterpret_cast<const u32x2*>(&sm.Bm[oC ^ nbx ^ (8 * q)]);
+        const float b4[4] = {bf_lo(bv[0]), bf_hi(bv[0]), bf_lo(bv[1]), bf_hi(bv[1])};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
+      }
+    }
+    // next head's rows and state images: issued behind Phase B (the register peak of the loop), in flight during Phase A
+    if (more && !(a.ablate & 8)) { issue_xy(h + 1); issue_sg(h + 1); }
     // ---- Phase A: intra-window terms
     float qm = 0.f;
+    float ra0[4] = {0.f, 0.f, 0.f, 0.f}, ra1[4] = {0.f, 0.f, 0.f, 0.f};   // e_intra row sums of the wave's two strips
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-      if (tmb[t] < 0) continue;
+      if (tmb[t] < 0 || (a.ablate & 1)) continue;
       const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
-        z = mfma16x16x32_bf16(as_s16x8(ld16(&sm.DY[ux3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.X[ux3(s0 + t16, 32 * ks + 8 * g16)])), z);
+        z = mfma16x16x32_bf16(as_s16x8(ld16(&sm.DY[(oA + 64 * m0) ^ (32 * ks)])), as_s16x8(ld16(&sm.X[(oA + 64 * s0) ^ (32 * ks)])), z);
       // z[r] = dy_m . x_s, m = m0 + 4 g16 + r, s = s0 + t16
       const float css = sm.c2[sb][s0 + t16], dss = sm.dts[sb][s0 + t16];
       f32x4 t2;
@@ -200,49 +272,30 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
           t2[r] = (4 * g16 + r >= t16) ? z[r] * exp2_fast(arg < 0.f ? arg : 0.f) : 0.f;
         }
       }
-      Wt[t] += t2 * dss;
-      const f32x4 d = t2 * g1[t];
-      float col = (d[0] + d[1]) + (d[2] + d[3]);            // w_intra: sum over m
-      col += shfl_xor(col, 16);
-      col += shfl_xor(col, 32);
-      if (g16 == 0) lds_add_f32(&sm.wl[sb][s0 + t16], col);
-      float rv[4] = {d[0] * dss, d[1] * dss, d[2] * dss, d[3] * dss};   // e_intra: sum over s of dt_s T (C . B)
-      if (m0 >= 64 && s0 < 64) qm += (rv[0] + rv[1]) + (rv[2] + rv[3]);
-      WaveMultiSum<4, 8>::run(rv, lane);                     // lane keeps row r = (t16 >> 2) & 3, summed over its 16 lanes
-      if ((t16 & 3) == 0) lds_add_f32(&sm.el[sb][m0 + 4 * g16 + ((t16 >> 2) & 3)], rv[0]);
+      f32x4 gg;
+      if (t < 4) { Wt[t < 4 ? t : 0] += t2 * dss; gg = g1[t < 4 ? t : 0]; }
+      else {
+        f32x4* wp5 = reinterpret_cast<f32x4*>(&sm.w5[w >> 1][4 * lane]);
+        *wp5 = *wp5 + t2 * dss;
+        gg = *reinterpret_cast<const f32x4*>(&sm.g5[w >> 1][4 * lane]);
+      }
+      const f32x4 d = t2 * gg;
+      // w_intra: sum over m -- the four lanes that hold the other rows of this column add into the same word
+      lds_add_f32(&sm.wl[sb][s0 + t16], (d[0] + d[1]) + (d[2] + d[3]));
+      const f32x4 dv = d * dss;                               // e_intra: sum over s of dt_s T (C . B), kept per strip
+      if (m0 >= 64 && s0 < 64) qm += (dv[0] + dv[1]) + (dv[2] + dv[3]);
+      if (tsl[t]) { ra1[0] += dv[0]; ra1[1] += dv[1]; ra1[2] += dv[2]; ra1[3] += dv[3]; }
+      else { ra0[0] += dv[0]; ra0[1] += dv[1]; ra0[2] += dv[2]; ra0[3] += dv[3]; }
     }
-    // ---- Phase B: inter-window terms; this wave owns rows n of two 32-blocks (2 nh, 2 nh + 1) x tokens 32 mbB ..
-    float ep = 0.f, wp = 0.f;
-    const float ecm_m = sm.ecm[sb][mrow], wsc_s = sm.wsc[sb][mrow], wsc0_s = sm.wsc0[sb][mrow], dts_s = sm.dts[sb][mrow];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int nb = 2 * nh + j;
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++)
-        acc = mfma32x32x16_bf16(tr_frag3<true>(sm.S, 16 * ks, 32 * nb, lane), as_s16x8(ld16(&sm.DY[ux3(mrow, 16 * ks + 8 * h32)])), acc);
-      // acc[r] = (S_in^T dy_m)[n], n = 32 nb + 8 (r >> 2) + 4 h32 + (r & 3), m = mrow
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const u32x2 cv = *reinterpret_cast<const u32x2*>(&sm.Cm[kx3(mrow, 32 * nb + 8 * q + 4 * h32)]);
-        const float c4[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
-#pragma unroll
-        for (int i = 0; i < 4; i++) { ep += acc[4 * q + i] * c4[i]; dCt[j][4 * q + i] += ecm_m * acc[4 * q + i]; }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++)
-        acc = mfma32x32x16_bf16(tr_frag3<true>(sm.Gt, 16 * ks, 32 * nb, lane), as_s16x8(ld16(&sm.X[ux3(mrow, 16 * ks + 8 * h32)])), acc);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const u32x2 bv = *reinterpret_cast<const u32x2*>(&sm.Bm[kx3(mrow, 32 * nb + 8 * q + 4 * h32)]);
-        const float b4[4] = {bf_lo(bv[0]), bf_hi(bv[0]), bf_lo(bv[1]), bf_hi(bv[1])};
-#pragma unroll
-        for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
-      }
+    if (has0 && !(a.ablate & 1)) {
+      row16_sum4(ra0);
+      const float v = t16 == 0 ? ra0[0] : (t16 == 1 ? ra0[1] : (t16 == 2 ? ra0[2] : ra0[3]));
+      if (t16 < 4) lds_add_f32(&sm.el[sb][16 * strip0 + 4 * g16 + t16], v);
+    }
+    if (has1 && !(a.ablate & 1)) {
+      row16_sum4(ra1);
+      const float v = t16 == 0 ? ra1[0] : (t16 == 1 ? ra1[1] : (t16 == 2 ? ra1[2] : ra1[3]));
+      if (t16 < 4) lds_add_f32(&sm.el[sb][16 * strip1 + 4 * g16 + t16], v);
     }
     ep += shfl_xor(ep, 32);
     wp += shfl_xor(wp, 32);
@@ -258,16 +311,20 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         lds_add_f32(&sm.misc[sb][4], s_qm);
       }
     }
-    if (w == 0 && more) scalars(h + 1, sb ^ 1);
+    if (w == SW && more) scalars(h + 1, sb ^ 1);
     block_sync();   // every read of this head's tiles and every add into its scalars is done
     // ---- token scalars, restart values and dD of this head; next head's tiles
     {
       const int64_t bh = (int64_t)b * a.H + h;
-      if (tid < TW) {
-        const float ev = sm.el[sb][tid], wv = sm.wl[sb][tid];
-        sm.el[sb][tid] = 0.f; sm.wl[sb][tid] = 0.f;
-        if (t0 + tid < a.L) { a.e[bh * a.L + t0 + tid] = ev; a.wsum[bh * a.L + t0 + tid] = wv; }
-      } else if (tid == TW) {
+      int tq = tid;
+      OMK_OPAQUE(tq);
+      if (tq < TW) {   // (buffer stores: rows past the end of the sequence are dropped by the range check)
+        const BufRes Er = make_buf(a.e + bh * a.L, (uint32_t)((int64_t)a.L * 4)), Wr = make_buf(a.wsum + bh * a.L, (uint32_t)((int64_t)a.L * 4));
+        const float ev = sm.el[sb][tq], wv = sm.wl[sb][tq];
+        sm.el[sb][tq] = 0.f; sm.wl[sb][tq] = 0.f;
+        buf_st_f32(Er, ev, 4u * (uint32_t)(t0 + tq), 0u);
+        buf_st_f32(Wr, wv, 4u * (uint32_t)(t0 + tq), 0u);
+      } else if (tq == TW) {
         const float qb = exp2_fast(sm.misc[sb][6]) * sm.misc[sb][7] * sm.misc[sb][0];
         const float q_end = qb + sm.misc[sb][1];
         const float q_mid = qb + sm.misc[sb][2] + sm.misc[sb][3] + sm.misc[sb][4];
@@ -278,12 +335,13 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         for (int i = 0; i < 6; i++) sm.misc[sb][i] = 0.f;
       }
     }
-    if (more) commit(sb ^ 1);
+    if (more && !(a.ablate & 16)) commit(sb ^ 1);
     block_sync();   // next head staged
   }
 
   // ---- W (sum over the heads, fp32 registers) -> bf16 tile [m][s] in LDS;  dC^T += B^T W^T,  dB^T += C^T W
   // (W as a bf16 hi + lo pair: one rounding of W would sit on top of the output rounding of dB / dC -- 1.7e-3 -> 2.3e-3 measured)
+  const f32x4 w5r = *reinterpret_cast<const f32x4*>(&sm.w5[w >> 1][4 * lane]);
   uint16_t* Wl = sm.X;        // 32 KB: X | DY
   uint16_t* Wlo = sm.S;       // 32 KB: S | Gt
   {
@@ -298,9 +356,10 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const uint16_t hi = f32_to_bf16(Wt[t][r]);
+      const float wv = t < 4 ? Wt[t < 4 ? t : 0][r] : w5r[r];
+      const uint16_t hi = f32_to_bf16(wv);
       Wl[kx3(m0 + 4 * g16 + r, s0 + t16)] = hi;
-      Wlo[kx3(m0 + 4 * g16 + r, s0 + t16)] = f32_to_bf16(Wt[t][r] - bf16_to_f32(hi));
+      Wlo[kx3(m0 + 4 * g16 + r, s0 + t16)] = f32_to_bf16(wv - bf16_to_f32(hi));
     }
   }
   block_sync();
@@ -368,7 +427,9 @@ int ssd_cp_heads_split(int B, int L, int H, int G) {
   return nhs;
 }
 
-int ssd_cp_launch(const CpArgs& a, omk_stream stream) {
+int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
+  CpArgs a = a0;
+  if (const char* e = getenv("OMK_CP_ABLATE")) a.ablate = atoi(e);
   const size_t smem = sizeof(SmemCp);
   if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
   dim3 grid((unsigned)((int64_t)a.B * a.G * a.nW * a.nhs)), block(512);

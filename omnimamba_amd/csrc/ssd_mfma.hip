@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       const int cid = rev ? nC - 1 - c : c;
       const bool here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
       if (here) {
-        uint16_t* dp = a.dump + ((bh * a.dump_nw + (cid >> 1)) << 13);
+        uint16_t* dp = a.dump + ((((int64_t)b * a.dump_nw + (cid >> 1)) * a.H + h) << 13);   // [b][window][h]: a window's heads are contiguous
 #pragma unroll
         for (int i = 0; i < 4; i++) st16(dp + (tid + 256 * i) * 8, ld16(&sm.S[(tid + 256 * i) * 8]));
         if (STATE) block_sync();   // (the scan proper has barrier X between these reads and the next publish)
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     }
     PT3(4);
     // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
-    if ((!STATE || spass) && !(abl & 8)) publish_state();
+    // (the state-only dump pass publishes only what the next iteration dumps: forward, the state in front of an even chunk)
+    if ((!STATE || (spass && (rev ? ((nC - 2 - c) & 1) != 0 : ((c + 1) & 1) == 0))) && !(abl & 8)) publish_state();
     commit(nxt);
     if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);

@@ -52,7 +52,7 @@ struct GScan {
   int seg_ready;                                                 // seg already holds the folded START states (slot j - 1 = segment j)
   int seg_fmt;                                                   // element order of seg: 0 = ssd_mfma_a3 accumulator order, 1 = logical [u][k] of the class A state
   // class A (MFMA): bf16 images of the carried state at the 128-token window boundaries, for the chunk-parallel backward
-  // (ssd_cp.hip): slot (b * H + h) * dump_nw + w holds the state in front of window w in scan direction -- forward: the state
+  // (ssd_cp.hip): slot (b * dump_nw + w) * H + h holds the state in front of window w in scan direction -- forward: the state
   // BEFORE token 128 w; reverse: the adjoint state at the first token BEHIND window w (dfinal_states for the last one) -- as
   // the raw 16 KB LDS image [u][k] (kx3 swizzle, ssd_tiles.h) the kernel publishes for its own Q . S product.
   uint16_t* dump; int dump_nw;
@@ -116,6 +116,7 @@ struct CpArgs {
   float *pB, *pC;                                                 // fp32 partials [nhs][B][L][G][128]
   void *dB, *dC; int64_t dbsb, dbsl, dbsg, dcsb, dcsl, dcsg; int dB_dt, dC_dt;
   int B, L, H, G, nW, nhs;
+  int ablate;   // developer only (OMK_CP_ABLATE): phases to skip, wrong results
 };
 int ssd_cp_heads_split(int B, int L, int H, int G);
 int ssd_cp_launch(const CpArgs& a, omk_stream stream);

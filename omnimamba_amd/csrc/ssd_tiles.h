@@ -49,6 +49,14 @@ __device__ __forceinline__ float buf_ld_f32(const BufRes& b, uint32_t voff, uint
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0));
 #endif
 }
+__device__ __forceinline__ void buf_st_f32(const BufRes& b, float v, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o < b.nbytes) *reinterpret_cast<float*>(const_cast<char*>(b.base) + o) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b.r, (int)voff, (int)soff, 0);
+#endif
+}
 __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
   const uint32_t o = voff + soff;
