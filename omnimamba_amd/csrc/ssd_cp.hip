@@ -41,7 +41,9 @@ struct SmemCp {
   uint16_t Bm[TW * 128];    // [t][n], kx3 swizzle
   uint16_t Cm[TW * 128];
   float c2[2][TW], alpha[2][TW], dts[2][TW], ecm[2][TW], wsc0[2][TW], wsc[2][TW];   // per head, double buffered
-  float el[2][TW], wl[2][TW];
+  // token-scalar pieces, plain stores into per-producer slots (LDS float atomics cost ~3 cycles per LANE: the first version spent
+  // 10 k of its 19 k cycles per head in them): column sums per Phase A tile, row sums per (wave, strip), Phase B halves per n half
+  float colA[2][36][16], rowA[2][8][2][16], eI[2][2][TW], wI[2][2][TW], mw[2][8][4];
   float g5[4][64 * 4], w5[4][64 * 4];   // G1 and the W accumulator of the fifth tile of the even waves (lane-linear float4): register diet
   float misc[2][8];         // 0 <Graw, S_in>, 1 sum dt w_inter, 2 the same for s < 64, 3 sum_{m >= 64} e_inter, 4 cross block, 5 dD, 6 c_end, 7 dec
 };
@@ -63,7 +65,6 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   const int nT = (a.L + 63) / 64;
 
   // ---- zero the accumulating scalars (both buffers)
-  if (tid < 2 * TW) { (&sm.el[0][0])[tid] = 0.f; (&sm.wl[0][0])[tid] = 0.f; }
   if (tid < 16) (&sm.misc[0][0])[tid] = 0.f;
   // ---- the window's B / C rows (shared by every head of the group)
   {
@@ -196,9 +197,38 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
 
   const int mbB = w & 3, nh = w >> 2;
   const int mrow = 32 * mbB + l31;
+  // token scalars, restart values and dD of a finished head from the slots its waves filled (buffer sb): runs while the NEXT head
+  // is being computed (waves 3 and 5: tokens; lane 0 of the scalar wave, ahead of its own next write of c_end / dec: the restart values), so nothing of it sits between the two barriers of a head
+  auto readout = [&](int h, int sb) {
+    if (a.ablate & 64) return;
+    const int64_t bh = (int64_t)b * a.H + h;
+    if (w == 3 || w == 5) {
+      int m = (w == 3 ? 0 : 64) + lane;
+      OMK_OPAQUE(m);
+      const int st = m >> 4, i = m & 15;
+      float ev = sm.eI[sb][0][m] + sm.eI[sb][1][m], wv = sm.wI[sb][0][m] + sm.wI[sb][1][m];
+      if (st >= 4) ev += sm.rowA[sb][2 * (7 - st)][0][i] + sm.rowA[sb][2 * (7 - st) + 1][0][i];
+      else ev += sm.rowA[sb][2 * st + 1][1][i];
+      for (int mb = st; mb < 8; mb++) wv += sm.colA[sb][mb * (mb + 1) / 2 + st][i];
+      // (buffer stores: rows past the end of the sequence are dropped by the range check)
+      const BufRes Er = make_buf(a.e + bh * a.L, (uint32_t)((int64_t)a.L * 4)), Wr = make_buf(a.wsum + bh * a.L, (uint32_t)((int64_t)a.L * 4));
+      buf_st_f32(Er, ev, 4u * (uint32_t)(t0 + m), 0u);
+      buf_st_f32(Wr, wv, 4u * (uint32_t)(t0 + m), 0u);
+    } else if (w == SW && lane == 0) {
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+      for (int k = 0; k < 8; k++) { s1 += sm.mw[sb][k][0]; s2 += sm.mw[sb][k][1]; s3 += sm.mw[sb][k][2]; s4 += sm.mw[sb][k][3]; }
+      const float qb = exp2_fast(sm.misc[sb][6]) * sm.misc[sb][7] * sm.misc[sb][0];
+      const float q_end = qb + s1, q_mid = qb + s2 + s3 + s4;
+      if (2 * win + 1 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 1] = q_mid;
+      if (2 * win + 2 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 2] = q_end;
+      if (a.dD) atomic_add_f32(a.dD + (int64_t)h * a.dDsh, sm.misc[sb][5]);
+      sm.misc[sb][0] = 0.f; sm.misc[sb][5] = 0.f;
+    }
+  };
   for (int hi = 0; hi < hps; hi++) {
     const int h = hbeg + hi, sb = hi & 1;
     const bool more = hi + 1 < hps;
+    if (hi > 0) readout(h - 1, sb ^ 1);
     // (lane bases of the swizzled tiles; tile row blocks, k steps and column blocks enter as uniform adds / XORs on top of them)
     int oA = ux3(t16, 8 * g16), oB = ux3(mrow, 8 * h32);
     int oT0 = kx3(8 * h32 + (t16 >> 2), 16 * (g16 & 1) + 4 * (t16 & 3)), oT1 = kx3(8 * h32 + (t16 >> 2) + 4, 16 * (g16 & 1) + 4 * (t16 & 3));
@@ -249,6 +279,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     // ---- Phase A: intra-window terms
     float qm = 0.f;
     float ra0[4] = {0.f, 0.f, 0.f, 0.f}, ra1[4] = {0.f, 0.f, 0.f, 0.f};   // e_intra row sums of the wave's two strips
+    float colv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                              // w_intra column sums of the wave's tiles (this lane's 4 rows)
 #pragma unroll
     for (int t = 0; t < 5; t++) {
       if (tmb[t] < 0 || (a.ablate & 1)) continue;
@@ -280,64 +311,43 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         gg = *reinterpret_cast<const f32x4*>(&sm.g5[w >> 1][4 * lane]);
       }
       const f32x4 d = t2 * gg;
-      // w_intra: sum over m -- the four lanes that hold the other rows of this column add into the same word
-      lds_add_f32(&sm.wl[sb][s0 + t16], (d[0] + d[1]) + (d[2] + d[3]));
+      colv[t] = (d[0] + d[1]) + (d[2] + d[3]);               // w_intra: sum over m (this lane's four rows)
       const f32x4 dv = d * dss;                               // e_intra: sum over s of dt_s T (C . B), kept per strip
       if (m0 >= 64 && s0 < 64) qm += (dv[0] + dv[1]) + (dv[2] + dv[3]);
       if (tsl[t]) { ra1[0] += dv[0]; ra1[1] += dv[1]; ra1[2] += dv[2]; ra1[3] += dv[3]; }
       else { ra0[0] += dv[0]; ra0[1] += dv[1]; ra0[2] += dv[2]; ra0[3] += dv[3]; }
     }
-    if (has0 && !(a.ablate & 1)) {
+    if (!(a.ablate & 1)) {
+      // column sums: the other twelve rows of a tile sit in the lanes 16, 32, 48 further on
+#pragma unroll
+      for (int t = 0; t < 5; t++) colv[t] += shfl_xor(colv[t], 16);
+#pragma unroll
+      for (int t = 0; t < 5; t++) colv[t] += shfl_xor(colv[t], 32);
+#pragma unroll
+      for (int t = 0; t < 5; t++)
+        if (tmb[t] >= 0 && g16 == 0) sm.colA[sb][tmb[t] * (tmb[t] + 1) / 2 + tsb[t]][t16] = colv[t];
+      // row sums of the two strips (zeros where the wave has no tile of a strip: every slot is rewritten for every head)
       row16_sum4(ra0);
-      const float v = t16 == 0 ? ra0[0] : (t16 == 1 ? ra0[1] : (t16 == 2 ? ra0[2] : ra0[3]));
-      if (t16 < 4) lds_add_f32(&sm.el[sb][16 * strip0 + 4 * g16 + t16], v);
-    }
-    if (has1 && !(a.ablate & 1)) {
       row16_sum4(ra1);
-      const float v = t16 == 0 ? ra1[0] : (t16 == 1 ? ra1[1] : (t16 == 2 ? ra1[2] : ra1[3]));
-      if (t16 < 4) lds_add_f32(&sm.el[sb][16 * strip1 + 4 * g16 + t16], v);
+      const float v0 = t16 == 0 ? ra0[0] : (t16 == 1 ? ra0[1] : (t16 == 2 ? ra0[2] : ra0[3]));
+      const float v1 = t16 == 0 ? ra1[0] : (t16 == 1 ? ra1[1] : (t16 == 2 ? ra1[2] : ra1[3]));
+      if (t16 < 4) { sm.rowA[sb][w][0][4 * g16 + t16] = v0; sm.rowA[sb][w][1][4 * g16 + t16] = v1; }
     }
     ep += shfl_xor(ep, 32);
     wp += shfl_xor(wp, 32);
-    {
+    if (!(a.ablate & 128)) {
       const float ei = h32 == 0 ? ecm_m * ep : 0.f, wi = h32 == 0 ? wsc0_s * wp : 0.f;   // this wave's n half
-      if (h32 == 0) { lds_add_f32(&sm.el[sb][mrow], ei); lds_add_f32(&sm.wl[sb][mrow], wi); }
+      if (h32 == 0) { sm.eI[sb][nh][mrow] = ei; sm.wI[sb][nh][mrow] = wi; }
       const float dtw = dts_s * wi;
       const float s_all = wave_sum(dtw), s_eh = wave_sum(ei), s_qm = wave_sum(qm);
-      if (lane == 0) {
-        lds_add_f32(&sm.misc[sb][1], s_all);
-        if (mbB < 2) lds_add_f32(&sm.misc[sb][2], s_all);
-        else lds_add_f32(&sm.misc[sb][3], s_eh);
-        lds_add_f32(&sm.misc[sb][4], s_qm);
-      }
+      if (lane == 0) *reinterpret_cast<f32x4*>(&sm.mw[sb][w][0]) = f32x4{s_all, mbB < 2 ? s_all : 0.f, mbB < 2 ? 0.f : s_eh, s_qm};
     }
-    if (w == SW && more) scalars(h + 1, sb ^ 1);
-    block_sync();   // every read of this head's tiles and every add into its scalars is done
-    // ---- token scalars, restart values and dD of this head; next head's tiles
-    {
-      const int64_t bh = (int64_t)b * a.H + h;
-      int tq = tid;
-      OMK_OPAQUE(tq);
-      if (tq < TW) {   // (buffer stores: rows past the end of the sequence are dropped by the range check)
-        const BufRes Er = make_buf(a.e + bh * a.L, (uint32_t)((int64_t)a.L * 4)), Wr = make_buf(a.wsum + bh * a.L, (uint32_t)((int64_t)a.L * 4));
-        const float ev = sm.el[sb][tq], wv = sm.wl[sb][tq];
-        sm.el[sb][tq] = 0.f; sm.wl[sb][tq] = 0.f;
-        buf_st_f32(Er, ev, 4u * (uint32_t)(t0 + tq), 0u);
-        buf_st_f32(Wr, wv, 4u * (uint32_t)(t0 + tq), 0u);
-      } else if (tq == TW) {
-        const float qb = exp2_fast(sm.misc[sb][6]) * sm.misc[sb][7] * sm.misc[sb][0];
-        const float q_end = qb + sm.misc[sb][1];
-        const float q_mid = qb + sm.misc[sb][2] + sm.misc[sb][3] + sm.misc[sb][4];
-        if (2 * win + 1 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 1] = q_mid;
-        if (2 * win + 2 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 2] = q_end;
-        if (a.dD) atomic_add_f32(a.dD + (int64_t)h * a.dDsh, sm.misc[sb][5]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) sm.misc[sb][i] = 0.f;
-      }
-    }
+    if (w == SW && more && !(a.ablate & 32)) scalars(h + 1, sb ^ 1);
+    block_sync();   // every read of this head's tiles is done, its token-scalar slots are complete
     if (more && !(a.ablate & 16)) commit(sb ^ 1);
     block_sync();   // next head staged
   }
+  readout(hbeg + hps - 1, (hps - 1) & 1);
 
   // ---- W (sum over the heads, fp32 registers) -> bf16 tile [m][s] in LDS;  dC^T += B^T W^T,  dB^T += C^T W
   // (W as a bf16 hi + lo pair: one rounding of W would sit on top of the output rounding of dB / dC -- 1.7e-3 -> 2.3e-3 measured)
