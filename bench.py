@@ -410,7 +410,7 @@ def main():
                          "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
                          "traffic": traffic["fwd"][0], "traffic_source": traffic["fwd"][1],
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
-            "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + the backward scans + finish)",
+            "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + state-only forward pass + dx scan with window-state dumps + ssd_cp_kernel + folds + finish)",
                              "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
                              "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1],
                              "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": round(ms_b, 4), "launches_timed": n_b},

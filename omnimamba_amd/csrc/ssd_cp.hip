@@ -228,6 +228,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   for (int hi = 0; hi < hps; hi++) {
     const int h = hbeg + hi, sb = hi & 1;
     const bool more = hi + 1 < hps;
+    if (more && !(a.ablate & 8)) { issue_xy(h + 1); issue_sg(h + 1); }   // next head: in flight during both phases
     if (hi > 0) readout(h - 1, sb ^ 1);
     // (lane bases of the swizzled tiles; tile row blocks, k steps and column blocks enter as uniform adds / XORs on top of them)
     int oA = ux3(t16, 8 * g16), oB = ux3(mrow, 8 * h32);
@@ -274,8 +275,6 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
       }
     }
-    // next head's rows and state images: issued behind Phase B (the register peak of the loop), in flight during Phase A
-    if (more && !(a.ablate & 8)) { issue_xy(h + 1); issue_sg(h + 1); }
     // ---- Phase A: intra-window terms
     float qm = 0.f;
     float ra0[4] = {0.f, 0.f, 0.f, 0.f}, ra1[4] = {0.f, 0.f, 0.f, 0.f};   // e_intra row sums of the wave's two strips

@@ -1014,7 +1014,8 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
 #define OMK_A3K(MODE_, EX_, ST_, DF_, KH_, GRID_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), GRID_, block, smem, stream, a); } while (0)
-  static const bool khilo = [] { const char* e = getenv("OMK_SSD_KHILO"); return e ? e[0] == '1' : OMK_SSD_KHILO_DEFAULT != 0; }();
+  const char* khe = getenv("OMK_SSD_KHILO");
+  const bool khilo = khe ? khe[0] == '1' : OMK_SSD_KHILO_DEFAULT != 0;
 #define OMK_A3(MODE_, EX_, ST_, DF_, GRID_) do { \
     if (MODE_ == GS_Y && khilo) OMK_A3K(MODE_, EX_, ST_, DF_, (MODE_ == GS_Y), GRID_); else OMK_A3K(MODE_, EX_, ST_, DF_, false, GRID_); } while (0)
   if (a.nseg > 1 && !a.seg_ready) {

@@ -80,24 +80,48 @@ def _mfma_case(dev, Bsz, L, H, G, with_z, with_init, seed=11):
     return out, out_x, fin, outg, fing, o0, f0, o32
 
 
-@pytest.mark.parametrize("L,H,G,with_z,with_init,arith", [(150, 2, 1, False, False, 1e-3), (64, 4, 2, True, True, 1.5e-3),
-                                                                 (200, 2, 1, True, True, 1.5e-3)])
-def test_ssd_mfma_fwd(dev, L, H, G, with_z, with_init, arith):
-    """bf16 MFMA path vs the fp32 oracle on identical bf16 inputs.  Tolerance: rel-L2 <= sqrt(arith^2 + q^2) where q is
-    the unavoidable bf16 quantisation of the output itself (measured on the oracle) and `arith` the arithmetic error
-    budget: 1e-3 (north star) from a zero state; 1.5e-3 for the stress cases that start from an O(1) random
-    initial_states, where the bf16 copy of S_in fed to the C.S MFMA (the rounding point upstream has too) dominates."""
+def _budgets(L, H, G, with_z, with_init, seed=11):
+    """Per-case bounds under the rule of tests/tolerances.py (same generator draws as _mfma_case)."""
+    from tolerances import forward_budget
+    P, N = 64, 128
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=seed)
+    A = -(torch.rand(H) * 15 + 1)
+    dtb = torch.randn(H) * 0.5 - 3.0
+    _, _, by, bf, up = forward_budget(x, dt, A, Bm, Cm, D=D, z=z if with_z else None, dt_bias=dtb, initial_states=init if with_init else None,
+                                      dt_softplus=True)
+    return by, bf, up
+
+
+@pytest.mark.parametrize("L,H,G,with_z,with_init", [(150, 2, 1, False, False), (64, 4, 2, True, True), (200, 2, 1, True, True)])
+def test_ssd_mfma_fwd(dev, L, H, G, with_z, with_init):
+    """bf16 MFMA path vs the fp32 / fp64 oracle on identical bf16 inputs.  Tolerance (tests/tolerances.py): rel-L2 <=
+    sqrt(arith^2 + q^2), q the unavoidable bf16 quantisation of the output itself (measured on the oracle), arith =
+    max(1e-3 north star, the arithmetic error of the reference pipeline's own rounding points on the same inputs): from an O(1)
+    random initial_states the bf16 copy of S_in fed to the C . S MFMA -- upstream rounds there too -- costs both ~1.2e-3."""
+    st = torch.random.get_rng_state()
+    by, bf, up = _budgets(L, H, G, with_z, with_init)
+    torch.random.set_rng_state(st)
     out, out_x, fin, outg, fing, o0, f0, o32 = _mfma_case(dev, 1, L, H, G, with_z, with_init)
     q = rel(o32.bfloat16().float(), o32)
-    tol = (arith ** 2 + q ** 2) ** 0.5
+    tol = (by ** 2 + q ** 2) ** 0.5
     e = rel(out.float(), o32)
-    assert e < tol, (e, q, tol)
-    # the state-update operand (dt * decay * x) is rounded to bf16 once (as upstream's chunk-state kernel does):
-    # one bf16 rounding = 1.65e-3 rms on the final state; its effect on y is < 3e-4 and inside the 1e-3 budget above
-    assert rel(fin, f0) < 2.5e-3
+    assert e < tol, (e, q, tol, up)
+    # final state: the w_l K_l operand of the state update is rounded to bf16 once (as upstream's chunk-state kernel does) unless
+    # OMK_SSD_KHILO / OMK_SSD_PRECISE ask for the hi + lo pair
+    assert rel(fin, f0) < bf, (rel(fin, f0), bf, up)
     assert rel(outg.float(), o32) < tol and rel(fing, f0) < 1e-4
     if with_z:
         assert out_x is not None
+
+
+def test_ssd_khilo_keeps_the_carried_state_exact(dev, monkeypatch):
+    """OMK_SSD_KHILO=1: the w_l K_l operand of the state update as a bf16 hi + lo pair -- the carried state (and final_states) no
+    longer carries one bf16 rounding per chunk: 1.7e-3 -> ~1e-5 (+ 10 % scan time on the MI355X, hence opt-in)."""
+    monkeypatch.setenv("OMK_SSD_KHILO", "1")
+    out, _, fin, _, _, o0, f0, o32 = _mfma_case(dev, 1, 200, 2, 1, False, True, seed=23)
+    assert rel(fin, f0) < 1e-4, rel(fin, f0)
+    q = rel(o32.bfloat16().float(), o32)
+    assert rel(out.float(), o32) < (1.2e-3 ** 2 + q ** 2) ** 0.5
 
 
 @pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(200, 2, 1, False, False, 1), (330, 2, 2, True, True, 2)])
@@ -110,9 +134,11 @@ def test_ssd_mfma_fwd_split_sequence(dev, monkeypatch, L, H, G, with_z, with_ini
     monkeypatch.setenv("OMK_SSD_NO_SPLIT", "1")
     torch.manual_seed(21)
     out1, _, fin1, _, _, _, _, _ = _mfma_case(dev, 1, L, H, G, with_z, with_init)
+    torch.manual_seed(21)
+    by, bf, up = _budgets(L, H, G, with_z, with_init)
     q = rel(o32.bfloat16().float(), o32)
-    tol = (1.5e-3 ** 2 + q ** 2) ** 0.5
-    assert rel(out.float(), o32) < tol and rel(fin, f0) < 2.5e-3
+    tol = (by ** 2 + q ** 2) ** 0.5
+    assert rel(out.float(), o32) < tol and rel(fin, f0) < bf, (rel(out.float(), o32), tol, rel(fin, f0), bf, up)
     assert rel(out.float(), out1.float().cpu()) < 2e-3 and rel(fin, fin1.cpu()) < 1e-5
 
 
@@ -136,9 +162,13 @@ def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
     y0, f0 = O.ssd_ref_sequential(dl[0], dl[1], dl[2], dl[3], dl[4], D=dl[5], dt_bias=dl[6], initial_states=dl[7],
                                   dt_softplus=True, return_final_states=True, compute_dtype=torch.float64)
     torch.autograd.backward([y0, f0], [gy.double(), gf.double()])
+    from tolerances import forward_budget
+    _, _, by, bf, up = forward_budget(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, initial_states=init, dt_softplus=True)
     q = rel(y0.float().bfloat16().float(), y0.float())
-    assert rel(y.float().cpu(), y0.float()) < (2.5e-3 ** 2 + q ** 2) ** 0.5
-    assert rel(fin.cpu(), f0.float()) < 3e-3
+    # slow decay: nearly all of y is the inter-chunk term, which sees the bf16 copy of the carried state -- in upstream's pipeline
+    # (the rule of tests/tolerances.py) as much as here
+    assert rel(y.float().cpu(), y0.float()) < (by ** 2 + q ** 2) ** 0.5, (rel(y.float().cpu(), y0.float()), by, q, up)
+    assert rel(fin.cpu(), f0.float()) < bf, (rel(fin.cpu(), f0.float()), bf, up)
     assert rel(lv[0].grad.float().cpu(), dl[0].grad.float()) < 6e-3          # dx: reverse scan, split the same way
     assert rel(lv[7].grad.float().cpu(), dl[7].grad.float()) < 6e-3          # d initial_states: its final state
     # the dC / dB scans cut the sequence the same way (their start states: the folded forward / adjoint segment states)
@@ -147,11 +177,17 @@ def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
     assert rel(lv[2].grad.float().cpu(), dl[2].grad.float()) < 3e-2          # dA: a signed sum of d(dt) over 300 tokens
 
 
+@pytest.mark.parametrize("cp", ["1", "0"])
 @pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(130, 2, 1, False, False, None), (70, 4, 2, True, True, None),
-                                                                (200, 2, 1, False, True, 1), (330, 4, 2, False, True, 2)])
-def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
-    """bf16 MFMA backward (3 scans + finish) vs autograd of the fp32 oracle on identical bf16 inputs.  minc: split the
-    sequence of the y and dx scans into segments of that many chunks (see test_ssd_mfma_fwd_split_sequence)."""
+                                                                (200, 2, 1, False, True, 1), (330, 4, 2, False, True, 2),
+                                                                (300, 8, 1, False, True, None)])
+def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc, cp):
+    """bf16 MFMA backward vs autograd of the fp64 oracle on identical bf16 inputs, both forms: cp = 1 the chunk-parallel backward
+    of round 3 (dx scan + state-only forward pass dump the window states, ssd_cp.hip forms dB / dC / token scalars / dD per
+    128-token window with the head sum on chip; the 8-head case splits the heads of the group over two workgroups), cp = 0 the
+    three sequential scans of rounds 1 / 2 (still the path for D per (head, column)).  minc: split the sequence of the class A
+    scans into segments of that many chunks (see test_ssd_mfma_fwd_split_sequence)."""
+    monkeypatch.setenv("OMK_SSD_BWD_CP", cp)
     if minc:
         monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
     import omnimamba_amd.ssd_combined as S
@@ -181,10 +217,14 @@ def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc):
     # (130 tokens, 1 sequence) cancellation amplifies the same bf16-level noise: 8e-2 of the vector norm here, shrinking
     # ~1/sqrt(tokens) at training sizes.  The fp32 generic path (test_ssd_generic_bwd) is exact to 2e-4.
     tol = {"x": 5e-3, "dt": 6e-3, "A": 8e-2, "B": 5e-3, "C": 5e-3, "D": 5e-3, "z": 5e-3, "dt_bias": 8e-2, "init": 5e-3}
+    if cp == "1":
+        # the chunk-parallel form builds the token scalars in fp32 from exact bf16 products (no bf16 M operand in that chain) and
+        # restarts the decay-gradient prefix from exact window values: d(dt) 1.4e-3 .. 2e-3, dA / d(dt_bias) 3e-4 .. 5e-3 measured
+        tol.update({"dt": 4e-3, "A": 1.5e-2, "dt_bias": 1.5e-2, "B": 4e-3, "C": 4e-3})
     for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "z", "dt_bias", "init"], leaves, dl):
         if a is not None:
             e = rel(a.grad, b.grad)
-            assert e < tol[n], (n, e)
+            assert e < tol[n], (n, e, cp)
 
 
 @pytest.mark.parametrize("L,H,G", [(200, 2, 1), (330, 4, 2)])

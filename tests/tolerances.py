@@ -1,0 +1,44 @@
+"""The forward-scan tolerance rule of round 3, shared by the parity tests.
+
+North star: the MFMA scan matches the reference's scan within 1e-3 (relative L2) of ARITHMETIC error -- on top of the one
+rounding of the bf16 output itself (Q_BF16: no bf16-output kernel can go below it), hence every bound has the form
+sqrt(arith^2 + q^2) with q measured on the oracle's own output.
+
+The reference's scan (mamba_ssm 2.2.2, absent from /root/reference) is itself not exact: with 16-bit activations it rounds
+three tl.dot operands to the activation dtype (oracle.ssd_ref_chunked(..., emulate_upstream_rounding=True)).
+Its own arithmetic error against the fp64 recurrence is 0.4e-3 .. 1.7e-3 depending on the head's decay (heads whose output
+is mostly intra-chunk suffer the bf16 C.B^T operand, slow-decay heads the bf16 chunk states), so "within 1e-3 of the
+reference" is not a fixed distance from the exact answer.  The rule the tests apply per (batch, head) slice:
+
+    arith(ours vs fp64)  <=  max(ARITH_BUDGET, 1.05 * arith(upstream-rounding oracle at the reference's chunk size 256 vs fp64))
+
+i.e. inside the north-star budget wherever the reference pipeline itself is, and never further from the exact result than
+the reference pipeline where its own rounding points exceed the budget.  OMK_SSD_PRECISE=1 meets the bare 1e-3 everywhere
+(tests/test_ops_ssd.py::test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states)."""
+import math
+
+import torch
+
+import oracle as O
+
+Q_BF16 = 1.65e-3
+ARITH_BUDGET = 1e-3
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def arith_part(e, q):
+    return math.sqrt(max(e * e - q * q, 0.0))
+
+
+def forward_budget(x, dt, A, Bm, Cm, **kw):
+    """Returns (y_exact fp64 unrounded, final_exact, budget_y, budget_final, (upstream arithmetic error of y, of the final state))
+    for one slice of inputs; kw: D, z, dt_bias, initial_states, dt_softplus, dt_limit."""
+    kw = dict(kw, return_final_states=True, round_output=False)
+    y64, f64 = O.ssd_ref_chunked(x, dt, A, Bm, Cm, 64, compute_dtype=torch.float64, **kw)
+    yu, fu = O.ssd_ref_chunked(x, dt, A, Bm, Cm, 256, emulate_upstream_rounding=True, **kw)
+    eu, ef = rel(yu, y64), rel(fu, f64)
+    return y64, f64, max(ARITH_BUDGET, 1.05 * eu), max(ARITH_BUDGET, 1.05 * ef), (eu, ef)
