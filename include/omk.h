@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 2
+#define OMK_ABI_VERSION 3
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -328,6 +328,23 @@ typedef struct {
   int32_t write_grad;      /* 0: only the losses */
 } OmkCrossEntropy;
 int omk_cross_entropy(const OmkCrossEntropy* p, omk_stream stream);
+
+/* ---- token sampling inside the decode step --------------------------------------------------------------
+ * reference models/stage2/generation.py:87-121 `sample(logits, top_k, top_p, min_p, temperature)`: the top_k == 1 short cut
+ * (argmax) and the top_k > 0 branch (top-k -> / temperature -> top-p filter of :64-76 -> multinomial), for 1 <= top_k <= 64.
+ * One uniform per row from Philox4x32-10 keyed by (seed, row, *step_counter + offset): the reference draws with
+ * torch.multinomial, so the ids agree in distribution (and exactly for top_k == 1), not stream for stream.  step_counter is a
+ * device int64 the caller advances (inside its captured graph), NULL = 0.  The full-vocabulary branches (top_k == 0: top-p /
+ * min-p over all logits) stay on the host library.                                                                            */
+typedef struct {
+  OmkTensor logits;        /* (batch, vocab) f32 / bf16 / f16, unit last stride */
+  OmkTensor out_ids;       /* out (batch) int64, dense (dtype field ignored) */
+  const void* step_counter; /* optional device int64 */
+  uint64_t seed, offset;
+  int32_t top_k;           /* 1 .. 64 */
+  float top_p, temperature;
+} OmkSample;
+int omk_sample(const OmkSample* p, omk_stream stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 2
+OMK_ABI_VERSION = 3
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
@@ -83,7 +83,10 @@ SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "dt
 CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("losses", _t), ("grad_scale", C.c_void_p),
                                       ("ignore_index", _i64), ("write_grad", _i)])
 
-STRUCTS = {s.__name__: s for s in (CrossEntropy, OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
+Sample = _S("OmkSample", [("logits", _t), ("out_ids", _t), ("step_counter", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                          ("top_k", _i), ("top_p", _f), ("temperature", _f)])
+
+STRUCTS = {s.__name__: s for s in (Sample, CrossEntropy, OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
                                    Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, NormLinear, LoraAdd, LoraUpBwd, SsdFwd, SsdBwd)}
 
 # every symbol include/omk.h declares
@@ -95,7 +98,7 @@ SYMBOLS = [
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
     "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
-    "omk_cross_entropy", "omk_lora_up_bwd_parts",
+    "omk_cross_entropy", "omk_lora_up_bwd_parts", "omk_sample",
 ]
 
 

@@ -34,7 +34,7 @@ size_t omk_sizeof(const char* n) {
   if (!n) return 0;
   OMK_SZ(OmkTensor); OMK_SZ(OmkAddNormFwd); OMK_SZ(OmkAddNormBwd); OMK_SZ(OmkNormGatedFwd); OMK_SZ(OmkNormGatedBwd);
   OMK_SZ(OmkConv1dFwd); OMK_SZ(OmkConv1dBwd); OMK_SZ(OmkConv1dUpdate); OMK_SZ(OmkStateUpdate); OMK_SZ(OmkSelScanFwd);
-  OMK_SZ(OmkSelScanBwd); OMK_SZ(OmkNormLinear); OMK_SZ(OmkLoraAdd); OMK_SZ(OmkLoraUpBwd); OMK_SZ(OmkSsdFwd); OMK_SZ(OmkSsdBwd); OMK_SZ(OmkCrossEntropy);
+  OMK_SZ(OmkSelScanBwd); OMK_SZ(OmkNormLinear); OMK_SZ(OmkLoraAdd); OMK_SZ(OmkLoraUpBwd); OMK_SZ(OmkSsdFwd); OMK_SZ(OmkSsdBwd); OMK_SZ(OmkCrossEntropy); OMK_SZ(OmkSample);
 #undef OMK_SZ
   return 0;
 }

@@ -15,6 +15,7 @@ constexpr int CONV_MAXW = 4;
 struct ConvArgs {
   const void* x; const void* w; const void* bias; const void* init; const void* dout;
   void* out; void* fin; void* dx; float* dw; float* db; void* dinit;
+  int FW;   // columns of final_states (>= W - 1)
   int64_t xsb, xsc, xsl, osb, osc, osl, isb, isc, isl, fsb, fsc, fsl, dosb, dosc, dosl, dxsb, dxsc, dxsl, disb, disc, disl;
   int64_t wsc, wsk;
   int B, C, L, W, silu, wdt, bdt, idt, fdt;
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
     }
   }
   if (a.fin && lend == a.L) {
-    // final_states[j] = xpad[L + j], xpad = [init | x]
-    for (int j = 0; j < W - 1; j++) {
-      const int l = a.L + j - (W - 1);
+    // final_states[j] = xpad[L + (W - 1) - FW + j], xpad = [init | x]: the last FW >= W - 1 inputs (FW = W: the conv_state of Mamba2's cache)
+    for (int j = 0; j < a.FW; j++) {
+      const int l = a.L + j - a.FW;
 #pragma unroll
       for (int i = 0; i < VEC; i++) {
         float v = 0.f;
         if (l >= 0) v = to_f32(x[(int64_t)l * a.xsl + i]);
-        else if (a.init) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt);
+        else if (a.init && W - 1 + l >= 0) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt);
         store_rt(a.fin, (int64_t)b * a.fsb + (int64_t)(c0 + i) * a.fsc + (int64_t)j * a.fsl, a.fdt, v);
       }
     }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
 template <class T>
 __device__ __forceinline__ float conv_in(const ConvArgs& a, const T* x, int b, int c, int l) {
   if (l >= 0) return to_f32(x[(int64_t)b * a.xsb + (int64_t)c * a.xsc + (int64_t)l * a.xsl]);
-  if (a.init) return load_rt(a.init, (int64_t)b * a.isb + (int64_t)c * a.isc + (int64_t)(a.W - 1 + l) * a.isl, a.idt);
+  if (a.init && a.W - 1 + l >= 0) return load_rt(a.init, (int64_t)b * a.isb + (int64_t)c * a.isc + (int64_t)(a.W - 1 + l) * a.isl, a.idt);
   return 0.f;
 }
 
@@ -131,7 +132,7 @@ __global__ void conv1d_fwd_generic_kernel(ConvArgs a, int l_fastest) {
 template <class T>
 __global__ void conv1d_final_states_kernel(ConvArgs a) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int Wm = a.W - 1;
+  const int Wm = a.FW;
   if (g >= (int64_t)a.B * a.C * Wm) return;
   const int c = (int)(g % a.C), j = (int)((g / a.C) % Wm), b = (int)(g / ((int64_t)a.C * Wm));
   float v = conv_in<T>(a, (const T*)a.x, b, c, a.L + j - Wm);
@@ -390,7 +391,9 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
   a.silu = p->silu;
   a.fin = p->final_states.data; a.fdt = p->final_states.dtype;
   if (present(p->final_states)) {
-    OMK_REQUIRE(p->final_states.ndim == 3 && p->final_states.shape[2] == a.W - 1, "causal_conv1d_fwd: final_states must be (B, C, W-1)");
+    OMK_REQUIRE(p->final_states.ndim == 3 && p->final_states.shape[0] == a.B && p->final_states.shape[1] == a.C && p->final_states.shape[2] >= a.W - 1 &&
+                p->final_states.shape[2] <= 2 * a.W, "causal_conv1d_fwd: final_states must be (B, C, state_len) with W - 1 <= state_len <= 2 W");
+    a.FW = (int)p->final_states.shape[2];
     a.fsb = p->final_states.stride[0]; a.fsc = p->final_states.stride[1]; a.fsl = p->final_states.stride[2];
   }
   if ((int64_t)a.B * a.C * a.L == 0) return OMK_OK;
@@ -416,7 +419,7 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
     int lf = (a.xsl == 1 && a.xsc != 1) ? 1 : 0;
     OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_fwd_generic_kernel<T>), grid, block, 0, stream, a, lf));
     if (a.fin) {
-      int64_t m = (int64_t)a.B * a.C * (a.W - 1);
+      int64_t m = (int64_t)a.B * a.C * a.FW;
       dim3 g2((unsigned)((m + 255) / 256));
       OMK_DISPATCH_DTYPE(p->x.dtype, T, OMK_LAUNCH((conv1d_final_states_kernel<T>), g2, block, 0, stream, a));
     }

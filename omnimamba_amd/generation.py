@@ -11,6 +11,8 @@ from typing import Optional
 
 import torch
 
+from . import sampling as SMP
+
 
 @dataclass
 class InferenceParams:
@@ -37,10 +39,22 @@ def _top_p_filter_(logits, top_p):
     logits.masked_fill_(remove.scatter(1, sorted_idx, remove), float("-inf"))
 
 
+_draws = 0     # Philox offset of the next host-side call of the device sampler (one stream position per call)
+
+
 def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
-    """(batch, vocab) -> (batch,) token ids.  top_k == 1 is greedy argmax (what the inference scripts use)."""
+    """(batch, vocab) -> (batch,) token ids.  top_k == 1 is greedy argmax (what the inference scripts use).  With 1 < top_k <= 64 on
+    the MI355X the draw is one omk_sample launch (top-k select, temperature, top-p, Philox inverse-CDF draw: csrc/sample.hip) seeded
+    from torch's generator -- same distribution as the reference's topk + softmax + multinomial chain, no host round trip."""
+    global _draws
     if top_k == 1:
         return logits.argmax(dim=-1)
+    if top_p > 0.0:
+        assert top_p <= 1.0, "top-p should be in (0, 1]."
+    if top_k > 0 and logits.is_cuda and SMP.applies(logits, min(top_k, logits.size(-1))):
+        _draws += 1
+        return SMP.sample_device(logits, top_k=min(top_k, logits.size(-1)), top_p=top_p, temperature=temperature,
+                                 seed=torch.initial_seed(), offset=_draws)
     if top_k > 0:
         top_k = min(top_k, logits.size(-1))
         vals, idx = torch.topk(logits, top_k, dim=-1)
@@ -105,15 +119,17 @@ class StepGraph:
 
 
 class GreedyLoopGraph:
-    """Greedy decoding with the SAMPLING ON THE DEVICE: one captured graph holds the 1-token
+    """Decoding with the SAMPLING ON THE DEVICE (greedy, or top-k / top-p / temperature through omk_sample): one captured graph holds the 1-token
     model step, the argmax, the write of the new id into the step's own input buffer and into the output slot, and the
     position / length counters.  The host only replays it -- no per-token copy_, clone, argmax launch or torch.cat from
     Python (the reference's loop, generation.py:239-257, does all of those per token).  Same ids as the host loop; used
     when top_k == 1 and there is no EOS test (the T2I path: exactly num_tokens codes, omnimamba.py:321)."""
 
-    def __init__(self, model, inference_params, batch_size, max_seqlen, n_steps, task, n_warmups=2):
+    def __init__(self, model, inference_params, batch_size, max_seqlen, n_steps, task, n_warmups=2, top_k=1, top_p=0.0, temperature=1.0,
+                 seed=0):
         dev = next(iter(model.parameters())).device
         self.ip = inference_params
+        self.draw = torch.zeros((), dtype=torch.int64, device=dev)      # Philox stream position, advanced inside the graph
         self.input_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
         self.position_ids = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
         self.slot = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)
@@ -125,7 +141,12 @@ class GreedyLoopGraph:
         def step():
             out = model(self.input_ids, None, position_ids=self.position_ids, task=task, inference_params=inference_params,
                         num_last_tokens=1)
-            nxt = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1).argmax(dim=-1, keepdim=True)
+            lg = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+            if top_k == 1:
+                nxt = lg.argmax(dim=-1, keepdim=True)
+            else:   # top-k / temperature / top-p / draw as ONE launch that reads its stream position from device memory
+                nxt = SMP.sample_device(lg, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, step_counter=self.draw).unsqueeze(1)
+                self.draw.add_(1)
             self.tokens.scatter_(1, self.slot.clamp(max=self.tokens.shape[1] - 1), nxt)
             self.input_ids.copy_(nxt)
             self.position_ids.add_(1)
@@ -146,10 +167,11 @@ class GreedyLoopGraph:
             step()
         inference_params.seqlen_offset = off
 
-    def run(self, first_ids, first_pos, n_steps):
+    def run(self, first_ids, first_pos, n_steps, draw0=1):
         self.input_ids.copy_(first_ids)
         self.position_ids.fill_(first_pos)
         self.slot.zero_()
+        self.draw.fill_(draw0)
         self.ip.lengths_per_sample[:] = first_pos
         for _ in range(n_steps):
             self.graph.replay()
@@ -167,8 +189,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     graph = None
     if hasattr(model, "prepare_decode"):
         model.prepare_decode(task)      # per-token-id tables of the embedding MLPs, built outside any graph capture
-    if device_loop and cg and top_k == 1 and eos_token_id is None and teacher_outputs is None and vocab_size is None and trace is None:
-        return _decode_device_loop(input_ids, input_embeddings, model, max_length, task)
+    if (device_loop and cg and 1 <= top_k <= SMP.MAX_TOP_K and min_p == 0.0 and eos_token_id is None and teacher_outputs is None
+            and vocab_size is None and trace is None):
+        return _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k, top_p, temperature)
     if cg:
         # the reference's cache rule (generation.py:308-369): one set of state tensors and one graph memory pool, thrown away
         # only when the device / dtype changes or a LARGER batch or max_seqlen arrives; captured steps are kept per
@@ -228,24 +251,28 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     return seqs
 
 
-def _decode_device_loop(input_ids, input_embeddings, model, max_length, task):
+def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k=1, top_p=0.0, temperature=1.0):
     """Prefill (eager, fills the caches), then max_length - P - 1 replays of GreedyLoopGraph."""
     batch_size, seqlen_og = input_ids.shape
     dev = input_embeddings.device
     n_steps = max_length - 1 - seqlen_og
     cache = getattr(model, "_decoding_cache", None)
-    key = ("device_loop", batch_size, max_length, n_steps, task)
+    seed = torch.initial_seed()
+    key = ("device_loop", batch_size, max_length, n_steps, task, top_k, top_p, temperature, seed if top_k != 1 else 0)
     if cache is None or cache.get("kind") != "device_loop" or cache.get("key") != key:
         dtype = next(iter(model.parameters())).dtype
         ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
                              key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
                              lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
-        cache = {"kind": "device_loop", "key": key, "ip": ip, "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task)}
+        cache = {"kind": "device_loop", "key": key, "ip": ip,
+                 "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed)}
         model._decoding_cache = cache
     ip, graph = cache["ip"], cache["graph"]
     ip.reset(max_length, batch_size)
     out = model(None, input_embeddings, position_ids=None, task=task, inference_params=ip, num_last_tokens=1)
-    first = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1).argmax(dim=-1, keepdim=True)
+    lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+    first = (lg0.argmax(dim=-1, keepdim=True) if top_k == 1 else
+             SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=0).unsqueeze(1))
     ip.seqlen_offset = seqlen_og
     seqs = torch.cat([input_ids, first], dim=1)
     if n_steps > 0:

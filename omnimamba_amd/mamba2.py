@@ -12,6 +12,7 @@ LoRA Linear (models/stage2/lora.py:90-106) and sets ``.task_types`` on it (mixer
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -121,6 +122,22 @@ class Mamba2(nn.Module):
         A = -torch.exp(self.A_log.float())
         dt_limit_kwargs = {} if self.dt_limit == (0.0, float("inf")) else dict(dt_limit=self.dt_limit)
         d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * self.ngroups * self.d_state - self.nheads) // 2
+        # prefill of a cached decode takes the same fused node: conv1d + SiLU with the conv_state fill in
+        # its epilogue -> scan with the final state -> gated norm -> out_proj, instead of the five separate ops of upstream's branch
+        fused_prefill = (inference_params is not None and conv_state is not None and not torch.is_grad_enabled()
+                         and conv_state.dtype == zxbcdt.dtype and os.environ.get("OMK_FUSED_PREFILL", "1") != "0")
+        if self.use_mem_eff_path and d_mlp == 0 and fused_prefill:
+            out, last_state = mamba_split_conv1d_scan_combined(
+                zxbcdt, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.dt_bias, A, D=self._D(),
+                chunk_size=self.chunk_size, activation=self.activation, return_final_states=True,
+                rmsnorm_weight=self.norm.weight if self.rmsnorm else None,
+                rmsnorm_eps=self.norm.eps if self.rmsnorm else 1e-6, outproj_weight=self.out_proj.weight,
+                outproj_bias=self.out_proj.bias, headdim=None if self.D_has_hdim else self.headdim,
+                ngroups=self.ngroups, norm_before_gate=self.norm_before_gate, conv_state_out=conv_state, **dt_limit_kwargs)
+            ssm_state.copy_(last_state)
+            if seqlen_og is not None:
+                out = out.reshape(batch * seqlen, -1)
+            return out
         if self.use_mem_eff_path and inference_params is None and d_mlp == 0:
             out = mamba_split_conv1d_scan_combined(
                 zxbcdt, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.dt_bias, A, D=self._D(),

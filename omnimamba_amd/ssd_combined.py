@@ -170,7 +170,7 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
     def forward(ctx, zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None, seq_idx=None,
                 dt_limit=(0.0, _INF), return_final_states=False, activation="silu", rmsnorm_weight=None,
                 rmsnorm_eps=1e-6, outproj_weight=None, outproj_bias=None, headdim=None, ngroups=1,
-                norm_before_gate=True):
+                norm_before_gate=True, conv_state_out=None):
         if seq_idx is not None:
             raise NotImplementedError("seq_idx never reaches the mixer in OmniMamba")
         if activation not in ("silu", "swish"):
@@ -189,7 +189,13 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         if zxbcdt.stride(-1) != 1:
             zxbcdt = zxbcdt.contiguous()
         z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
-        xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv1d_weight, conv1d_bias, activation=activation).transpose(1, 2)
+        if conv_state_out is not None:
+            # prefill: the conv kernel's epilogue leaves the last `state_len` pre-conv inputs in the
+            # cache's conv_state (left zero padded when L < state_len) -- no separate pad / copy pass
+            xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv1d_weight, conv1d_bias, return_final_states=True,
+                                     final_states_out=conv_state_out, activation=activation)[0].transpose(1, 2)
+        else:
+            xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv1d_weight, conv1d_bias, activation=activation).transpose(1, 2)
         x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
         use_norm = rmsnorm_weight is not None
         zz = z.reshape(Bsz, L, H, P) if z.is_contiguous() else z.unflatten(-1, (H, P))
@@ -307,16 +313,18 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         return (dzxbcdt, dw.to(conv_w.dtype), None if conv_b is None else db.to(conv_b.dtype),
                 g["ddt_bias"].to(dt_bias.dtype), g["dA"].to(A.dtype), g["dD"].to(D.dtype), None,
                 None if dinit is None else dinit.to(initial_states.dtype), None, None, None, None, d_norm_w, None,
-                d_outproj_w, d_outproj_b, None, None, None)
+                d_outproj_w, d_outproj_b, None, None, None, None)
 
 
 def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None,
                                      seq_idx=None, dt_limit=(0.0, _INF), return_final_states=False, activation="silu",
                                      rmsnorm_weight=None, rmsnorm_eps=1e-6, outproj_weight=None, outproj_bias=None,
-                                     headdim=None, ngroups=1, norm_before_gate=True):
+                                     headdim=None, ngroups=1, norm_before_gate=True, conv_state_out=None):
     """zxbcdt: (batch, seqlen, 2 * dim + 2 * ngroups * dstate + nheads); conv1d_weight: (dim + 2 * ngroups * dstate,
-    width); dt_bias, A: (nheads); D: (nheads, headdim) or (nheads,).  Returns out (batch, seqlen, d_model | dim)."""
+    width); dt_bias, A: (nheads); D: (nheads, headdim) or (nheads,).  Returns out (batch, seqlen, d_model | dim)
+    [, final_states (batch, nheads, headdim, dstate)].  conv_state_out (extension for the prefill of a cached decode): a
+    (batch, dim + 2 * ngroups * dstate, state_len >= width - 1) buffer the conv kernel fills with the last pre-conv inputs."""
     return MambaSplitConv1dScanCombinedFn.apply(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size,
                                                 initial_states, seq_idx, dt_limit, return_final_states, activation,
                                                 rmsnorm_weight, rmsnorm_eps, outproj_weight, outproj_bias, headdim,
-                                                ngroups, norm_before_gate)
+                                                ngroups, norm_before_gate, conv_state_out)

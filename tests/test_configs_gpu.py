@@ -241,3 +241,27 @@ def test_device_loop_greedy_decode_equals_host_loop(lm_1p3b):
     c = decode(ids, emb, model, Pn + new, top_k=1, task="t2i", cg=True, device_loop=True)       # cached graph again
     model._decoding_cache = None
     assert a.shape == b.shape == (2, Pn + new) and torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_device_loop_sampled_decode_is_reproducible_and_in_range(lm_1p3b):
+    """cfg 3 with sampling (the reference's inference default is top_k > 1 for T2I): omk_sample inside the captured step, the
+    Philox stream position advanced by the graph itself.  Same torch seed -> same 256 ids; another seed -> other ids; every id is
+    a VQ code; the greedy loop differs."""
+    from omnimamba_amd.generation import decode
+    model = lm_1p3b
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    Pn, new = 72, 64
+    ids = torch.zeros(1, Pn, dtype=torch.long, device=dev)
+    emb = torch.randn(1, Pn, model.cfg.d_model, device=dev) * 0.02 + model.backbone.pos_embed[:, :Pn]
+    torch.manual_seed(11)
+    a = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)
+    torch.manual_seed(11)
+    b = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)
+    torch.manual_seed(12)
+    c = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)
+    g = decode(ids, emb, model, Pn + new, top_k=1, task="t2i", cg=True, device_loop=True)
+    model._decoding_cache = None
+    assert a.shape == (1, Pn + new) and torch.equal(a, b)
+    assert not torch.equal(a, c) and not torch.equal(a, g)
+    assert int(a[:, Pn:].min()) >= 0 and int(a[:, Pn:].max()) < model.cfg.vqvae_vocab_size

@@ -117,3 +117,30 @@ def test_frozen_out_proj_forms_no_weight_gradient(dev):
     for n, v in grads[False].items():
         if n != "out_proj.weight":
             assert rel(grads[True][n], v) < 1e-5, n      # (not bit-equal on the GPU: the conv weight gradient is summed with atomics)
+
+
+@pytest.mark.parametrize("L", [13, 2])
+def test_fused_prefill_fills_both_states_like_the_unfused_branch(dev, monkeypatch, L):
+    """the prefill of a cached decode through the fused node (conv1d + SiLU with the conv_state fill in
+    its epilogue -> scan with the final state -> gated norm -> out_proj) == upstream's unfused prefill branch (A.2 of the survey):
+    same output, same ssm_state, and the same conv_state in ALL d_conv columns (left zero padded when L < d_conv)."""
+    from types import SimpleNamespace
+    m, p = build(dev)
+    torch.manual_seed(4)
+    u = torch.randn(2, L, 32).to(dev)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OMK_FUSED_PREFILL", flag)
+        with torch.no_grad():
+            ip = SimpleNamespace(key_value_memory_dict={}, seqlen_offset=0, max_seqlen=64, max_batch_size=2, lengths_per_sample=None)
+            cs, ss = m.allocate_inference_cache(2, 64)
+            cs.fill_(7.0)
+            ss.fill_(-3.0)
+            ip.key_value_memory_dict[0] = (cs, ss)
+            out = m(u, inference_params=ip)
+        res[flag] = (out.cpu(), cs.cpu().clone(), ss.cpu().clone())
+    assert rel(res["1"][0], res["0"][0]) < 1e-6
+    assert torch.equal(res["1"][1], res["0"][1])          # copies of the same inputs: bit-equal, zero padding included
+    assert rel(res["1"][2], res["0"][2]) < 1e-6
+    if L < 4:
+        assert (res["1"][1][:, :, : 4 - L] == 0).all()

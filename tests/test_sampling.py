@@ -1,0 +1,107 @@
+"""the on-device sampler (omk_sample, csrc/sample.hip) against the semantics of the reference's
+`sample` (/root/reference/models/stage2/generation.py:87-121 with the top-p filter of :64-76):
+  * top_k == 1: the ids of torch.argmax, bit-exact;
+  * 1 < top_k <= 64 with temperature and top-p: the candidate set is exactly the reference's (torch.topk + the ascending
+    cumulative-probability cut), and the empirical distribution of 4096 draws (different Philox streams) matches the reference's
+    probabilities by chi-square; a fixed (seed, counter) reproduces its ids;
+  * ties at the k-th logit (16-bit logits tie often) resolve towards the lowest indices, deterministically."""
+import math
+
+import pytest
+import torch
+
+
+def ref_distribution(logits_row, top_k, top_p, temperature):
+    """Probabilities over the vocabulary as the reference's sample() draws them (generation.py:94-104)."""
+    vals, idx = torch.topk(logits_row.float(), top_k)
+    vals = vals / temperature
+    if 0.0 < top_p < 1.0:
+        sv, si = torch.sort(vals, descending=False)
+        remove = sv.softmax(-1).cumsum(-1) <= (1 - top_p)
+        vals = vals.masked_fill(remove.scatter(0, si, remove), float("-inf"))
+    p = torch.zeros_like(logits_row, dtype=torch.float64)
+    p[idx] = torch.softmax(vals.double(), -1)
+    return p
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_greedy_equals_argmax(dev, dtype):
+    from omnimamba_amd.sampling import sample_device
+    g = torch.Generator().manual_seed(0)
+    V = 50288 if dev.type == "cuda" else 3000
+    logits = torch.randn(5, V, generator=g).to(dtype)
+    if dtype == torch.bfloat16:          # make the maximum unique (bf16 rows tie; the kernel takes the lowest index, torch any)
+        for b in range(5):
+            logits[b, 17 * (b + 1)] = 9.0
+    ids = sample_device(logits.to(dev), top_k=1)
+    assert torch.equal(ids.cpu(), logits.float().argmax(-1))
+
+
+@pytest.mark.parametrize("top_k,top_p,temp", [(8, 0.0, 1.0), (20, 0.9, 0.7), (64, 0.6, 1.3), (3, 0.999, 1.0)])
+def test_topk_topp_distribution_matches_reference(dev, top_k, top_p, temp):
+    from omnimamba_amd.sampling import sample_device
+    g = torch.Generator().manual_seed(1)
+    V = 16384 if dev.type == "cuda" else 700
+    row = torch.randn(V, generator=g) * 2.0
+    p_ref = ref_distribution(row, top_k, top_p, temp)
+    support = (p_ref > 0).nonzero().squeeze(-1)
+    nrow, nlaunch = (256, 16) if dev.type == "cuda" else (64, 24)
+    logits = row[None].repeat(nrow, 1).contiguous().to(dev)
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    counts = torch.zeros(V, dtype=torch.float64)
+    for i in range(nlaunch):
+        counter.fill_(i)
+        ids = sample_device(logits, top_k=top_k, top_p=top_p, temperature=temp, seed=1234, step_counter=counter).cpu()
+        counts += torch.bincount(ids, minlength=V).double()
+    n = nrow * nlaunch
+    assert counts.sum() == n
+    assert (counts[p_ref == 0] == 0).all(), "a token outside the reference's candidate set was drawn"
+    # chi-square over the support (cells with expectation < 5 pooled)
+    exp = p_ref[support] * n
+    obs = counts[support]
+    big = exp >= 5
+    chi = (((obs[big] - exp[big]) ** 2) / exp[big]).sum().item()
+    dof = int(big.sum().item()) - 1
+    if (~big).any():
+        e, o = exp[~big].sum().item(), obs[~big].sum().item()
+        if e > 0:
+            chi += (o - e) ** 2 / e
+            dof += 1
+    # mean dof, variance 2 dof: five sigma
+    assert chi < dof + 5 * math.sqrt(2 * max(dof, 1)) + 5, (chi, dof)
+    # reproducible: the same (seed, counter) draws the same ids; another seed does not (64 candidates, many rows)
+    counter.fill_(3)
+    a = sample_device(logits, top_k=top_k, top_p=top_p, temperature=temp, seed=1234, step_counter=counter)
+    b = sample_device(logits, top_k=top_k, top_p=top_p, temperature=temp, seed=1234, step_counter=counter)
+    c = sample_device(logits, top_k=top_k, top_p=top_p, temperature=temp, seed=99, step_counter=counter)
+    assert torch.equal(a, b)
+    if len(support) > 1:
+        assert not torch.equal(a, c)
+
+
+def test_ties_at_the_threshold_take_the_lowest_indices(dev):
+    from omnimamba_amd.sampling import sample_device
+    V = 2048
+    row = torch.full((V,), -5.0)
+    row[100] = 3.0
+    tied = [7, 300, 301, 999, 1500, 2000]          # six logits tie for the remaining three slots of top_k = 4
+    row[tied] = 1.0
+    logits = row[None].repeat(64, 1).bfloat16().to(dev)
+    seen = set()
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    for i in range(12):
+        counter.fill_(i)
+        seen |= set(sample_device(logits, top_k=4, temperature=2.0, seed=5, step_counter=counter).cpu().tolist())
+    assert seen <= {100, 7, 300, 301} and {100, 7, 300, 301} <= seen, seen
+
+
+def test_tiny_top_p_is_greedy_and_argument_checks(dev):
+    from omnimamba_amd.sampling import sample_device
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(16, 900, generator=g).to(dev)
+    ids = sample_device(logits, top_k=10, top_p=1e-6, seed=3)
+    assert torch.equal(ids.cpu(), logits.cpu().argmax(-1))
+    with pytest.raises(RuntimeError):
+        sample_device(logits, top_k=65)
+    with pytest.raises(RuntimeError):
+        sample_device(logits, top_k=4, temperature=0.0)
