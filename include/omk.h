@@ -275,7 +275,9 @@ typedef struct {
   OmkTensor z;              /* optional (B, L, H, P): out = y * silu(z) */
   OmkTensor dt_bias;        /* optional (H) */
   OmkTensor initial_states; /* optional (B, H, P, N) */
-  OmkTensor out;            /* (B, L, H, P) */
+  OmkTensor out;            /* (B, L, H, P); absent = the STATE-ONLY pass: only final_states is produced (one shard of a
+                             * sequence cut over several GPUs, omnimamba_amd/context_parallel.py) -- MFMA shape only, else
+                             * OMK_EUNSUPPORTED; Cm, D are ignored */
   OmkTensor out_x;          /* optional out (B, L, H, P): the pre-gate y (only meaningful with z; saved for backward) */
   OmkTensor final_states;   /* optional out (B, H, P, N) f32 */
   void* workspace;

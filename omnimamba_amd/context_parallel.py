@@ -1,20 +1,25 @@
-"""Context-parallel SSD scan: ONE sequence cut along L over the ranks of a process group (SURVEY.md section 8 rows e / f2).
+"""Context-parallel Mamba-2: ONE sequence cut along L over the ranks of a process group (SURVEY.md section 8 rows e / f2).
 
 The reference has no sequence parallelism (its length scaling comes from the O(L) recurrence alone);
 the regime it advertises (assets/teaser.png (c): 4 K - 128 K tokens) is where a single sequence stops fitting one GPU's
-activation memory.  The SSD recurrence needs exactly ONE exchange for that:
+activation memory.  The SSD recurrence needs exactly ONE exchange per layer for that, the conv1d in front of it a 3-token halo:
 
   rank r holds tokens [r L/W, (r + 1) L/W) of every sequence
-  1. local scan from a ZERO start (omk_ssd_scan_fwd, the same MFMA kernel): y_loc, S_loc = end state, fp32 (B, H, P, N)
-  2. all-gather of (S_loc, log-decay of the whole shard) -- 2.1 MB per sequence and layer at the 1.3B shape, over xGMI --
-     and an exclusive scan over the ranks:  s_r = sum_{q < r} (prod_{q < j < r} a_j) S_q      (a_j = shard decay per head)
-  3. correction  y_t += C_t . (exp(cs_t) s_r)   with cs_t the inclusive log-decay prefix inside the shard: a (tokens x N) x
-     (N x P) GEMM per (batch, head) on the library (hipBLASLt), and  S_final = a_r s_r + S_loc.
+  0. conv1d halo: the last d_conv - 1 pre-conv xBC tokens of rank r - 1 enter rank r's conv as `initial_states`
+     (3 x 4352 values per sequence at the 1.3B shape) -- all-gather of the tails, every rank picks its left neighbour's
+  1. state-only pass over the shard from a ZERO start (omk_ssd_scan_fwd with `out` absent: about a third of a scan):
+     S_loc = end state, fp32 (B, H, P, N); the shard's total log-decay is A * sum dt'
+  2. all-gather of (S_loc, log-decay) -- 2.1 MB per sequence and layer at the 1.3B shape, over xGMI -- and the exclusive scan over
+     the ranks   s_r = sum_{q < r} (prod_{q < j < r} a_j) S_q   (a_j = shard decay per head), initial_states in front of shard 0
+  3. the scan proper of the shard FROM s_r (`initial_states` of the same MFMA kernel): y of the shard with ONE output rounding,
+     exactly what the unsharded scan computes -- no correction pass, no (B, L, H, P) fp32 temporary -- and
+     S_final = a_r s_r + S_loc on the last rank.
 
-No second pass over the shard, no collective inside the scan kernel.  Everything around the scan is differentiable
-torch code and the all-gather has a backward (sum of the gradient slices), so the same function trains: gradients of the
-boundary states flow back to the ranks that produced them.  One process per GPU, backend "nccl" (= RCCL); the CPU test
-runs two gloo ranks on the emulated kernels and compares with the single-process scan of the whole sequence.
+Everything is differentiable: the exchange is ONE autograd node (`_CpExchange`) whose backward all-reduces the gradients of the
+gathered states -- it sits in every rank's graph (the scan proper always takes `initial_states = s_r`, zeros on rank 0), so no
+rank can skip a collective its peers issue.  One process per GPU, backend "nccl" (= RCCL); the CPU test runs two gloo ranks on the
+emulated kernels, the -m gpu test walks two shards on one MI355X in bf16 through the MFMA kernels and compares with the oracle on
+the whole sequence.
 """
 from __future__ import annotations
 
@@ -22,25 +27,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from .ssd_combined import mamba_chunk_scan_combined
-
-
-class _AllGatherCat(torch.autograd.Function):
-    """all_gather along a new leading dim with a backward that works on every backend (all_reduce of the stacked gradient)."""
-
-    @staticmethod
-    def forward(ctx, t, group):
-        ctx.group = group
-        world = dist.get_world_size(group)
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t.contiguous(), group=group)
-        return torch.stack(out, 0)
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g[dist.get_rank(ctx.group)], None
+from .ssd_combined import mamba_chunk_scan_combined, ssd_final_state
 
 
 def _dt_eff(dt, dt_bias, dt_softplus, dt_limit):
@@ -63,6 +50,78 @@ def start_states_from_shards(S_all, logdec_all, rank, initial_states=None):
     return s
 
 
+class _LocalGroup:
+    """The exchange of a 'group' whose shards are walked one after the other in ONE process (tests, single-GPU long sequences):
+    all_gather = the list the caller filled."""
+
+    def __init__(self, world):
+        self.world, self.rank = world, 0
+
+
+class _CpExchange(torch.autograd.Function):
+    """(S_loc, logdec_loc, initial_states) of this rank -> (state at the start of this rank's shard, state behind the whole
+    sequence).  Forward: two all-gathers.  Backward: the local gradients of the gathered tensors (autograd of
+    start_states_from_shards on this rank's two outputs) summed over the ranks -- one all-reduce each, issued by EVERY rank."""
+
+    @staticmethod
+    def forward(ctx, S_loc, ld_loc, init, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        Ss = [torch.empty_like(S_loc) for _ in range(world)]
+        ls = [torch.empty_like(ld_loc) for _ in range(world)]
+        dist.all_gather(Ss, S_loc.contiguous(), group=group)
+        dist.all_gather(ls, ld_loc.contiguous(), group=group)
+        S_all, ld_all = torch.stack(Ss, 0), torch.stack(ls, 0)
+        ctx.save_for_backward(S_all, ld_all, init)
+        ctx.group, ctx.rank, ctx.world = group, rank, world
+        return start_states_from_shards(S_all, ld_all, rank, init), start_states_from_shards(S_all, ld_all, world, init)
+
+    @staticmethod
+    def backward(ctx, ds_in, dfinal):
+        S_all, ld_all, init = ctx.saved_tensors
+        with torch.enable_grad():
+            Sa, la = S_all.detach().requires_grad_(), ld_all.detach().requires_grad_()
+            ii = None if init is None else init.detach().float().requires_grad_()
+            outs = (start_states_from_shards(Sa, la, ctx.rank, ii), start_states_from_shards(Sa, la, ctx.world, ii))
+            leaves = [Sa, la] + ([ii] if ii is not None else [])
+            pairs = [(o, g.float()) for o, g in zip(outs, (ds_in, dfinal)) if o.requires_grad]   # rank 0 without initial_states: s_in is a constant
+            grads = (torch.autograd.grad([o for o, _ in pairs], leaves, [g for _, g in pairs], allow_unused=True) if pairs
+                     else [None] * len(leaves))
+        gS = torch.zeros_like(S_all) if grads[0] is None else grads[0]
+        gl = torch.zeros_like(ld_all) if grads[1] is None else grads[1]
+        dist.all_reduce(gS, op=dist.ReduceOp.SUM, group=ctx.group)
+        dist.all_reduce(gl, op=dist.ReduceOp.SUM, group=ctx.group)
+        # initial_states is a replicated input: every rank returns ITS contribution (the caller sums parameter-like gradients over
+        # the ranks, as for A / D / dt_bias)
+        gi = None if ii is None else (torch.zeros_like(ii) if grads[2] is None else grads[2]).to(init.dtype)
+        return gS[ctx.rank], gl[ctx.rank], gi, None
+
+
+class _HaloExchange(torch.autograd.Function):
+    """tail (B, C, W - 1) of every rank's pre-conv input -> the left neighbour's tail (zeros on rank 0).  Backward: the gradient of
+    rank r + 1's halo returns to rank r's tail.  All-gather both ways, so every rank issues the same collectives."""
+
+    @staticmethod
+    def forward(ctx, tail, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ts = [torch.empty_like(tail) for _ in range(world)]
+        dist.all_gather(ts, tail.contiguous(), group=group)
+        ctx.group, ctx.rank, ctx.world = group, rank, world
+        return ts[rank - 1] if rank > 0 else torch.zeros_like(tail)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = [torch.empty_like(g) for _ in range(ctx.world)]
+        dist.all_gather(gs, g.contiguous(), group=ctx.group)
+        return (gs[ctx.rank + 1] if ctx.rank + 1 < ctx.world else torch.zeros_like(g)), None
+
+
+def shard_states(x, dt, A, B, dt_bias=None, dt_softplus=False, dt_limit=(0.0, float("inf"))):
+    """Step 1 for one shard: (end state from a zero start (B, H, P, N) fp32, natural-log decay of the whole shard (B, H))."""
+    S_loc = ssd_final_state(x, dt, A, B, dt_bias=dt_bias, dt_softplus=dt_softplus, dt_limit=dt_limit)
+    ld = (_dt_eff(dt, dt_bias, dt_softplus, dt_limit) * A.float()).sum(1)
+    return S_loc, ld
+
+
 def mamba_chunk_scan_context_parallel(x, dt, A, B, C, chunk_size, D=None, z=None, dt_bias=None, initial_states=None,
                                       dt_softplus=False, dt_limit=(0.0, float("inf")), return_final_states=False, group=None):
     """mamba_chunk_scan_combined for a sequence sharded along L over `group` (this rank's shard: x (B, L/W, H, P), ...).
@@ -70,26 +129,18 @@ def mamba_chunk_scan_context_parallel(x, dt, A, B, C, chunk_size, D=None, z=None
     Returns this shard's output [, the state after the WHOLE sequence (identical on every rank)]."""
     if group is None:
         group = dist.group.WORLD
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    H, G = x.shape[2], B.shape[2]
-    y_loc, S_loc = mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D=D, z=None, dt_bias=dt_bias, dt_softplus=dt_softplus,
-                                             dt_limit=dt_limit, return_final_states=True)
-    cs = torch.cumsum(_dt_eff(dt, dt_bias, dt_softplus, dt_limit) * A.float(), dim=1)        # (B, L_loc, H) natural log
-    S_all = _AllGatherCat.apply(S_loc.float(), group)
-    ld_all = _AllGatherCat.apply(cs[:, -1], group)
-    s_in = start_states_from_shards(S_all, ld_all, rank, initial_states)
-    # correction: y[b, t, h, p] += exp(cs[b, t, h]) * sum_n C[b, t, g(h), n] s_in[b, h, p, n]
-    # one GEMM per (batch, group) over ALL heads of the group -- (L_loc x N) x (N x (H / G) P) -- with the decay applied to the
-    # product (C is shared by the heads of a group: expanding it per head first would be a (B, L, H, N) fp32 temporary, 1 GB at the
-    # 1.3B shape with L_loc = 4096)
-    Pd = x.shape[3]
-    sg = s_in.view(s_in.shape[0], G, H // G, Pd, s_in.shape[-1])                              # (B, G, H / G, P, N)
-    corr = torch.einsum("blgn,bgkpn->blgkp", C.float(), sg).reshape(x.shape[0], x.shape[1], H, Pd)
-    y = torch.addcmul(y_loc.float(), corr, torch.exp(cs)[..., None])
-    if z is not None:
-        y = y * F.silu(z.float())
-    y = y.to(x.dtype)
-    if not return_final_states:
-        return y
-    final = start_states_from_shards(S_all, ld_all, world, initial_states)                    # state behind the last shard
-    return y, final
+    S_loc, ld = shard_states(x, dt, A, B, dt_bias, dt_softplus, dt_limit)
+    s_in, final = _CpExchange.apply(S_loc, ld, initial_states, group)
+    y = mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D=D, z=z, dt_bias=dt_bias, initial_states=s_in, dt_softplus=dt_softplus,
+                                  dt_limit=dt_limit)
+    return (y, final) if return_final_states else y
+
+
+def conv1d_halo(xBC_t, width, group=None):
+    """xBC_t: this shard's pre-conv input (B, C, L_loc) -> the `initial_states` (B, C, width - 1) of its causal conv1d: the last
+    width - 1 tokens of the left neighbour's shard (zeros on rank 0)."""
+    if group is None:
+        group = dist.group.WORLD
+    n = width - 1
+    tail = xBC_t[..., -n:] if xBC_t.shape[-1] >= n else F.pad(xBC_t, (n - xBC_t.shape[-1], 0))
+    return _HaloExchange.apply(tail.contiguous(), group)

@@ -396,12 +396,14 @@ extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
 }
 
 extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
-  OMK_REQUIRE(p && present(p->out), "ssd_scan_fwd: out required");
+  OMK_REQUIRE(p && (present(p->out) || present(p->final_states)), "ssd_scan_fwd: out (or, for the state-only pass, final_states) required");
   SsdDims d;
   int rc = ssd_check_common(p->x, p->dt, p->A, p->Bm, p->Cm, p->D, p->dt_bias, p->initial_states, &d, "ssd_scan_fwd");
   if (rc) return rc;
-  OMK_REQUIRE(p->out.ndim == 4 && p->out.shape[0] == d.B && p->out.shape[1] == d.L && p->out.shape[2] == d.H && p->out.shape[3] == d.P && p->out.stride[3] == 1, "ssd_scan_fwd: out must be (B,L,H,P) with unit last stride");
-  OMK_REQUIRE(p->Bm.dtype == p->x.dtype && p->Cm.dtype == p->x.dtype && p->out.dtype == p->x.dtype, "ssd_scan_fwd: B, C, out must have x's dtype");
+  const bool state_only = !present(p->out);   // out absent: only the state behind the sequence (one shard of a context-parallel scan)
+  if (!state_only) OMK_REQUIRE(p->out.ndim == 4 && p->out.shape[0] == d.B && p->out.shape[1] == d.L && p->out.shape[2] == d.H && p->out.shape[3] == d.P && p->out.stride[3] == 1, "ssd_scan_fwd: out must be (B,L,H,P) with unit last stride");
+  OMK_REQUIRE(p->Bm.dtype == p->x.dtype && p->Cm.dtype == p->x.dtype && (state_only || p->out.dtype == p->x.dtype), "ssd_scan_fwd: B, C, out must have x's dtype");
+  if (state_only) OMK_REQUIRE(!present(p->z) && !present(p->out_x), "ssd_scan_fwd: the state-only pass takes no gate and writes no output");
   if (present(p->z)) OMK_REQUIRE(p->z.ndim == 4 && p->z.stride[3] == 1 && p->z.dtype == p->x.dtype, "ssd_scan_fwd: z must be (B,L,H,P) of x's dtype");
   if (present(p->out_x)) OMK_REQUIRE(p->out_x.dtype == p->out.dtype && p->out_x.stride[0] == p->out.stride[0] && p->out_x.stride[1] == p->out.stride[1] && p->out_x.stride[2] == p->out.stride[2], "ssd_scan_fwd: out_x must match out's dtype and strides");
   if (present(p->final_states)) OMK_REQUIRE(p->final_states.dtype == OMK_F32 && p->final_states.ndim == 4, "ssd_scan_fwd: final_states must be f32 (B,H,P,N)");
@@ -431,6 +433,12 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
 #endif
   if (ssd_seg_bytes(d.B * d.H, d.L) && !getenv("OMK_SSD_NO_SPLIT")) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
+  if (state_only) {
+    rc = (p->force_generic || p->x.dtype != OMK_BF16) ? OMK_EUNSUPPORTED : ssd_mfma_state_only(g, stream);
+    if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the state-only pass exists for the MFMA shape only (bf16, headdim 64, d_state 128); run the scan and drop its output");
+    if (rc) return rc;
+    return finish_launch("ssd_scan_fwd");
+  }
   rc = run_scan(g, p->force_generic, stream);
   if (rc) return rc;
   return finish_launch("ssd_scan_fwd");

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   // workgroup order (b, segment, h): the heads of one (batch, segment) share B / C rows and an XCD
   // spass: the state-only pass that dumps window states starts like a scan (every segment, folded start states) and leaves no
   // segment state behind
-  const bool spass = STATE && a.dump != nullptr;
+  const bool spass = STATE && (a.dump != nullptr || a.state_only != 0);
   const int nwseg = (STATE && !spass) ? a.nseg - 1 : a.nseg;
   const int h = vid % a.H, seg = (vid / a.H) % nwseg, b = vid / (a.H * nwseg);
   const int g = h / (a.H / a.G);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   prefetch_u();
   commit(0);
   if (w == 0) scalars(0, true);
-  if (spass) publish_state();
+  if (spass && a.dump) publish_state();
   if (!STATE) {
     publish_state();
     if (!DFOLD && tid < 64) sm.Dv[tid] = a.D ? load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)tid * a.Dsp, a.D_dt) : 0.f;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     PT3(4);
     // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
     // (the state-only dump pass publishes only what the next iteration dumps: forward, the state in front of an even chunk)
-    if ((!STATE || (spass && (rev ? ((nC - 2 - c) & 1) != 0 : ((c + 1) & 1) == 0))) && !(abl & 8)) publish_state();
+    if ((!STATE || (spass && a.dump && (rev ? ((nC - 2 - c) & 1) != 0 : ((c + 1) & 1) == 0))) && !(abl & 8)) publish_state();
     commit(nxt);
     if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);
@@ -426,8 +426,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   if (prof && lane == 0)
     for (int i = 0; i < 12; i++) a.prof[w * 12 + i] = pt[i];
 #endif
-  if (spass) return;
-  if (STATE) {
+  if (STATE && !spass) {
     float* sp = a.seg + (bh * a.nseg + seg) * SEG_STATE + segoff;
 #pragma unroll
     for (int ut = 0; ut < 2; ut++)
@@ -963,7 +962,7 @@ static int ssd_mfma_launch_b(const GScan& g, omk_stream stream, int dry) {
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
   if (seg_fmt) *seg_fmt = 0;
   GScan a = g;
-  a.dump = nullptr;   // the zero-start pass is not the one that dumps window states
+  a.dump = nullptr; a.state_only = 0;   // the zero-start pass is not the one that dumps window states / leaves the final state
   const SegPlan sp = ssd_segments(a.B * a.H, a.L);
   a.nseg = sp.nseg; a.cps = sp.cps;
   if (!a.seg || a.nseg < 2) return OMK_OK;
@@ -981,6 +980,30 @@ int ssd_mfma_state_dump(const GScan& g, omk_stream stream) {
   if (!g.dump || g.DU != 64 || g.DK != 128) return OMK_EUNSUPPORTED;
   GScan a = g;
   const SegPlan sp = (a.seg && a.seg_ready) ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
+  const size_t smem = sizeof(SmemA3);
+  if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+  OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), grid, block, smem, stream, a);
+  return OMK_OK;
+}
+
+int ssd_mfma_state_only(const GScan& g, omk_stream stream) {
+  if (g.mode != GS_Y || g.DU != 64 || g.DK != 128 || !g.fin || (g.H / g.G) < 1) return OMK_EUNSUPPORTED;
+  if (!src_ok16(g.U, true) || !src_ok16(g.K, true) || !stride_ok(g.K.sl) || !stride_ok(g.U.sl)) return OMK_EUNSUPPORTED;
+  {
+    const int64_t ms = g.K.sl > g.U.sl ? g.K.sl : g.U.sl;
+    if ((int64_t)g.L * ms * 2 >= (int64_t)0xfffff000) return OMK_EUNSUPPORTED;
+  }
+  GScan a = g;
+  a.Q = a.K;   // never read by the state pass; keeps the buffer descriptors well formed
+  a.state_only = 1; a.out = nullptr; a.outx = nullptr; a.dump = nullptr;
+  const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
+  if (sp.nseg > 1) {
+    int rc = ssd_mfma_prepare_segments(a, stream);
+    if (rc) return rc;
+    a.seg_ready = 1;
+  }
   a.nseg = sp.nseg; a.cps = sp.cps;
   dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
   const size_t smem = sizeof(SmemA3);

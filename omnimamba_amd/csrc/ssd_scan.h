@@ -56,6 +56,7 @@ struct GScan {
   // BEFORE token 128 w; reverse: the adjoint state at the first token BEHIND window w (dfinal_states for the last one) -- as
   // the raw 16 KB LDS image [u][k] (kx3 swizzle, ssd_tiles.h) the kernel publishes for its own Q . S product.
   uint16_t* dump; int dump_nw;
+  int state_only;                                                // class A (MFMA): no output, only the state pass from the initial state to `fin` (context-parallel shards)
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results
 };
@@ -104,6 +105,8 @@ bool ssd_v6_applies(const GScan& g);
 int ssd_v6_launch(const GScan& g, omk_stream stream);
 // state-only pass over the whole sequence that leaves the window-boundary states in g.dump (class A descriptor, no output)
 int ssd_mfma_state_dump(const GScan& g, omk_stream stream);
+// state-only pass that leaves the state behind the sequence in g.fin (OMK_EUNSUPPORTED outside the MFMA shape)
+int ssd_mfma_state_only(const GScan& g, omk_stream stream);
 // chunk-parallel dB / dC / token scalars from the dumped states (ssd_cp.hip)
 struct CpArgs {
   const uint16_t *X, *DY; int64_t xsb, xsl, xsh, ysb, ysl, ysh;   // (B, L, H, 64) bf16

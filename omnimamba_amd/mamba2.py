@@ -94,10 +94,16 @@ class Mamba2(nn.Module):
     def _D(self):
         return self.D.view(self.nheads, self.headdim) if self.D_has_hdim else self.D
 
-    def forward(self, u, seqlen=None, seq_idx=None, cu_seqlens=None, inference_params=None):
-        """u: (batch, seqlen, hidden_dim) -> same shape."""
+    def forward(self, u, seqlen=None, seq_idx=None, cu_seqlens=None, inference_params=None, cp_group=None):
+        """u: (batch, seqlen, hidden_dim) -> same shape.  cp_group (extension): a torch.distributed group
+        over which the SEQUENCE is cut -- u is this rank's shard (batch, seqlen / world, hidden_dim); the conv1d takes a 3-token halo
+        from the left neighbour and the scan one boundary-state exchange (omnimamba_amd/context_parallel.py)."""
         if seq_idx is not None or cu_seqlens is not None:
             raise NotImplementedError("seq_idx / cu_seqlens never reach the mixer in OmniMamba")
+        if cp_group is not None:
+            if inference_params is not None or seqlen is not None:
+                raise NotImplementedError("context-parallel forward: training / prefill-free path only")
+            return self._forward_context_parallel(u, cp_group)
         seqlen_og = seqlen
         if seqlen is None:
             batch, seqlen, _ = u.shape
@@ -174,6 +180,29 @@ class Mamba2(nn.Module):
             y = torch.cat([F.silu(z0) * x0, y], dim=-1)
         if seqlen_og is not None:
             y = y.reshape(batch * seqlen, -1)
+        return self.out_proj(y)
+
+    def _forward_context_parallel(self, u, group):
+        from . import context_parallel as CP
+        zxbcdt = linear(u, self.in_proj.weight, self.in_proj.bias) if type(self.in_proj) is nn.Linear else self.in_proj(u)
+        A = -torch.exp(self.A_log.float())
+        d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * self.ngroups * self.d_state - self.nheads) // 2
+        if d_mlp != 0:
+            raise NotImplementedError("context-parallel forward: d_ssm < d_inner is not on the OmniMamba path")
+        z, xBC, dt = torch.split(zxbcdt, [self.d_ssm, self.d_ssm + 2 * self.ngroups * self.d_state, self.nheads], dim=-1)
+        xBC_t = xBC.transpose(1, 2)
+        halo = CP.conv1d_halo(xBC_t, self.d_conv, group)
+        xBC = causal_conv1d_fn(xBC_t, self.conv1d.weight.squeeze(1), self.conv1d.bias, initial_states=halo,
+                               activation=self.activation).transpose(1, 2)
+        x, B, C = torch.split(xBC, [self.d_ssm, self.ngroups * self.d_state, self.ngroups * self.d_state], dim=-1)
+        y = CP.mamba_chunk_scan_context_parallel(
+            x.unflatten(-1, (self.nheads, self.headdim)), dt, A, B.unflatten(-1, (self.ngroups, self.d_state)),
+            C.unflatten(-1, (self.ngroups, self.d_state)), self.chunk_size, D=self._D(),
+            z=z.unflatten(-1, (self.nheads, self.headdim)) if not self.rmsnorm else None, dt_bias=self.dt_bias,
+            dt_softplus=True, dt_limit=self.dt_limit, group=group)
+        y = y.flatten(-2)
+        if self.rmsnorm:
+            y = self.norm(y, z)
         return self.out_proj(y)
 
     def _A_inference(self):

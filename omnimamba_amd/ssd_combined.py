@@ -109,6 +109,67 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
     return dict(dx=dx, ddt=ddt, dA=dA, dB=dB, dC=dC, dD=dD, ddt_bias=ddtb, dinitial_states=dinit)
 
 
+def ssd_final_state_raw(x, dt, A, B, dt_bias=None, initial_states=None, dt_softplus=False, dt_limit=(0.0, _INF)):
+    """State behind the sequence, fp32 (batch, nheads, headdim, dstate), without the scan's output: the state-only pass of
+    omk_ssd_scan_fwd (`out` absent; bf16, headdim 64, d_state 128) -- about a third of a scan -- or, for other shapes, the scan
+    itself with its output dropped."""
+    lib = get_lib()
+    require_device(lib, x, dt, A, B, dt_bias, initial_states)
+    Bsz, L, H, P = x.shape
+    N = B.shape[-1]
+    if x.numel() == 0:
+        fin = torch.zeros(Bsz, H, P, N, dtype=torch.float32, device=x.device)
+        return fin if initial_states is None else fin.copy_(initial_states)
+    if x.dtype == torch.bfloat16 and P == 64 and N == 128 and os.environ.get("OMK_SSD_STATE_ONLY", "1") != "0":
+        x, B = _last_contig(x), _last_contig(B)
+        B = B if B.dtype == x.dtype else B.to(x.dtype)
+        fin = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=x.device)
+        p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A.float().contiguous()), Bm=K.T(B), Cm=K.T(B), dt_bias=K.T(dt_bias),
+                     initial_states=K.T(initial_states), final_states=K.T(fin), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
+                     dt_softplus=int(dt_softplus), chunk_size=256)
+        ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
+        fn = getattr(lib, "omk_ssd_scan_fwd")
+        import ctypes as C
+        if lib.omk_is_emulated():
+            rc = fn(C.byref(p), None)
+        else:
+            with torch.cuda.device(x.device):
+                rc = fn(C.byref(p), K.stream_of(lib, x))
+        if rc == 0:
+            return fin
+        if rc != -4:       # OMK_EUNSUPPORTED (strides / alignment outside the MFMA kernel): fall through to the scan
+            K.check(lib, rc, "omk_ssd_scan_fwd (state only)")
+    return ssd_scan_fwd(x, dt, A, B, B, dt_bias=dt_bias, initial_states=initial_states, dt_softplus=dt_softplus, dt_limit=dt_limit,
+                        return_final_states=True)[2]
+
+
+class SsdFinalStateFn(torch.autograd.Function):
+    """final_states of the scan as a differentiable function of (x, dt, A, B, dt_bias, initial_states) -- the first dispatch of a
+    context-parallel shard.  Backward = the scan's backward with a zero output gradient and dfinal_states."""
+
+    @staticmethod
+    def forward(ctx, x, dt, A, B, dt_bias, initial_states, dt_softplus, dt_limit):
+        fin = ssd_final_state_raw(x, dt, A, B, dt_bias, initial_states, dt_softplus, dt_limit)
+        ctx.save_for_backward(x, dt, A, B, dt_bias, initial_states)
+        ctx.cfg = (dt_softplus, dt_limit)
+        return fin
+
+    @staticmethod
+    def backward(ctx, dfin):
+        x, dt, A, B, dt_bias, initial_states = ctx.saved_tensors
+        dt_softplus, dt_limit = ctx.cfg
+        g = ssd_scan_bwd(torch.zeros_like(x), x, dt, A, B, torch.zeros_like(B), dt_bias=dt_bias, initial_states=initial_states,
+                         dfinal_states=dfin, dt_softplus=dt_softplus, dt_limit=dt_limit, need_dinit=initial_states is not None)
+        dinit = g["dinitial_states"]
+        return (g["dx"], g["ddt"].to(dt.dtype), g["dA"].to(A.dtype), g["dB"].to(B.dtype),
+                None if dt_bias is None else g["ddt_bias"].to(dt_bias.dtype),
+                None if dinit is None else dinit.to(initial_states.dtype), None, None)
+
+
+def ssd_final_state(x, dt, A, B, dt_bias=None, initial_states=None, dt_softplus=False, dt_limit=(0.0, _INF)):
+    return SsdFinalStateFn.apply(x, dt, A, B, dt_bias, initial_states, dt_softplus, dt_limit)
+
+
 def _silu_grad(z):
     s = torch.sigmoid(z)
     return s * (1 + z * (1 - s))
