@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     const int tlo = chunk_lo(c);
     const int cnext = c + 1 < c1 ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
     PT3(0);
-    if (a.dump) {   // window-boundary image of the state in front of this chunk (sm.S, published before the last barrier)
+    if ((MODE == GS_DX || STATE) && a.dump) {   // (compiled out of the forward scan) window-boundary image of the state in front of this chunk (sm.S, published before the last barrier)
       const int cid = rev ? nC - 1 - c : c;
       const bool here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
       if (here) {
