@@ -202,6 +202,12 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
+// Phase markers for tools/isa_phases.py (developer builds with -DOMK_ISA_MARKS only): a comment line in the ISA
+#if defined(OMK_ISA_MARKS) && !defined(OMK_EMU)
+#define OMK_ISA_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
+#else
+#define OMK_ISA_MARK(name) do { } while (0)
+#endif
 // Instruction-scheduling fence: nothing moves across it
 #ifdef OMK_EMU
 #define OMK_SCHED_FENCE() do { } while (0)

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
         if (STATE) block_sync();   // (the scan proper has barrier X between these reads and the next publish)
       }
     }
+    OMK_ISA_MARK("1 Q.S_in (16 MFMA) + scale");
     // ---- (1) O = exp2(cs_l) * (Q . S_in): A = Q fragments (registers), B = S_in[k][u] as [u][k] bf16 rows
     f32x4 acc[4];
 #pragma unroll
@@ -285,9 +286,11 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       block_sync();   // X: every wave is done with S_in
     }
     PT3(2);
+    OMK_ISA_MARK("2 prefetch K / U of the next chunk");
     stlo = chunk_lo(cnext);
     prefetch_k();
     prefetch_u();
+    OMK_ISA_MARK("3 intra: G tiles, M build (decay, mask, hi + lo), M.U");
     // ---- (2) intra-chunk: G tiles -> M fragments (registers) -> M . U
     if (!STATE) {
       const float cs_l = sm.cs[cur][16 * w + t16];
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       else { block(0, true, false, false); block(1, true, false, true); }
     }
     PT3(3);
+    OMK_ISA_MARK("4 prefetch Q + state update (decay, w K operand, 8 MFMA 32x32)");
     if (!STATE) prefetch_q();
     // ---- (3) state update: S^T[k][u] = exp2(cs_end) S^T + sum_l (ws_l K^T[k][l]) U[l][u]
     if (!(abl & 4)) {
@@ -383,12 +387,14 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       }
     }
     PT3(4);
+    OMK_ISA_MARK("5 publish S_out (bf16) + commit next chunk + scalars (wave 0)");
     // ---- (4) publish S_out, stage the next chunk, next chunk's scalars
     // (the state-only dump pass publishes only what the next iteration dumps: forward, the state in front of an even chunk)
     if ((!STATE || (spass && a.dump && (rev ? ((nC - 2 - c) & 1) != 0 : ((c + 1) & 1) == 0))) && !(abl & 8)) publish_state();
     commit(nxt);
     if (w == 0) scalars(nxt, c + 1 < c1);
     PT3(5);
+    OMK_ISA_MARK("6 epilogue: convert + store O");
     // ---- epilogue from the MFMA layout: 4 consecutive columns of one row per (lane, ut); buffer stores drop rows >= L
     if (!STATE && !(abl & 16)) {
       const float dts = MODE == GS_DX ? sm.dtl[cur][16 * w + t16] : 1.f;
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       }
     }
     PT3(6);
+    OMK_ISA_MARK("7 barrier Y + loop");
     block_sync();   // Y: tiles, scalars and the bf16 state of the next chunk are visible
     PT3(7);
   }
