@@ -18,6 +18,7 @@ namespace omk {
 struct DtPrepArgs {
   const void* dt; const void* bias; float* dtp; float* dsoft;
   int64_t sb, sl, sh; int B, L, H, dt_dt, bias_dt, softplus; float lo, hi;
+  float* zero[3]; int nzero[3];   // backward: the small accumulators (dA, dD, d dt_bias) cleared by workgroup 0 -- three 4 us launches less
 };
 // block = 32 tokens x 32 heads of one batch element: loads follow the unit-stride head dimension of (B, L, H), the stores
 // the unit-stride token dimension of (B, H, L); the tile turns in LDS (a direct per-element mapping writes 4 bytes per
@@ -28,6 +29,11 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_kernel(DtPrepArgs a) {
   const int nth = (a.H + 31) / 32, ntl = (a.L + 31) / 32;
   const int hb = blockIdx.x % nth, lb = (blockIdx.x / nth) % ntl, b = blockIdx.x / (nth * ntl);
   const int h = hb * 32 + tx;
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      for (int i = threadIdx.x; i < a.nzero[k]; i += 256) a.zero[k][i] = 0.f;
+  }
   const float bias = (a.bias && h < a.H) ? load_rt(a.bias, h, a.bias_dt) : 0.f;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -35,7 +41,14 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_kernel(DtPrepArgs a) {
     float v = 0.f, d = 1.f;
     if (t < a.L && h < a.H) {
       v = load_rt(a.dt, (int64_t)b * a.sb + (int64_t)t * a.sl + (int64_t)h * a.sh, a.dt_dt) + bias;
-      if (a.softplus) { d = v > 20.f ? 1.f : sigmoid_f(v); v = softplus_f(v); }
+      if (a.softplus && v <= 20.f) {
+        // softplus and its derivative from ONE hardware exp2: e = exp(v), u = 1 + e; log1p(e) = log(u) e / (u - 1) repairs the
+        // rounding of 1 + e (classic compensation), sigmoid(v) = e / u.  The libm forms (expf, log1pf, a second expf) were ~150
+        // instructions per element: the 2 M elements of the 1.3B shape kept this launch VALU bound at 17 us.
+        const float e = exp2_fast(v * LOG2E), u = 1.f + e;
+        d = e * rcp_fast(u);
+        v = u == 1.f ? e : log2_fast(u) * 0.6931471805599453f * e * rcp_fast(u - 1.f);
+      }
       if (v < a.lo) { v = a.lo; d = 0.f; }
       if (v > a.hi) { v = a.hi; d = 0.f; }
     }
@@ -50,6 +63,62 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_kernel(DtPrepArgs a) {
       const int64_t o = ((int64_t)b * a.H + hh) * a.L + t;
       a.dtp[o] = sv[tx][ty + 8 * j];
       if (a.dsoft) a.dsoft[o] = sd[tx][ty + 8 * j];
+    }
+  }
+}
+
+// The same for 16-bit dt with unit head stride (the block's zxbcdt view): 64 tokens x 64 heads per block, two adjacent heads per
+// 4-byte load, the (B, H, L) rows stored as 16-byte vectors of four tokens.
+template <class T>
+__global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
+  __shared__ float sv[64][65], sd[64][65];
+  const int tid = threadIdx.x;
+  const int nth = (a.H + 63) / 64, ntl = (a.L + 63) / 64;
+  const int hb = blockIdx.x % nth, lb = (blockIdx.x / nth) % ntl, b = blockIdx.x / (nth * ntl);
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      for (int i = tid; i < a.nzero[k]; i += 256) a.zero[k][i] = 0.f;
+  }
+  const int hp = tid & 31, tr = tid >> 5;
+  const int h = hb * 64 + 2 * hp;
+  const bool hok = h < a.H;   // H is even: both heads of the pair are in or out
+  float bias[2] = {0.f, 0.f};
+  if (a.bias && hok) { bias[0] = load_rt(a.bias, h, a.bias_dt); bias[1] = load_rt(a.bias, h + 1, a.bias_dt); }
+  const T* src = (const T*)a.dt + (int64_t)b * a.sb + h;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int tl = 8 * j + tr, t = lb * 64 + tl;
+    float v2[2] = {0.f, 0.f}, d2[2] = {1.f, 1.f};
+    if (t < a.L && hok) {
+      load_vec<T, 2>(src + (int64_t)t * a.sl, v2);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float v = v2[e] + bias[e], d = 1.f;
+        if (a.softplus && v <= 20.f) {
+          const float ex = exp2_fast(v * LOG2E), u = 1.f + ex;
+          d = ex * rcp_fast(u);
+          v = u == 1.f ? ex : log2_fast(u) * 0.6931471805599453f * ex * rcp_fast(u - 1.f);
+        }
+        if (v < a.lo) { v = a.lo; d = 0.f; }
+        if (v > a.hi) { v = a.hi; d = 0.f; }
+        v2[e] = v; d2[e] = d;
+      }
+    }
+    sv[2 * hp][tl] = v2[0]; sv[2 * hp + 1][tl] = v2[1];
+    sd[2 * hp][tl] = d2[0]; sd[2 * hp + 1][tl] = d2[1];
+  }
+  block_sync();
+  const int hh = tid >> 2, q = tid & 3, hg = hb * 64 + hh;
+  if (hg < a.H) {
+    const int64_t o = ((int64_t)b * a.H + hg) * a.L + lb * 64 + 16 * q;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int tl = 16 * q + 4 * i;
+      if (lb * 64 + tl < a.L) {   // L % 4 == 0: a vector is in or out as a whole
+        *reinterpret_cast<f32x4*>(a.dtp + o + 4 * i) = f32x4{sv[hh][tl], sv[hh][tl + 1], sv[hh][tl + 2], sv[hh][tl + 3]};
+        if (a.dsoft) *reinterpret_cast<f32x4*>(a.dsoft + o + 4 * i) = f32x4{sd[hh][tl], sd[hh][tl + 1], sd[hh][tl + 2], sd[hh][tl + 3]};
+      }
     }
   }
 }
@@ -363,12 +432,23 @@ static int ssd_check_common(const OmkTensor& x, const OmkTensor& dt, const OmkTe
   return OMK_OK;
 }
 
-static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdDims& d, float* dtp, float* dsoft, int softplus, float lo, float hi, omk_stream stream) {
+static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdDims& d, float* dtp, float* dsoft, int softplus, float lo, float hi, omk_stream stream,
+                           float* z0 = nullptr, int64_t n0 = 0, float* z1 = nullptr, int64_t n1 = 0, float* z2 = nullptr, int64_t n2 = 0) {
   DtPrepArgs a = {};
+  a.zero[0] = z0; a.nzero[0] = z0 ? (int)n0 : 0; a.zero[1] = z1; a.nzero[1] = z1 ? (int)n1 : 0; a.zero[2] = z2; a.nzero[2] = z2 ? (int)n2 : 0;
   a.dt = dt.data; a.bias = dtb.data; a.dtp = dtp; a.dsoft = dsoft; a.sb = dt.stride[0]; a.sl = dt.stride[1]; a.sh = dt.stride[2];
   a.B = d.B; a.L = d.L; a.H = d.H; a.dt_dt = dt.dtype; a.bias_dt = dtb.dtype; a.softplus = softplus; a.lo = lo;
   a.hi = hi > 0.f ? hi : INFINITY;
-  dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 31) / 32))), block(256);
+  dim3 block(256);
+  const bool vec = (dt.dtype == OMK_BF16 || dt.dtype == OMK_F16) && a.sh == 1 && (a.sl % 2) == 0 && (a.sb % 2) == 0 && ((uintptr_t)dt.data & 3) == 0 &&
+                   (d.H % 2) == 0 && (d.L % 4) == 0 && ((uintptr_t)dtp & 15) == 0 && (!dsoft || ((uintptr_t)dsoft & 15) == 0);
+  if (vec) {
+    dim3 grid((unsigned)((int64_t)d.B * ((d.L + 63) / 64) * ((d.H + 63) / 64)));
+    if (dt.dtype == OMK_BF16) OMK_LAUNCH((ssd_dt_prep_vec_kernel<bf16_t>), grid, block, 0, stream, a);
+    else OMK_LAUNCH((ssd_dt_prep_vec_kernel<f16_t>), grid, block, 0, stream, a);
+    return;
+  }
+  dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 31) / 32)));
   OMK_LAUNCH(ssd_dt_prep_kernel, grid, block, 0, stream, a);
 }
 static void launch_zero(float* p, int64_t n, omk_stream stream) {
@@ -582,10 +662,9 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, path);
   const int64_t bhl = (int64_t)d.B * d.H * d.L, blgn = (int64_t)d.B * d.L * d.G * d.N;
   if (!mfma) { launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream); }
-  launch_zero((float*)p->dA.data, d.H, stream);
-  if (present(p->dD)) launch_zero((float*)p->dD.data, numel(p->dD), stream);
-  if (present(p->ddt_bias)) launch_zero((float*)p->ddt_bias.data, d.H, stream);
-  launch_dt_prep(p->dt, p->dt_bias, d, w.dtp, w.dsoft, p->dt_softplus, p->dt_min, p->dt_max, stream);
+  launch_dt_prep(p->dt, p->dt_bias, d, w.dtp, w.dsoft, p->dt_softplus, p->dt_min, p->dt_max, stream, (float*)p->dA.data, d.H,
+                 present(p->dD) ? (float*)p->dD.data : nullptr, present(p->dD) ? numel(p->dD) : 0,
+                 present(p->ddt_bias) ? (float*)p->ddt_bias.data : nullptr, d.H);
   const float* A = (const float*)p->A.data;
   GScan gdc, gdx, gdb;
   bwd_scans(p, d, w, mfma, &gdc, &gdx, &gdb);
