@@ -18,7 +18,7 @@ SUFFIX = os.environ.get("OMK_LIB_SUFFIX", "")
 LIB = os.path.join(LIBDIR, f"libomnimamba_hip{SUFFIX}.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
-         "-ffp-contract=fast"] + (["-DOMK_PHASE_PROF"] if os.environ.get("OMK_PHASE_PROF") else [])
+         "-ffp-contract=fast"] + (["-DOMK_PHASE_PROF"] if os.environ.get("OMK_PHASE_PROF") else []) + os.environ.get("OMK_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   for (int hi = 0; hi < hps; hi++) {
     const int h = hbeg + hi, sb = hi & 1;
     const bool more = hi + 1 < hps;
-    if (more && !(a.ablate & 8)) { issue_xy(h + 1); issue_sg(h + 1); }   // next head: in flight during both phases
+    if (more && !(a.ablate & 8)) { if (!(a.ablate & 512)) issue_xy(h + 1); if (!(a.ablate & 256)) issue_sg(h + 1); }   // next head: in flight during both phases
     if (hi > 0) readout(h - 1, sb ^ 1);
     // (lane bases of the swizzled tiles; tile row blocks, k steps and column blocks enter as uniform adds / XORs on top of them)
     int oA = ux3(t16, 8 * g16), oB = ux3(mrow, 8 * h32);
@@ -238,38 +238,43 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     // ---- Phase B: inter-window terms; this wave owns rows n of two 32-blocks (2 nh, 2 nh + 1) x tokens 32 mbB ..
     float ep = 0.f, wp = 0.f;
     const float ecm_m = sm.ecm[sb][mrow], wsc_s = sm.wsc[sb][mrow], wsc0_s = sm.wsc0[sb][mrow], dts_s = sm.dts[sb][mrow];
+    // (the k step of the row operands is an XOR on the swizzled segment index: four lane addresses shared by dy and x, both tiles)
+    const int oB0 = oB, oB1 = oB ^ 16, oB2 = oB ^ 32, oB3 = oB ^ 48;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       if (a.ablate & 2) continue;
       const int nbx = 32 * (2 * nh + j);   // column block of the state images: an XOR on the swizzled segment index
+      // oT0, oT1 < 2048 (rows 0 .. 15 of a 128-column tile): the k step (16 rows = 2048 elements) stays an immediate offset
+      const int t0 = oT0 ^ nbx, t1 = oT1 ^ nbx, cb = oC ^ nbx;
       f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const s16x4 f0 = lds_read_tr16_b64(&sm.S[(oT0 + 2048 * ks) ^ nbx]), f1 = lds_read_tr16_b64(&sm.S[(oT1 + 2048 * ks) ^ nbx]);
-        const s16x8 fa = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-        acc = mfma32x32x16_bf16(fa, as_s16x8(ld16(&sm.DY[oB ^ (16 * ks)])), acc);
+#define OMK_CP_STATE_FRAG(tile, ks) ({ const s16x4 f0_ = lds_read_tr16_b64(&(tile)[t0 + 2048 * (ks)]), f1_ = lds_read_tr16_b64(&(tile)[t1 + 2048 * (ks)]); \
+                                       s16x8{f0_[0], f0_[1], f0_[2], f0_[3], f1_[0], f1_[1], f1_[2], f1_[3]}; })
+      {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.S, 0), as_s16x8(ld16(&sm.DY[oB0])), zero16);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.S, 1), as_s16x8(ld16(&sm.DY[oB1])), acc);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.S, 2), as_s16x8(ld16(&sm.DY[oB2])), acc);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.S, 3), as_s16x8(ld16(&sm.DY[oB3])), acc);
       }
       // acc[r] = (S_in^T dy_m)[n], n = 32 nb + 8 (r >> 2) + 4 h32 + (r & 3), m = mrow
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const u32x2 cv = *reinterpret_cast<const u32x2*>(&sm.Cm[oC ^ nbx ^ (8 * q)]);
+        const u32x2 cv = *reinterpret_cast<const u32x2*>(&sm.Cm[cb ^ (8 * q)]);
         const float c4[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
 #pragma unroll
         for (int i = 0; i < 4; i++) { ep += acc[4 * q + i] * c4[i]; dCt[j][4 * q + i] += ecm_m * acc[4 * q + i]; }
       }
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const s16x4 f0 = lds_read_tr16_b64(&sm.Gt[(oT0 + 2048 * ks) ^ nbx]), f1 = lds_read_tr16_b64(&sm.Gt[(oT1 + 2048 * ks) ^ nbx]);
-        const s16x8 fa = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-        acc = mfma32x32x16_bf16(fa, as_s16x8(ld16(&sm.X[oB ^ (16 * ks)])), acc);
+      {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.Gt, 0), as_s16x8(ld16(&sm.X[oB0])), zero16);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.Gt, 1), as_s16x8(ld16(&sm.X[oB1])), acc);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.Gt, 2), as_s16x8(ld16(&sm.X[oB2])), acc);
+        acc = mfma32x32x16_bf16(OMK_CP_STATE_FRAG(sm.Gt, 3), as_s16x8(ld16(&sm.X[oB3])), acc);
       }
+#undef OMK_CP_STATE_FRAG
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const u32x2 bv = *reinterpret_cast<const u32x2*>(&sm.Bm[oC ^ nbx ^ (8 * q)]);
+        const u32x2 bv = *reinterpret_cast<const u32x2*>(&sm.Bm[cb ^ (8 * q)]);
         const float b4[4] = {bf_lo(bv[0]), bf_hi(bv[0]), bf_lo(bv[1]), bf_hi(bv[1])};
 #pragma unroll
         for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
