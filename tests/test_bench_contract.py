@@ -13,13 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--min-seconds", "0", "--no-train-1p3b"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--min-seconds", "0", "--no-train-1p3b", "--no-decode"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "roofline_bwd", "cpu_baseline", "train_1p3b", "train_1p3b_stage2", "selscan_cfg1", "steps_requested"):
+              "dtype", "data", "config", "roofline", "roofline_bwd", "cpu_baseline", "train_1p3b", "train_1p3b_stage2", "selscan_cfg1", "scan_target",
+              "decode_1p3b", "sustained"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
     assert j["unit"] == "M-elements/s" and j["value"] > 0 and abs(j["value"] - 8 * 4096 * 4096 / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 1e-2
@@ -29,18 +30,25 @@ def test_bench_json_contract():
     assert 0.05 < rf["frac"] < 1.0 and (rf["traffic"] is None or rf["traffic"] >= 0.9 * rf["algorithmic_bytes_per_launch"])
     rb = j["roofline_bwd"]
     assert rb["bound"] == "hbm" and rb["algorithmic_bytes_per_launch"] == 8 * 4096 * 25856 and 0.02 < rb["frac"] < 1.0
+    st = j["scan_target"]                          # the north-star target shape: L = 8192, B = 8 and B = 1
+    assert st["B8_L8192"]["algorithmic_bytes"] == 8 * 8192 * 17024 and 0.05 < st["B8_L8192"]["frac_of_hbm_peak"] < 1.0 and st["B1_L8192"]["launch_ms"] > 0
+    assert j["sustained"] is None                  # --min-seconds 0
     c1 = j["selscan_cfg1"]                         # BASELINE configs[0]: HIP selective_scan next to the CPU restatement
     assert c1["rel_l2_vs_cpu_ref"] < 1e-3 and c1["cpu_ref"]["value"] > 0 and c1["hip_B2"]["value"] > c1["cpu_ref"]["value"]
 
 
 @pytest.mark.gpu
-def test_bench_timed_region_is_stretched_to_min_seconds():
+def test_bench_times_exactly_k_steps_and_reports_the_sustained_region_separately():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--min-seconds", "1.0", "--no-train-1p3b", "--no-selscan-cfg1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--min-seconds", "1.0", "--no-train-1p3b", "--no-selscan-cfg1", "--no-scan-target", "--no-decode"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
-    assert j["steps_requested"] == 3 and j["steps"] % 3 == 0 and j["steps"] > 3 and j["timed_seconds"] >= 0.6   # sized from a probe of K steps: +-30 %
-    assert j["roofline"]["launches_timed"] == j["steps"]
+    assert j["steps"] == 3 and j["warmup"] == 1                      # the contract: EXACTLY K timed steps
+    assert abs(j["ms_per_step"] - j["timed_seconds"] / 3 * 1e3) < 0.02 * j["ms_per_step"]
+    su = j["sustained"]                                              # the >= 1 s region behind it (utilisation sampling), never the headline
+    assert su["steps"] > 3 and su["seconds"] >= 0.8
+    assert j["roofline"]["launches_timed"] == 3 + su["steps"]        # the scan launches are HIP-event timed over both regions
 
 
 @pytest.mark.parametrize("n", [1, 2])
