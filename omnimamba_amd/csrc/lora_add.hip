@@ -199,8 +199,11 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
                 "lora_add: mask must be u8 (T, N) with contiguous rows");
     a.mask = (const uint8_t*)p->mask.data; a.ms = p->mask.stride[0];
   }
+  const int nvec = a.N / vec, cvb = (nvec + 255) / 256;
+  // few tokens (a 72-token prefill: 18 workgroups of 64 tokens took 19 us): cut the token blocks until the chip has work
   a.tokens_per_block = 64;
-  const int nvec = a.N / vec, cvb = (nvec + 255) / 256, tbs = (a.T + a.tokens_per_block - 1) / a.tokens_per_block;
+  while (a.tokens_per_block > 8 && (int64_t)cvb * ((a.T + a.tokens_per_block - 1) / a.tokens_per_block) < 256) a.tokens_per_block >>= 1;
+  const int tbs = (a.T + a.tokens_per_block - 1) / a.tokens_per_block;
   dim3 grid((unsigned)((int64_t)cvb * tbs)), block(256);
   if (a.mask) {
     if (a.R == 8) OMK_DISPATCH_DTYPE(p->out.dtype, TO, OMK_LAUNCH((lora_add_kernel<TO, 8, true>), grid, block, 0, stream, a));

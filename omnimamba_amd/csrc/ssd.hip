@@ -204,13 +204,19 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
       sdec[tid] = expf(la); sw[tid] = w; sdt[tid] = d;
     }
     block_sync();
-    for (int tt = 0; tt < nl; tt++) {
-      const int t = a.reverse ? nl - 1 - tt : tt;
+    // The recurrence of a thread's 16 state elements needs nothing from other lanes; only the output does (sum over the TK lanes
+    // of a row).  So the token loop keeps one partial sum per token in registers and the cross-lane sums of all 16 tokens are
+    // formed behind it, as independent shuffle chains -- three DEPENDENT ds_bpermute round trips per token made this loop latency
+    // bound (72 us for a 72-token fp32 prefill layer).  Tokens past the end of a ragged tile are no-ops (decay 1, input 0).
+    float accv[GEN_TT];
+#pragma unroll
+    for (int tt = 0; tt < GEN_TT; tt++) {
+      const int t = a.reverse ? GEN_TT - 1 - tt : tt;
       const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
       float acc = 0.f;
       if (k0 + GEN_NPT <= a.DK && (a.DK & 3) == 0) {
         // the thread's 16 consecutive k as four 16-byte LDS reads per operand (row offsets are multiples of 16 bytes here; the
-        // element-wise form below costs 32 ds_read_b32 per token and thread, and this loop is LDS-bound)
+        // element-wise form below costs 32 ds_read_b32 per token and thread)
         const f32x4* kq = reinterpret_cast<const f32x4*>(sK + t * a.DK + k0);
         const f32x4* qq = reinterpret_cast<const f32x4*>(sQ + t * a.DK + k0);
 #pragma unroll
@@ -232,8 +238,15 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
           }
         }
       }
-      for (int m = TK >> 1; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
-      if (ks == 0) sO[t * RW + r] = acc;
+      accv[t] = acc;
+    }
+    for (int m = TK >> 1; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int t = 0; t < GEN_TT; t++) accv[t] += shfl_xor(accv[t], m);
+    }
+    if (ks == 0) {
+#pragma unroll
+      for (int t = 0; t < GEN_TT; t++) sO[t * RW + r] = accv[t];
     }
     block_sync();
     // ---- epilogue over the tile

@@ -39,6 +39,12 @@ def _top_p_filter_(logits, top_p):
     logits.masked_fill_(remove.scatter(1, sorted_idx, remove), float("-inf"))
 
 
+def _prefill_graph_ok(seqlen):
+    """Short prompts are launch bound: capture them.  Long ones (MMU prompts) run eager -- one graph per length would pin memory."""
+    import os
+    return os.environ.get("OMK_PREFILL_GRAPH", "1") != "0" and seqlen <= 512
+
+
 _draws = 0     # Philox offset of the next host-side call of the device sampler (one stream position per call)
 
 
@@ -114,6 +120,40 @@ class StepGraph:
         self.ip.lengths_per_sample[:] = seqlen
         self.input_ids.copy_(new_ids)
         self.position_ids.copy_(new_pos)
+        self.graph.replay()
+        return self.logits.clone()
+
+
+class PrefillGraph:
+    """The captured PREFILL of a fixed (batch, prompt length): one replay instead of ~20 eager launches per layer (the T2I prompt is
+    always the same length -- caption of 73 ids, omnimamba.py:264 -- and at 72 tokens the prefill is launch bound: 16 ms eager for
+    the 1.3B stack).  Static embedding buffer refreshed by copy_, the caches filled in place by the fused prefill node."""
+
+    def __init__(self, model, inference_params, batch_size, seqlen, d_model, task, dtype, n_warmups=2, mempool=None):
+        dev = next(iter(model.parameters())).device
+        self.ip = inference_params
+        self.emb = torch.zeros(batch_size, seqlen, d_model, dtype=dtype, device=dev)
+        off = inference_params.seqlen_offset
+        inference_params.seqlen_offset = 0
+
+        def fwd():
+            out = model(None, self.emb, position_ids=None, task=task, inference_params=inference_params, num_last_tokens=1)
+            return (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(n_warmups):
+                fwd()
+            s.synchronize()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=mempool):
+            self.logits = fwd()
+        inference_params.seqlen_offset = off
+
+    def run(self, embeddings):
+        self.emb.copy_(embeddings)
         self.graph.replay()
         return self.logits.clone()
 
@@ -211,8 +251,15 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
             cache["graphs"][batch_size, 1, task] = StepGraph(model, cache["ip"], batch_size, cache["max_seqlen"], task, mempool=cache["mempool"])
         inference_params, graph = cache["ip"], cache["graphs"][batch_size, 1, task]
         inference_params.reset(max_length, batch_size)
+        pkey = ("prefill", batch_size, seqlen_og, task, input_embeddings.dtype)
+        if _prefill_graph_ok(seqlen_og) and pkey not in cache["graphs"]:
+            cache["graphs"][pkey] = PrefillGraph(model, cache["ip"], batch_size, seqlen_og, input_embeddings.shape[-1], task,
+                                                 input_embeddings.dtype, mempool=cache["mempool"])
+            inference_params.reset(max_length, batch_size)
+        prefill_graph = cache["graphs"].get(pkey)
     else:
         inference_params = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size)
+        prefill_graph = None
 
     def logits_of(out):
         lg = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
@@ -225,6 +272,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
             trace.append((inference_params.seqlen_offset, None if pos is None else int(pos[0, 0])))
         if graph is not None and decoding:
             lg = graph.run(tokens, pos, inference_params.seqlen_offset)
+            return lg[..., :vocab_size] if vocab_size is not None else lg
+        if prefill_graph is not None and not decoding:
+            lg = prefill_graph.run(embeddings)
             return lg[..., :vocab_size] if vocab_size is not None else lg
         return logits_of(model(tokens, embeddings, position_ids=pos, task=task, inference_params=inference_params,
                                num_last_tokens=1))
@@ -266,11 +316,18 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
                              lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
         cache = {"kind": "device_loop", "key": key, "ip": ip,
                  "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed)}
+        if _prefill_graph_ok(seqlen_og):
+            ip.reset(max_length, batch_size)
+            cache["prefill"] = PrefillGraph(model, ip, batch_size, seqlen_og, input_embeddings.shape[-1], task, input_embeddings.dtype)
         model._decoding_cache = cache
     ip, graph = cache["ip"], cache["graph"]
     ip.reset(max_length, batch_size)
-    out = model(None, input_embeddings, position_ids=None, task=task, inference_params=ip, num_last_tokens=1)
-    lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+    pg = cache.get("prefill")
+    if pg is not None and pg.emb.shape == input_embeddings.shape and pg.emb.dtype == input_embeddings.dtype:
+        lg0 = pg.run(input_embeddings)
+    else:
+        out = model(None, input_embeddings, position_ids=None, task=task, inference_params=ip, num_last_tokens=1)
+        lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
     first = (lg0.argmax(dim=-1, keepdim=True) if top_k == 1 else
              SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=0).unsqueeze(1))
     ip.seqlen_offset = seqlen_og

@@ -125,7 +125,8 @@ class Mamba2(nn.Module):
         zxbcdt = linear(u, self.in_proj.weight, self.in_proj.bias) if type(self.in_proj) is nn.Linear else self.in_proj(u)
         if seqlen_og is not None:
             zxbcdt = zxbcdt.view(batch, seqlen, -1)
-        A = -torch.exp(self.A_log.float())
+        # (inference: the persistent buffer the decode step reads -- two elementwise launches per layer less in a prefill)
+        A = self._A_inference() if (inference_params is not None and not torch.is_grad_enabled()) else -torch.exp(self.A_log.float())
         dt_limit_kwargs = {} if self.dt_limit == (0.0, float("inf")) else dict(dt_limit=self.dt_limit)
         d_mlp = (zxbcdt.shape[-1] - 2 * self.d_ssm - 2 * self.ngroups * self.d_state - self.nheads) // 2
         # prefill of a cached decode takes the same fused node: conv1d + SiLU with the conv_state fill in

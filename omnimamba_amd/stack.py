@@ -356,6 +356,12 @@ class OmniMambaLM(nn.Module):
         embedding MLP for the T2I loop (its inputs are sampled VQ ids)."""
         if task == "t2i" and self.cfg.t2i_task:
             self.backbone.img_embeddings.prepare_decode()
+        # the step graphs read every mixer's persistent -exp(A_log) buffer; with the PREFILL captured too (generation.PrefillGraph) no
+        # eager forward refreshes it any more after an in-place weight update -- do it here, outside any capture
+        if not torch.is_grad_enabled():
+            for blk in self.backbone.layers:
+                if hasattr(blk.mixer, "_A_inference"):
+                    blk.mixer._A_inference()
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.backbone.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
