@@ -143,11 +143,16 @@ __global__ void cvt_f32_kernel(const float* src, void* dst, int64_t sb, int64_t 
 constexpr int GEN_NPT = 16;
 constexpr int GEN_TT = 16;
 
+// F32: every activation source is fp32 (the reference's inference default): plain loads.  With the run-time dtype switch of load_rt
+// every load sits under control flow, the compiler drains the memory pipeline at each one, and the 16 staging loads of a thread
+// became 16 serial round trips per tile (65 us for a 72-token prefill layer).
+template <bool F32>
 __device__ __forceinline__ float src_at(const Src& s, int b, int t, int h, int g, int i) {
-  return load_rt(s.p, (int64_t)b * s.sb + (int64_t)t * s.sl + (int64_t)(s.per_group ? g : h) * s.sh + i, s.dt);
+  const int64_t o = (int64_t)b * s.sb + (int64_t)t * s.sl + (int64_t)(s.per_group ? g : h) * s.sh + i;
+  return F32 ? ((const float*)s.p)[o] : load_rt(s.p, o, s.dt);
 }
 
-template <int MODE>
+template <int MODE, bool F32 = false>
 __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   OMK_DYN_SMEM(smem);
   const int RW = 256 / TK;
@@ -176,21 +181,68 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   }
   float dDacc = 0.f;
   const int nT = (a.L + GEN_TT - 1) / GEN_TT;
+  // F32 specialisation (launched only with DK = 128, TK = 8, RW = 32): the next tile's rows are fetched into registers while this
+  // tile is computed -- 2 + 2 + 8 + 8 + 2 values per thread -- so the global round trips overlap the token loop
+  float pu[2], pz[2], pk[8], pq[8], pd = 0.f, pla = 0.f;
+  auto fetch = [&](int ti_) {
+    const int tile_ = a.reverse ? nT - 1 - ti_ : ti_, t0_ = tile_ * GEN_TT;
+    const int nl_ = (a.L - t0_) < GEN_TT ? (a.L - t0_) : GEN_TT;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = tid + 256 * j, t = i / 32, uu = ub * 32 + (i % 32);
+      const bool ok = t < nl_ && uu < a.DU;
+      const int tc = ok ? t0_ + t : 0, uc = ok ? uu : 0;                     // clamped: unconditional loads
+      const float vu = src_at<true>(a.U, b, tc, h, g, uc);
+      pu[j] = ok ? vu : 0.f;
+      pz[j] = 0.f;
+      if (a.Z.p) { const float vz = src_at<true>(a.Z, b, tc, h, g, uc); pz[j] = ok ? vz : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = tid + 256 * j, t = i / 128, k = i % 128;
+      const int tc = t < nl_ ? t0_ + t : 0;
+      const float vk = src_at<true>(a.K, b, tc, h, g, k), vq = src_at<true>(a.Q, b, tc, h, g, k);
+      pk[j] = t < nl_ ? vk : 0.f;
+      pq[j] = t < nl_ ? vq : 0.f;
+    }
+    if (tid < GEN_TT) {
+      const int t = t0_ + tid;
+      const bool ok = tid < nl_;
+      const int ta = a.reverse ? t + 1 : t;
+      const float d = dtp[ok ? t : 0], da = dtp[(ok && ta < a.L) ? ta : 0];
+      pd = ok ? d : 0.f;
+      pla = (ok && ta < a.L) ? da * Ah : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; j++) { sU[tid + 256 * j] = pu[j]; sX[tid + 256 * j] = pz[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sK[tid + 256 * j] = pk[j]; sQ[tid + 256 * j] = pq[j]; }
+    if (tid < GEN_TT) { sdec[tid] = expf(pla); sw[tid] = a.w_is_dt ? pd : 1.f; sdt[tid] = pd; }
+  };
+  if (F32) { fetch(0); }
   for (int ti = 0; ti < nT; ti++) {
     const int tile = a.reverse ? nT - 1 - ti : ti;
     const int t0 = tile * GEN_TT;
     const int nl = (a.L - t0) < GEN_TT ? (a.L - t0) : GEN_TT;
+    if (F32) {
+      commit();
+      if (tid < GEN_TT && tid >= nl) sw[tid] = 0.f;     // tokens past the end of a ragged tile: no input
+      block_sync();
+      if (ti + 1 < nT) fetch(ti + 1);
+    } else {
     for (int i = tid; i < GEN_TT * RW; i += 256) {
       const int t = i / RW, rr = i % RW, uu = ub * RW + rr;
       const bool ok = t < nl && uu < a.DU;
-      sU[i] = ok ? src_at(a.U, b, t0 + t, h, g, uu) : 0.f;
-      if (MODE == GS_DC || MODE == GS_DB) sX[i] = ok ? src_at(a.X4, b, t0 + t, h, g, uu) : 0.f;
-      if (MODE == GS_Y) sX[i] = (ok && a.Z.p) ? src_at(a.Z, b, t0 + t, h, g, uu) : 0.f;
+      sU[i] = ok ? src_at<F32>(a.U, b, t0 + t, h, g, uu) : 0.f;
+      if (MODE == GS_DC || MODE == GS_DB) sX[i] = ok ? src_at<F32>(a.X4, b, t0 + t, h, g, uu) : 0.f;
+      if (MODE == GS_Y) sX[i] = (ok && a.Z.p) ? src_at<F32>(a.Z, b, t0 + t, h, g, uu) : 0.f;
     }
     for (int i = tid; i < GEN_TT * a.DK; i += 256) {
       const int t = i / a.DK, k = i % a.DK;
-      sK[i] = t < nl ? src_at(a.K, b, t0 + t, h, g, k) : 0.f;
-      sQ[i] = t < nl ? src_at(a.Q, b, t0 + t, h, g, k) : 0.f;
+      sK[i] = t < nl ? src_at<F32>(a.K, b, t0 + t, h, g, k) : 0.f;
+      sQ[i] = t < nl ? src_at<F32>(a.Q, b, t0 + t, h, g, k) : 0.f;
     }
     if (tid < GEN_TT) {
       const int t = t0 + tid;
@@ -203,50 +255,57 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
       }
       sdec[tid] = expf(la); sw[tid] = w; sdt[tid] = d;
     }
+    }
+    if (!F32)
     block_sync();
     // The recurrence of a thread's 16 state elements needs nothing from other lanes; only the output does (sum over the TK lanes
     // of a row).  So the token loop keeps one partial sum per token in registers and the cross-lane sums of all 16 tokens are
     // formed behind it, as independent shuffle chains -- three DEPENDENT ds_bpermute round trips per token made this loop latency
     // bound (72 us for a 72-token fp32 prefill layer).  Tokens past the end of a ragged tile are no-ops (decay 1, input 0).
-    float accv[GEN_TT];
+    // (four tokens per batch: four independent chains hide the round trips; sixteen cost 63 more registers and half the occupancy
+    // of the large-shape launches: 4.9 -> 6.9 ms at B 8, L 4096)
+    for (int tb = 0; tb < GEN_TT; tb += 4) {
+      float accv[4];
 #pragma unroll
-    for (int tt = 0; tt < GEN_TT; tt++) {
-      const int t = a.reverse ? GEN_TT - 1 - tt : tt;
-      const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
-      float acc = 0.f;
-      if (k0 + GEN_NPT <= a.DK && (a.DK & 3) == 0) {
-        // the thread's 16 consecutive k as four 16-byte LDS reads per operand (row offsets are multiples of 16 bytes here; the
-        // element-wise form below costs 32 ds_read_b32 per token and thread)
-        const f32x4* kq = reinterpret_cast<const f32x4*>(sK + t * a.DK + k0);
-        const f32x4* qq = reinterpret_cast<const f32x4*>(sQ + t * a.DK + k0);
+      for (int q = 0; q < 4; q++) {
+        const int tt = tb + q;
+        const int t = a.reverse ? GEN_TT - 1 - tt : tt;
+        const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
+        float acc = 0.f;
+        if (k0 + GEN_NPT <= a.DK && (a.DK & 3) == 0) {
+          // the thread's 16 consecutive k as four 16-byte LDS reads per operand (row offsets are multiples of 16 bytes here; the
+          // element-wise form below costs 32 ds_read_b32 per token and thread)
+          const f32x4* kq = reinterpret_cast<const f32x4*>(sK + t * a.DK + k0);
+          const f32x4* qq = reinterpret_cast<const f32x4*>(sQ + t * a.DK + k0);
 #pragma unroll
-        for (int v = 0; v < GEN_NPT / 4; v++) {
-          const f32x4 kv = kq[v], qv = qq[v];
+          for (int v = 0; v < GEN_NPT / 4; v++) {
+            const f32x4 kv = kq[v], qv = qq[v];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            s[4 * v + e] = s[4 * v + e] * dec + wu * kv[e];
-            acc += s[4 * v + e] * qv[e];
+            for (int e = 0; e < 4; e++) {
+              s[4 * v + e] = s[4 * v + e] * dec + wu * kv[e];
+              acc += s[4 * v + e] * qv[e];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < GEN_NPT; j++) {
+            const int k = k0 + j;
+            if (k < a.DK) {
+              s[j] = s[j] * dec + wu * sK[t * a.DK + k];
+              acc += s[j] * sQ[t * a.DK + k];
+            }
           }
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < GEN_NPT; j++) {
-          const int k = k0 + j;
-          if (k < a.DK) {
-            s[j] = s[j] * dec + wu * sK[t * a.DK + k];
-            acc += s[j] * sQ[t * a.DK + k];
-          }
-        }
+        accv[q] = acc;
       }
-      accv[t] = acc;
-    }
-    for (int m = TK >> 1; m >= 1; m >>= 1) {
+      for (int m = TK >> 1; m >= 1; m >>= 1) {
 #pragma unroll
-      for (int t = 0; t < GEN_TT; t++) accv[t] += shfl_xor(accv[t], m);
-    }
-    if (ks == 0) {
+        for (int q = 0; q < 4; q++) accv[q] += shfl_xor(accv[q], m);
+      }
+      if (ks == 0) {
 #pragma unroll
-      for (int t = 0; t < GEN_TT; t++) sO[t * RW + r] = accv[t];
+        for (int q = 0; q < 4; q++) sO[(a.reverse ? GEN_TT - 1 - (tb + q) : tb + q) * RW + r] = accv[q];
+      }
     }
     block_sync();
     // ---- epilogue over the tile
@@ -305,6 +364,8 @@ int ssd_generic_launch(const GScan& g, omk_stream stream) {
   const int ublocks = (g.DU + RW - 1) / RW;
   dim3 grid((unsigned)((int64_t)g.B * g.H * ublocks)), block(256);
   const size_t smem = (size_t)(GEN_TT * (3 * RW + 2 * g.DK) + 3 * GEN_TT) * 4;
+  const bool f32 = g.U.dt == OMK_F32 && g.K.dt == OMK_F32 && g.Q.dt == OMK_F32 && (!g.Z.p || g.Z.dt == OMK_F32);
+  if (g.mode == GS_Y && f32 && g.DK == 128 && TK == 8) { OMK_LAUNCH((ssd_generic_kernel<GS_Y, true>), grid, block, smem, stream, g, TK); return OMK_OK; }
   switch (g.mode) {
     case GS_Y: OMK_LAUNCH((ssd_generic_kernel<GS_Y>), grid, block, smem, stream, g, TK); break;
     case GS_DC: OMK_LAUNCH((ssd_generic_kernel<GS_DC>), grid, block, smem, stream, g, TK); break;
