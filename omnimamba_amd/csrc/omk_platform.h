@@ -227,6 +227,21 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
 #else
 #define OMK_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
+// Static issue priority of the wave (0 .. 3) from here on.
+#ifdef OMK_EMU
+#define OMK_SET_PRIO(n) do { } while (0)
+#else
+#define OMK_SET_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+// Every vector-memory operation issued so far has completed, and the COMPILER knows it (a real s_waitcnt, not inline asm).  In
+// front of a loop whose back edge carries counted loads behind stores: the wait-count pass merges the scoreboards of the two
+// edges of the loop header, and prologue loads still pending there turn the loop's exact vmcnt(N) into vmcnt(0 / 1) -- a
+// wait for the previous iteration's STORES.
+#ifdef OMK_EMU
+#define OMK_VM_DRAIN() do { } while (0)
+#else
+#define OMK_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
 // Sum of each of 4 per-lane values over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15); every lane of the row gets the
 // totals.  GPU: four row rotations per value with the DPP modifier on the add (no LDS crossbar round trips).
 __device__ __forceinline__ void row16_sum4(float (&v)[4]) {

@@ -45,7 +45,7 @@ struct SmemCp {
   // 10 k of its 19 k cycles per head in them): column sums per Phase A tile, row sums per (wave, strip), Phase B halves per n half
   float colA[2][36][16], rowA[2][8][2][16], eI[2][2][TW], wI[2][2][TW], mw[2][8][4];
   float g5[4][64 * 4], w5[4][64 * 4];   // G1 and the W accumulator of the fifth tile of the even waves (lane-linear float4): register diet
-  float misc[2][8];         // 0 <Graw, S_in>, 1 sum dt w_inter, 2 the same for s < 64, 3 sum_{m >= 64} e_inter, 4 cross block, 5 dD, 6 c_end, 7 dec
+  float ddgs[3][8][2], cdr[3][2];   // per-wave dD and < G, S > sums; c_end and dec: rings of three -- written one head ahead, read one head behind
 };
 static_assert(sizeof(SmemCp) <= 160 * 1024, "one workgroup per CU");
 
@@ -64,8 +64,6 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   const int t0 = win * TW;
   const int nT = (a.L + 63) / 64;
 
-  // ---- zero the accumulating scalars (both buffers)
-  if (tid < 16) (&sm.misc[0][0])[tid] = 0.f;
   // ---- the window's B / C rows (shared by every head of the group)
   {
     const uint16_t* Bb = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
@@ -81,7 +79,10 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   // ---- per-head staging: x, dy rows (two 16-byte segments per thread each), the two state images (two each)
   u32x4 rx[2], ry[2], rs[2], rg[2];
   float rd0 = 0.f, rd1 = 0.f, rdn = 0.f;
-  constexpr int SW = 7;   // the wave that prepares the per-head scalars: it owns four Phase A tiles, the even waves five
+  // Who does the per-head bookkeeping.  Measured per head (tools: OMK_PHASE_PROF build, OMK_CP_PROF=1): the first-dispatched half of
+  // the workgroup (waves 0 - 3) wins the SIMD arbitration and waits 3.4 - 4.7 k of 15.4 k cycles at the first barrier, waves 4 - 7 set
+  // the pace -- so the scalars of the next head (SW), the restart values and the token readout sit on waves 1, 0 and 2.
+  constexpr int SW = 1, RW0 = 0, RW1 = 2, MW = 3;   // scalars, token readout (two halves of the window), restart values
   auto issue_xy = [&](int h) {
     const uint16_t* Xb = a.X + (int64_t)b * a.xsb + (int64_t)h * a.xsh;
     const uint16_t* Yb = a.DY + (int64_t)b * a.ysb + (int64_t)h * a.ysh;
@@ -112,8 +113,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       rg[i] = buf_ld16(Gr, 16u * (uint32_t)(tq + 512 * i), 0u);
     }
   };
-  auto commit = [&](int sb) {   // registers -> LDS; dD and < Graw, S_in > fall out of the staged registers
-    float dd = 0.f, gs = 0.f;
+  auto commit = [&](int) {   // registers -> LDS (between the two barriers of a head: nothing but the eight stores)
     int tq = tid;
     OMK_OPAQUE(tq);
 #pragma unroll
@@ -123,13 +123,20 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       st16(&sm.DY[ux3(row, seg * 8)], ry[i]);
       st16(&sm.S[q * 8], rs[i]);
       st16(&sm.Gt[q * 8], rg[i]);
+    }
+  };
+  // dD and < Graw, S_in > of the staged head fall out of the staging registers: per-wave partial sums into plain slots, ahead of
+  // the first barrier (in the waiting time of the fast waves), summed by the readout
+  auto stage_sums = [&](int ring) {
+    float dd = 0.f, gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int e = 0; e < 4; e++) { dd = dot2_bf16(rx[i][e], ry[i][e], dd); gs = dot2_bf16(rs[i][e], rg[i][e], gs); }
-    }
     dd = wave_sum(dd); gs = wave_sum(gs);
-    if (lane == 0) { lds_add_f32(&sm.misc[sb][5], dd); lds_add_f32(&sm.misc[sb][0], gs); }
+    if (lane == 0) { sm.ddgs[ring][w][0] = dd; sm.ddgs[ring][w][1] = gs; }
   };
-  auto scalars = [&](int h, int sb) {   // wave 0; lanes = tokens 0 .. 63 and 64 .. 127 of the window
+  auto scalars = [&](int h, int sb, int ring) {   // wave 0; lanes = tokens 0 .. 63 and 64 .. 127 of the window
     const float Ah2 = a.A[h] * LOG2E;
     const float c0 = wave_incl_scan_add(rd0 * Ah2);
     const float tot0 = wave_read_lane(c0, 63);
@@ -147,15 +154,17 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     const float k0 = dec * exp2_fast(cend - c0), k1 = dec * exp2_fast(cend - c1);
     sm.wsc0[sb][lane] = k0; sm.wsc0[sb][64 + lane] = k1;
     sm.wsc[sb][lane] = rd0 * k0; sm.wsc[sb][64 + lane] = rd1 * k1;
-    if (lane == 0) { sm.misc[sb][6] = cend; sm.misc[sb][7] = dec; }
+    if (lane == 0) { sm.cdr[ring][0] = cend; sm.cdr[ring][1] = dec; }
   };
 
   // ---- Phase A tiles of this wave: the 36 lower-triangular 16 x 16 tiles (m block, s block).  Row strips i and 7 - i hold
   // 9 tiles together; waves 2 p and 2 p + 1 share the pair (p, 7 - p): the even wave takes five tiles of strip 7 - p, the odd one
   // the rest of it and strip p -- four or five tiles per wave, at most two strips, so the row sums of a strip stay in registers
+  // (roles: waves 0 - 3, the first-dispatched half that wins the SIMD arbitration, take the five-tile roles 0, 2, 4, 6)
+  const int rl = w < 4 ? 2 * w : 2 * (w - 4) + 1;
   int tmb[5], tsb[5], tsl[5];
   {
-    const int p = w >> 1, q = w & 1, big = 7 - p;
+    const int p = rl >> 1, q = rl & 1, big = 7 - p;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
       if (q == 0) { tmb[t] = big; tsb[t] = t; tsl[t] = 0; }
@@ -164,13 +173,13 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       else { tmb[t] = -1; tsb[t] = 0; tsl[t] = 0; }
     }
   }
-  const int strip0 = 7 - (w >> 1), strip1 = w >> 1;
-  const bool has0 = !((w & 1) && (w >> 1) == 3), has1 = (w & 1) != 0;
+  const int strip0 = 7 - (rl >> 1), strip1 = rl >> 1;
+  const bool has0 = !((rl & 1) && (rl >> 1) == 3), has1 = (rl & 1) != 0;
   f32x4 Wt[4], g1[4];   // tiles 0 .. 3; the fifth tile of the even waves keeps both in LDS (sm.w5 / sm.g5)
   f32x16 dCt[2], dBt[2];
 #pragma unroll
   for (int t = 0; t < 4; t++) { Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  if (!(w & 1)) *reinterpret_cast<f32x4*>(&sm.w5[w >> 1][4 * lane]) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!(rl & 1)) *reinterpret_cast<f32x4*>(&sm.w5[rl >> 1][4 * lane]) = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -180,7 +189,8 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   issue_xy(hbeg);
   issue_sg(hbeg);
   commit(0);
-  if (w == SW) scalars(hbeg, 0);
+  stage_sums(0);
+  if (w == SW) scalars(hbeg, 0, 0);
   // G1[m][s] = C_m . B_s of this wave's tiles (the same for every head)
 #pragma unroll
   for (int t = 0; t < 5; t++) {
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     for (int ks = 0; ks < 4; ks++)
       gg = mfma16x16x32_bf16(as_s16x8(ld16(&sm.Cm[kx3(m0 + t16, 32 * ks + 8 * g16)])), as_s16x8(ld16(&sm.Bm[kx3(s0 + t16, 32 * ks + 8 * g16)])), gg);
     if (t < 4) g1[t < 4 ? t : 0] = gg;
-    else *reinterpret_cast<f32x4*>(&sm.g5[w >> 1][4 * lane]) = gg;
+    else *reinterpret_cast<f32x4*>(&sm.g5[rl >> 1][4 * lane]) = gg;
   }
   block_sync();   // head 0 staged
 
@@ -199,11 +209,11 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   const int mrow = 32 * mbB + l31;
   // token scalars, restart values and dD of a finished head from the slots its waves filled (buffer sb): runs while the NEXT head
   // is being computed (waves 3 and 5: tokens; lane 0 of the scalar wave, ahead of its own next write of c_end / dec: the restart values), so nothing of it sits between the two barriers of a head
-  auto readout = [&](int h, int sb) {
+  auto readout = [&](int h, int sb, int ring) {
     if (a.ablate & 64) return;
     const int64_t bh = (int64_t)b * a.H + h;
-    if (w == 3 || w == 5) {
-      int m = (w == 3 ? 0 : 64) + lane;
+    if (w == RW0 || w == RW1) {
+      int m = (w == RW0 ? 0 : 64) + lane;
       OMK_OPAQUE(m);
       const int st = m >> 4, i = m & 15;
       float ev = sm.eI[sb][0][m] + sm.eI[sb][1][m], wv = sm.wI[sb][0][m] + sm.wI[sb][1][m];
@@ -214,22 +224,40 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       const BufRes Er = make_buf(a.e + bh * a.L, (uint32_t)((int64_t)a.L * 4)), Wr = make_buf(a.wsum + bh * a.L, (uint32_t)((int64_t)a.L * 4));
       buf_st_f32(Er, ev, 4u * (uint32_t)(t0 + m), 0u);
       buf_st_f32(Wr, wv, 4u * (uint32_t)(t0 + m), 0u);
-    } else if (w == SW && lane == 0) {
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-      for (int k = 0; k < 8; k++) { s1 += sm.mw[sb][k][0]; s2 += sm.mw[sb][k][1]; s3 += sm.mw[sb][k][2]; s4 += sm.mw[sb][k][3]; }
-      const float qb = exp2_fast(sm.misc[sb][6]) * sm.misc[sb][7] * sm.misc[sb][0];
-      const float q_end = qb + s1, q_mid = qb + s2 + s3 + s4;
-      if (2 * win + 1 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 1] = q_mid;
-      if (2 * win + 2 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 2] = q_end;
-      if (a.dD) atomic_add_f32(a.dD + (int64_t)h * a.dDsh, sm.misc[sb][5]);
-      sm.misc[sb][0] = 0.f; sm.misc[sb][5] = 0.f;
+    } else if (w == MW) {   // lanes 0 .. 7 fetch the eight waves' partial sums, three butterfly steps add them up
+      const int k = lane & 7;
+      f32x4 m4 = *reinterpret_cast<const f32x4*>(&sm.mw[sb][k][0]);
+      f32x2 d2 = *reinterpret_cast<const f32x2*>(&sm.ddgs[ring][k][0]);
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) m4[i] += shfl_xor(m4[i], m);
+        d2[0] += shfl_xor(d2[0], m); d2[1] += shfl_xor(d2[1], m);
+      }
+      if (lane == 0) {
+        const float qb = exp2_fast(sm.cdr[ring][0]) * sm.cdr[ring][1] * d2[1];
+        const float q_end = qb + m4[0], q_mid = qb + m4[1] + m4[2] + m4[3];
+        if (2 * win + 1 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 1] = q_mid;
+        if (2 * win + 2 <= nT) a.bnd[bh * (nT + 1) + 2 * win + 2] = q_end;
+        if (a.dD) atomic_add_f32(a.dD + (int64_t)h * a.dDsh, d2[0]);
+      }
     }
   };
+#ifdef OMK_PHASE_PROF   // developer build: s_memtime deltas per phase, workgroup 0 (printed by ssd_cp_launch under OMK_CP_PROF=1)
+  uint64_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+  uint64_t tprev = prof ? clock64_() : 0;
+#define PTC(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+#else
+#define PTC(i) do { } while (0)
+#endif
+  int r_prev = 2, r_cur = 0, r_next = 1;   // hi - 1, hi, hi + 1 modulo 3
   for (int hi = 0; hi < hps; hi++) {
     const int h = hbeg + hi, sb = hi & 1;
     const bool more = hi + 1 < hps;
-    if (more && !(a.ablate & 8)) { if (!(a.ablate & 512)) issue_xy(h + 1); if (!(a.ablate & 256)) issue_sg(h + 1); }   // next head: in flight during both phases
-    if (hi > 0) readout(h - 1, sb ^ 1);
+    if (more && !(a.ablate & 8) && !(a.ablate & 512)) issue_xy(h + 1);   // next head's rows: in flight during both phases
+    if (hi > 0) readout(h - 1, sb ^ 1, r_prev);
+    PTC(0);
     // (lane bases of the swizzled tiles; tile row blocks, k steps and column blocks enter as uniform adds / XORs on top of them)
     int oA = ux3(t16, 8 * g16), oB = ux3(mrow, 8 * h32);
     int oT0 = kx3(8 * h32 + (t16 >> 2), 16 * (g16 & 1) + 4 * (t16 & 3)), oT1 = kx3(8 * h32 + (t16 >> 2) + 4, 16 * (g16 & 1) + 4 * (t16 & 3));
@@ -280,6 +308,9 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         for (int i = 0; i < 4; i++) { wp += acc[4 * q + i] * b4[i]; dBt[j][4 * q + i] += wsc_s * acc[4 * q + i]; }
       }
     }
+    // the two state images of the next head behind Phase B: sixteen 1 KB requests per wave in one burst stall on the address path
+    if (more && !(a.ablate & 8) && !(a.ablate & 256)) issue_sg(h + 1);
+    PTC(1);
     // ---- Phase A: intra-window terms
     float qm = 0.f;
     float ra0[4] = {0.f, 0.f, 0.f, 0.f}, ra1[4] = {0.f, 0.f, 0.f, 0.f};   // e_intra row sums of the wave's two strips
@@ -310,9 +341,9 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       f32x4 gg;
       if (t < 4) { Wt[t < 4 ? t : 0] += t2 * dss; gg = g1[t < 4 ? t : 0]; }
       else {
-        f32x4* wp5 = reinterpret_cast<f32x4*>(&sm.w5[w >> 1][4 * lane]);
+        f32x4* wp5 = reinterpret_cast<f32x4*>(&sm.w5[rl >> 1][4 * lane]);
         *wp5 = *wp5 + t2 * dss;
-        gg = *reinterpret_cast<const f32x4*>(&sm.g5[w >> 1][4 * lane]);
+        gg = *reinterpret_cast<const f32x4*>(&sm.g5[rl >> 1][4 * lane]);
       }
       const f32x4 d = t2 * gg;
       colv[t] = (d[0] + d[1]) + (d[2] + d[3]);               // w_intra: sum over m (this lane's four rows)
@@ -335,8 +366,9 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       row16_sum4(ra1);
       const float v0 = t16 == 0 ? ra0[0] : (t16 == 1 ? ra0[1] : (t16 == 2 ? ra0[2] : ra0[3]));
       const float v1 = t16 == 0 ? ra1[0] : (t16 == 1 ? ra1[1] : (t16 == 2 ? ra1[2] : ra1[3]));
-      if (t16 < 4) { sm.rowA[sb][w][0][4 * g16 + t16] = v0; sm.rowA[sb][w][1][4 * g16 + t16] = v1; }
+      if (t16 < 4) { sm.rowA[sb][rl][0][4 * g16 + t16] = v0; sm.rowA[sb][rl][1][4 * g16 + t16] = v1; }
     }
+    PTC(2);
     ep += shfl_xor(ep, 32);
     wp += shfl_xor(wp, 32);
     if (!(a.ablate & 128)) {
@@ -346,16 +378,27 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       const float s_all = wave_sum(dtw), s_eh = wave_sum(ei), s_qm = wave_sum(qm);
       if (lane == 0) *reinterpret_cast<f32x4*>(&sm.mw[sb][w][0]) = f32x4{s_all, mbB < 2 ? s_all : 0.f, mbB < 2 ? 0.f : s_eh, s_qm};
     }
-    if (w == SW && more && !(a.ablate & 32)) scalars(h + 1, sb ^ 1);
+    if (more && !(a.ablate & 16)) stage_sums(r_next);
+    PTC(3);
+    if (w == SW && more && !(a.ablate & 32)) scalars(h + 1, sb ^ 1, r_next);
+    PTC(4);
     block_sync();   // every read of this head's tiles is done, its token-scalar slots are complete
+    PTC(5);
     if (more && !(a.ablate & 16)) commit(sb ^ 1);
+    PTC(6);
     block_sync();   // next head staged
+    PTC(7);
+    { const int t_ = r_prev; r_prev = r_cur; r_cur = r_next; r_next = t_; }
   }
-  readout(hbeg + hps - 1, (hps - 1) & 1);
+#ifdef OMK_PHASE_PROF
+  if (prof && lane == 0)
+    for (int i = 0; i < 8; i++) a.prof[w * 8 + i] = pt[i];
+#endif
+  readout(hbeg + hps - 1, (hps - 1) & 1, r_prev);
 
   // ---- W (sum over the heads, fp32 registers) -> bf16 tile [m][s] in LDS;  dC^T += B^T W^T,  dB^T += C^T W
   // (W as a bf16 hi + lo pair: one rounding of W would sit on top of the output rounding of dB / dC -- 1.7e-3 -> 2.3e-3 measured)
-  const f32x4 w5r = *reinterpret_cast<const f32x4*>(&sm.w5[w >> 1][4 * lane]);
+  const f32x4 w5r = *reinterpret_cast<const f32x4*>(&sm.w5[rl >> 1][4 * lane]);
   uint16_t* Wl = sm.X;        // 32 KB: X | DY
   uint16_t* Wlo = sm.S;       // 32 KB: S | Gt
   {
@@ -447,7 +490,28 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
   const size_t smem = sizeof(SmemCp);
   if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
   dim3 grid((unsigned)((int64_t)a.B * a.G * a.nW * a.nhs)), block(512);
+#ifdef OMK_PHASE_PROF
+  static unsigned long long* dprof = nullptr;
+  const bool want = getenv("OMK_CP_PROF") != nullptr;
+  if (want && !dprof) (void)hipMalloc((void**)&dprof, 64 * sizeof(unsigned long long));
+  a.prof = want ? dprof : nullptr;
+#endif
   OMK_LAUNCH(ssd_cp_kernel, grid, block, smem, stream, a);
+#ifdef OMK_PHASE_PROF
+  if (want) {
+    unsigned long long hp[64];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost);
+    const int hps = a.H / a.G / a.nhs;
+    fprintf(stderr, "ssd_cp cycles per head and wave:   top+readout    phaseB    phaseA      tail   scalars     wait1    commit     wait2     total\n");
+    for (int w = 0; w < 8; w++) {
+      unsigned long long tot = 0;
+      fprintf(stderr, "wave %d:                           ", w);
+      for (int i = 0; i < 8; i++) { fprintf(stderr, "%10llu", hp[w * 8 + i] / hps); tot += hp[w * 8 + i]; }
+      fprintf(stderr, "%10llu\n", tot / hps);
+    }
+  }
+#endif
   const int64_t total = (int64_t)a.B * a.L * a.G * 16;
   dim3 fgrid((unsigned)((total + 255) / 256)), fblock(256);
   OMK_LAUNCH(ssd_cp_fold_kernel, fgrid, fblock, 0, stream, (const float*)a.pC, a.dC, a.dcsb, a.dcsl, a.dcsg, a.dC_dt, a.B, a.L, a.G, a.nhs);

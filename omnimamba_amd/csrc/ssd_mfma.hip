@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
 #define PT3(i) do { } while (0)
   constexpr int abl = 0;
 #endif
+  OMK_VM_DRAIN();
   for (int c = c0; c < c1; c++) {
     const int cur = (c - c0) & 1, nxt = cur ^ 1;
     const int tlo = chunk_lo(c);

@@ -120,6 +120,7 @@ struct CpArgs {
   void *dB, *dC; int64_t dbsb, dbsl, dbsg, dcsb, dcsl, dcsg; int dB_dt, dC_dt;
   int B, L, H, G, nW, nhs;
   int ablate;   // developer only (OMK_CP_ABLATE): phases to skip, wrong results
+  unsigned long long* prof;   // developer only (OMK_PHASE_PROF builds, OMK_CP_PROF=1): per-wave phase cycle sums of workgroup 0
 };
 int ssd_cp_heads_split(int B, int L, int H, int G);
 int ssd_cp_launch(const CpArgs& a, omk_stream stream);
