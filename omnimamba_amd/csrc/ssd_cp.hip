@@ -26,6 +26,7 @@
 // underflow only where the exact product underflows too); diagonal tiles evaluate exp2 per element under the causal mask.
 #include <cstdlib>
 
+#include <type_traits>
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
 
@@ -48,6 +49,11 @@ struct SmemCp {
   float ddgs[3][8][2], cdr[3][2];   // per-wave dD and < G, S > sums; c_end and dec: rings of three -- written one head ahead, read one head behind
 };
 static_assert(sizeof(SmemCp) <= 160 * 1024, "one workgroup per CU");
+
+// Phase A tiles of a role (see the kernel): row block, column block, which of the role's two strips (0: strip 7 - p, 1: strip p)
+constexpr int cp_tile_m(int rl, int t) { const int p = rl >> 1, q = rl & 1; return q == 0 ? 7 - p : (t < 3 - p ? 7 - p : (t < 4 ? p : -1)); }
+constexpr int cp_tile_s(int rl, int t) { const int p = rl >> 1, q = rl & 1; return q == 0 ? t : (t < 3 - p ? 5 + t : (t < 4 ? t - (3 - p) : 0)); }
+constexpr int cp_tile_l(int rl, int t) { const int p = rl >> 1, q = rl & 1; return (q == 1 && t >= 3 - p && t < 4) ? 1 : 0; }
 
 __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   OMK_DYN_SMEM(smem_raw);
@@ -163,16 +169,8 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   // (roles: waves 0 - 3, the first-dispatched half that wins the SIMD arbitration, take the five-tile roles 0, 2, 4, 6)
   const int rl = w < 4 ? 2 * w : 2 * (w - 4) + 1;
   int tmb[5], tsb[5], tsl[5];
-  {
-    const int p = rl >> 1, q = rl & 1, big = 7 - p;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      if (q == 0) { tmb[t] = big; tsb[t] = t; tsl[t] = 0; }
-      else if (t < 3 - p) { tmb[t] = big; tsb[t] = 5 + t; tsl[t] = 0; }
-      else if (t < 4) { tmb[t] = p; tsb[t] = t - (3 - p); tsl[t] = 1; }
-      else { tmb[t] = -1; tsb[t] = 0; tsl[t] = 0; }
-    }
-  }
+  for (int t = 0; t < 5; t++) { tmb[t] = cp_tile_m(rl, t); tsb[t] = cp_tile_s(rl, t); tsl[t] = cp_tile_l(rl, t); }
   const int strip0 = 7 - (rl >> 1), strip1 = rl >> 1;
   const bool has0 = !((rl & 1) && (rl >> 1) == 3), has1 = (rl & 1) != 0;
   f32x4 Wt[4], g1[4];   // tiles 0 .. 3; the fifth tile of the even waves keeps both in LDS (sm.w5 / sm.g5)
@@ -315,42 +313,60 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     float qm = 0.f;
     float ra0[4] = {0.f, 0.f, 0.f, 0.f}, ra1[4] = {0.f, 0.f, 0.f, 0.f};   // e_intra row sums of the wave's two strips
     float colv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                              // w_intra column sums of the wave's tiles (this lane's 4 rows)
-#pragma unroll
-    for (int t = 0; t < 5; t++) {
-      if (tmb[t] < 0 || (a.ablate & 1)) continue;
-      const int m0 = 16 * tmb[t], s0 = 16 * tsb[t];
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++)
-        z = mfma16x16x32_bf16(as_s16x8(ld16(&sm.DY[(oA + 64 * m0) ^ (32 * ks)])), as_s16x8(ld16(&sm.X[(oA + 64 * s0) ^ (32 * ks)])), z);
-      // z[r] = dy_m . x_s, m = m0 + 4 g16 + r, s = s0 + t16
-      const float css = sm.c2[sb][s0 + t16], dss = sm.dts[sb][s0 + t16];
-      f32x4 t2;
-      if (m0 != s0) {
-        const float beta = exp2_fast(sm.c2[sb][m0 - 1] - css);
-        const f32x4 al = *reinterpret_cast<const f32x4*>(&sm.alpha[sb][m0 + 4 * g16]);
-        t2 = z * al * beta;
-      } else {
-        const f32x4 cm = *reinterpret_cast<const f32x4*>(&sm.c2[sb][m0 + 4 * g16]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float arg = cm[r] - css;
-          t2[r] = (4 * g16 + r >= t16) ? z[r] * exp2_fast(arg < 0.f ? arg : 0.f) : 0.f;
-        }
+    // The tile positions of a wave are a function of its role, a run-time value -- but only eight of them exist: phase A is compiled
+    // once per role (tile rows / columns, diagonal or not, strip membership, the window-half crossing all constants: immediate LDS
+    // offsets and no branch in front of a tile), and the wave jumps to its copy.
+    auto phaseA = [&](auto role_c) {
+      constexpr int RL = decltype(role_c)::value;
+#define OMK_CP_TILE(T_) do {                                                                                                    \
+      constexpr int mb_ = cp_tile_m(RL, T_), sb_ = cp_tile_s(RL, T_);                                                            \
+      if constexpr (mb_ >= 0) {                                                                                                  \
+        constexpr int m0 = 16 * mb_, s0 = 16 * sb_;                                                                              \
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                                         \
+          z = mfma16x16x32_bf16(as_s16x8(ld16(&sm.DY[(oA + 64 * m0) ^ (32 * ks)])), as_s16x8(ld16(&sm.X[(oA + 64 * s0) ^ (32 * ks)])), z); \
+        /* z[r] = dy_m . x_s, m = m0 + 4 g16 + r, s = s0 + t16 */                                                               \
+        const float css = sm.c2[sb][s0 + t16], dss = sm.dts[sb][s0 + t16];                                                       \
+        f32x4 t2;                                                                                                                \
+        if constexpr (m0 != s0) {                                                                                                \
+          const float beta = exp2_fast(sm.c2[sb][m0 > 0 ? m0 - 1 : 0] - css);                                                    \
+          const f32x4 al = *reinterpret_cast<const f32x4*>(&sm.alpha[sb][m0 + 4 * g16]);                                         \
+          t2 = z * al * beta;                                                                                                    \
+        } else {                                                                                                                 \
+          const f32x4 cm = *reinterpret_cast<const f32x4*>(&sm.c2[sb][m0 + 4 * g16]);                                            \
+          _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                                        \
+            const float arg = cm[r] - css;                                                                                       \
+            t2[r] = (4 * g16 + r >= t16) ? z[r] * exp2_fast(arg < 0.f ? arg : 0.f) : 0.f;                                        \
+          }                                                                                                                      \
+        }                                                                                                                        \
+        f32x4 gg;                                                                                                                \
+        if constexpr (T_ < 4) { Wt[T_ < 4 ? T_ : 0] += t2 * dss; gg = g1[T_ < 4 ? T_ : 0]; }                                      \
+        else {                                                                                                                   \
+          f32x4* wp5 = reinterpret_cast<f32x4*>(&sm.w5[RL >> 1][4 * lane]);                                                      \
+          *wp5 = *wp5 + t2 * dss;                                                                                                \
+          gg = *reinterpret_cast<const f32x4*>(&sm.g5[RL >> 1][4 * lane]);                                                       \
+        }                                                                                                                        \
+        const f32x4 d = t2 * gg;                                                                                                 \
+        colv[T_] = (d[0] + d[1]) + (d[2] + d[3]);               /* w_intra: sum over m (this lane's four rows) */                \
+        const f32x4 dv = d * dss;                               /* e_intra: sum over s of dt_s T (C . B), kept per strip */      \
+        if constexpr (m0 >= 64 && s0 < 64) qm += (dv[0] + dv[1]) + (dv[2] + dv[3]);                                              \
+        if constexpr (cp_tile_l(RL, T_) != 0) { ra1[0] += dv[0]; ra1[1] += dv[1]; ra1[2] += dv[2]; ra1[3] += dv[3]; }            \
+        else { ra0[0] += dv[0]; ra0[1] += dv[1]; ra0[2] += dv[2]; ra0[3] += dv[3]; }                                             \
+      } } while (0)
+      OMK_CP_TILE(0); OMK_CP_TILE(1); OMK_SCHED_FENCE(); OMK_CP_TILE(2); OMK_CP_TILE(3); OMK_SCHED_FENCE(); OMK_CP_TILE(4);   // (pairs: five interleaved tiles do not fit the registers)
+#undef OMK_CP_TILE
+    };
+    if (!(a.ablate & 1)) {
+      switch (rl) {
+        case 0: phaseA(std::integral_constant<int, 0>{}); break;
+        case 1: phaseA(std::integral_constant<int, 1>{}); break;
+        case 2: phaseA(std::integral_constant<int, 2>{}); break;
+        case 3: phaseA(std::integral_constant<int, 3>{}); break;
+        case 4: phaseA(std::integral_constant<int, 4>{}); break;
+        case 5: phaseA(std::integral_constant<int, 5>{}); break;
+        case 6: phaseA(std::integral_constant<int, 6>{}); break;
+        default: phaseA(std::integral_constant<int, 7>{}); break;
       }
-      f32x4 gg;
-      if (t < 4) { Wt[t < 4 ? t : 0] += t2 * dss; gg = g1[t < 4 ? t : 0]; }
-      else {
-        f32x4* wp5 = reinterpret_cast<f32x4*>(&sm.w5[rl >> 1][4 * lane]);
-        *wp5 = *wp5 + t2 * dss;
-        gg = *reinterpret_cast<const f32x4*>(&sm.g5[rl >> 1][4 * lane]);
-      }
-      const f32x4 d = t2 * gg;
-      colv[t] = (d[0] + d[1]) + (d[2] + d[3]);               // w_intra: sum over m (this lane's four rows)
-      const f32x4 dv = d * dss;                               // e_intra: sum over s of dt_s T (C . B), kept per strip
-      if (m0 >= 64 && s0 < 64) qm += (dv[0] + dv[1]) + (dv[2] + dv[3]);
-      if (tsl[t]) { ra1[0] += dv[0]; ra1[1] += dv[1]; ra1[2] += dv[2]; ra1[3] += dv[3]; }
-      else { ra0[0] += dv[0]; ra0[1] += dv[1]; ra0[2] += dv[2]; ra0[3] += dv[3]; }
     }
     if (!(a.ablate & 1)) {
       // column sums: the other twelve rows of a tile sit in the lanes 16, 32, 48 further on
