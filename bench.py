@@ -194,12 +194,11 @@ def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage
 
 def scan_target(dev):
     """The north-star target shape: the Mamba-2 chunked scan (omk_ssd_scan_fwd through mamba_chunk_scan_combined) at L = 8192,
-    d_model 2048 (H 64, P 64, N 128, one group), bf16, B = 8 and B = 1; HIP events on the launch stream, algorithmic bytes of
-    SURVEY.md section 8d (17 024 B per token)."""
+    d_model 2048 (H 64, P 64, N 128, one group), bf16, B = 8 and B = 1, and the plain (inference-form) forward at the shape of the
+    timed step (B 8, L 4096); HIP events on the launch stream, algorithmic bytes of SURVEY.md section 8d (17 024 B per token)."""
     from omnimamba_amd.ssd_combined import mamba_chunk_scan_combined
     out = {}
-    L = 8192
-    for Bsz in (8, 1):
+    for L, Bsz in ((4096, 8), (8192, 8), (8192, 1)):   # (the first: the plain forward at the shape of the timed step, whose own forward also writes window states)
         torch.manual_seed(0)
         x = torch.randn(Bsz, L, H, HEADDIM, device=dev, dtype=torch.bfloat16)
         dt = (torch.randn(Bsz, L, H, device=dev) * 0.5).bfloat16()
@@ -402,6 +401,8 @@ def main():
                     traffic[key] = (int(tj["traffic_bytes_per_launch"]), tj.get("source"))
             except (OSError, KeyError, ValueError):
                 traffic[key] = (None, None)
+        from omnimamba_amd.ssd_combined import save_window_states_enabled
+        save_ws = save_window_states_enabled()
         out = {
             "metric": "selective-scan M-elements/sec", "value": round(value, 1), "unit": "M-elements/s",
             "n_gpus": world, "steps": nsteps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -411,11 +412,14 @@ def main():
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
                        "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
-            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel" + (
+                             "; the forward also leaves its window states behind for the backward: +256 MiB of writes that are not algorithmic bytes; the plain forward of this shape is scan_target.B8_L4096)"
+                             if save_ws else ")"),
                          "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
                          "traffic": traffic["fwd"][0], "traffic_source": traffic["fwd"][1],
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
-            "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + state-only forward pass + dx scan with window-state dumps + ssd_cp_kernel + folds + finish)",
+            "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + " + ("" if save_ws else "state-only forward pass + ") + "dx scan with window-state dumps + ssd_cp_kernel + folds + finish" + (
+                                 "; forward window states saved by the training forward)" if save_ws else ")"),
                              "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
                              "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1],
                              "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": round(ms_b, 4), "launches_timed": n_b},

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 3
+#define OMK_ABI_VERSION 4
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -280,6 +280,11 @@ typedef struct {
                              * OMK_EUNSUPPORTED; Cm, D are ignored */
   OmkTensor out_x;          /* optional out (B, L, H, P): the pre-gate y (only meaningful with z; saved for backward) */
   OmkTensor final_states;   /* optional out (B, H, P, N) f32 */
+  OmkTensor window_states;  /* optional out, bf16, contiguous, omk_ssd_scan_fwd_window_states_bytes(p) bytes: the carried state in
+                             * front of every 128-token window, (B, ceil(L / 128), H) images of 16 KB in the kernel's own operand
+                             * layout.  A training forward saves it and hands it to omk_ssd_scan_bwd, which then skips its own
+                             * state pass over x (upstream's backward recomputes the chunk states the same way, ssd_combined.py
+                             * _mamba_chunk_scan_combined_bwd).  Opaque: only omk_ssd_scan_bwd reads it */
   void* workspace;
   size_t workspace_bytes;
   float dt_min, dt_max;     /* clamp (dt_limit); (0, +inf) = none */
@@ -288,6 +293,9 @@ typedef struct {
   int32_t force_generic;    /* 1 = use the shape-generic fp32 VALU kernel even when the MFMA kernel applies */
 } OmkSsdFwd;
 size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p);
+/* bytes of window_states for these arguments (window_states itself is not looked at); 0 = this forward cannot save them (shape
+ * outside the MFMA kernel, gate / out_x requested, fp32 activations): pass none */
+size_t omk_ssd_scan_fwd_window_states_bytes(const OmkSsdFwd* p);
 int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream);
 
 typedef struct {
@@ -305,6 +313,8 @@ typedef struct {
   OmkTensor dD;              /* optional out (H) or (H, P) f32 */
   OmkTensor ddt_bias;        /* optional out (H) f32 */
   OmkTensor dinitial_states; /* optional out (B, H, P, N) f32 */
+  OmkTensor window_states;   /* optional in: what omk_ssd_scan_fwd left in its window_states for the SAME x, dt, A, Bm, dt_bias,
+                                initial_states and clamp; ignored by the paths that do not use window states */
   void* workspace;
   size_t workspace_bytes;
   float dt_min, dt_max;

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 3
+OMK_ABI_VERSION = 4
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
@@ -73,11 +73,11 @@ NormLinear = _S("OmkNormLinear", [(n, _t) for n in ("x", "residual", "z", "norm_
 LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b", "mask")] + [("scale", _f)])
 LoraUpBwd = _S("OmkLoraUpBwd", [(n, _t) for n in ("dy", "lora_b", "h", "dh", "dlora_b")])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
-                                            "out_x", "final_states")] + _ws
+                                            "out_x", "final_states", "window_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
 SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "dt_bias", "initial_states", "y", "dout",
                                             "dfinal_states", "dx", "ddt", "dA", "dB", "dC", "dD", "ddt_bias",
-                                            "dinitial_states")] + _ws
+                                            "dinitial_states", "window_states")] + _ws
             + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
 
 CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("losses", _t), ("grad_scale", C.c_void_p),
@@ -97,7 +97,7 @@ SYMBOLS = [
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
     "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
-    "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
+    "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd_window_states_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
     "omk_cross_entropy", "omk_lora_up_bwd_parts", "omk_sample",
 ]
 
@@ -111,7 +111,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.omk_sizeof.argtypes = [C.c_char_p]
     for s in SYMBOLS:
         fn = getattr(lib, s)  # raises AttributeError when a declared symbol is missing
-        if s.endswith("_workspace_bytes"):
+        if s.endswith("_workspace_bytes") or s.endswith("_window_states_bytes"):
             fn.restype = C.c_size_t
             fn.argtypes = [C.c_void_p]
         elif s == "omk_lora_up_bwd_parts":

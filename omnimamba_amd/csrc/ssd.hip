@@ -549,6 +549,18 @@ extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
   return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024 + ssd_seg_bytes((int)(p->x.shape[0] * p->x.shape[2]), (int)p->x.shape[1]);
 }
 
+// Can this forward leave its window states behind, and how large are they?  The class-A MFMA kernel of the plain scan only (bf16,
+// headdim 64, d_state 128, no gate, no pre-gate copy: the instantiations a training forward of the model uses).
+static size_t fwd_window_states_bytes(const OmkSsdFwd* p) {
+  if (!p || p->force_generic || !present(p->out) || present(p->z) || present(p->out_x)) return 0;
+  if (p->x.ndim != 4 || p->Bm.ndim != 4 || p->x.dtype != OMK_BF16 || p->x.shape[3] != 64 || p->Bm.shape[3] != 128) return 0;
+  if (const char* e = getenv("OMK_SSD_KHILO")) if (e[0] == '1') return 0;
+  if (const char* e = getenv("OMK_SSD_PRECISE")) if (e[0] == '1') return 0;
+  const int64_t B = p->x.shape[0], L = p->x.shape[1], H = p->x.shape[2];
+  return (size_t)B * ((L + 127) / 128) * H * 16384;
+}
+extern "C" size_t omk_ssd_scan_fwd_window_states_bytes(const OmkSsdFwd* p) { return fwd_window_states_bytes(p); }
+
 extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   OMK_REQUIRE(p && (present(p->out) || present(p->final_states)), "ssd_scan_fwd: out (or, for the state-only pass, final_states) required");
   SsdDims d;
@@ -590,6 +602,16 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (state_only) {
     rc = (p->force_generic || p->x.dtype != OMK_BF16) ? OMK_EUNSUPPORTED : ssd_mfma_state_only(g, stream);
     if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the state-only pass exists for the MFMA shape only (bf16, headdim 64, d_state 128); run the scan and drop its output");
+    if (rc) return rc;
+    return finish_launch("ssd_scan_fwd");
+  }
+  if (present(p->window_states)) {
+    const size_t need = fwd_window_states_bytes(p);
+    OMK_REQUIRE(need > 0, "ssd_scan_fwd: this forward cannot save window states (omk_ssd_scan_fwd_window_states_bytes is 0 for these arguments)");
+    OMK_REQUIRE(p->window_states.dtype == OMK_BF16 && (size_t)numel(p->window_states) * 2 >= need, "ssd_scan_fwd: window_states must be bf16 with omk_ssd_scan_fwd_window_states_bytes(p) bytes");
+    g.dump = (uint16_t*)p->window_states.data; g.dump_nw = (d.L + 127) / 128;
+    rc = ssd_mfma_launch(g, stream);
+    if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: window_states asked for on a shape outside the MFMA kernel (strides / alignment)");
     if (rc) return rc;
     return finish_launch("ssd_scan_fwd");
   }
@@ -754,7 +776,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     }
     gf.seg = w.segf;
     int fmt_f = 0, fmt_a = 0;   // element order each pass left its states in (ssd_scan.h: seg_fmt)
-    if ((rc = ssd_mfma_prepare_segments(gf, stream, &fmt_f))) return rc;
+    if (!(cp && present(p->window_states)) && (rc = ssd_mfma_prepare_segments(gf, stream, &fmt_f))) return rc;   // (saved window states: no forward state pass at all)
     if ((rc = ssd_mfma_prepare_segments(gdx, stream, &fmt_a))) return rc;
     gdc.seg = w.segf; gdc.seg_ready = 1; gdc.seg_fmt = fmt_f;
     gdx.seg_ready = 1; gdx.seg_fmt = fmt_a;
@@ -772,8 +794,15 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
       gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
     }
     if (gdc.seg_ready) { gf.seg = w.segf; gf.seg_ready = 1; gf.seg_fmt = gdc.seg_fmt; }
-    gf.dump = w.Sf; gf.dump_nw = nW;
-    if ((rc = ssd_mfma_state_dump(gf, stream))) return rc;
+    // (a training forward that saved its window states spares this pass: the same images, written by the same code)
+    const uint16_t* Sf = w.Sf;
+    if (present(p->window_states)) {
+      OMK_REQUIRE(p->window_states.dtype == OMK_BF16 && (size_t)numel(p->window_states) >= (size_t)d.B * nW * d.H * 8192, "ssd_scan_bwd: window_states too small");
+      Sf = (const uint16_t*)p->window_states.data;
+    } else {
+      gf.dump = w.Sf; gf.dump_nw = nW;
+      if ((rc = ssd_mfma_state_dump(gf, stream))) return rc;
+    }
     gdx.dump = w.Sg; gdx.dump_nw = nW;
     if ((rc = ssd_mfma_launch(gdx, stream))) return rc;
     CpArgs c = {};
@@ -781,7 +810,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     c.DY = (const uint16_t*)p->dout.data; c.ysb = p->dout.stride[0]; c.ysl = p->dout.stride[1]; c.ysh = p->dout.stride[2];
     c.Bm = (const uint16_t*)p->Bm.data; c.bsb = p->Bm.stride[0]; c.bsl = p->Bm.stride[1]; c.bsg = p->Bm.stride[2];
     c.Cm = (const uint16_t*)p->Cm.data; c.csb = p->Cm.stride[0]; c.csl = p->Cm.stride[1]; c.csg = p->Cm.stride[2];
-    c.dtp = w.dtp; c.A = A; c.Sf = w.Sf; c.Sg = w.Sg; c.e = w.e; c.wsum = w.wsum; c.bnd = w.bnd;
+    c.dtp = w.dtp; c.A = A; c.Sf = Sf; c.Sg = w.Sg; c.e = w.e; c.wsum = w.wsum; c.bnd = w.bnd;
     if (present(p->dD)) { c.dD = (float*)p->dD.data; c.dDsh = p->dD.stride[0]; }
     c.pB = w.pB; c.pC = w.pC;
     c.dB = p->dB.data; c.dbsb = p->dB.stride[0]; c.dbsl = p->dB.stride[1]; c.dbsg = p->dB.stride[2]; c.dB_dt = p->dB.dtype;

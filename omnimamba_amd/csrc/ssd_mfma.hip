@@ -69,10 +69,12 @@ static_assert(sizeof(SmemA3) <= 80 * 1024, "two workgroups must fit the 160 KB o
 // nseg workgroups per head) starts every segment from the fold of the earlier segments' states.
 // DFOLD (forward, one D per head): D x_l rides on the diagonal of M (M_ll += D, kept to 16 bits by the hi + lo split)
 // instead of an epilogue that re-reads x and D from LDS.
+// DUMP (forward of a training step): the scan leaves the carried state in front of every 128-token window behind (GScan::dump), as the
+// dx scan and the state-only pass do -- a separate instantiation so that the inference forward carries none of it.
 // KHILO (forward, OMK_SSD_KHILO): the w_l K_l operand of the state update enters as a bf16 hi + lo pair (8 more 32x32x16 MFMAs per
 // wave and chunk, no LDS): the carried state -- and with it final_states -- is then exact to fp32 accumulation instead of carrying
 // one bf16 rounding per chunk (1.7e-3 -> 1e-5 on the final state; y of slow-decay heads 1.4e-3 -> 1.0e-3).
-template <int MODE, bool EXTRAS, bool STATE, bool DFOLD = false, bool KHILO = false>
+template <int MODE, bool EXTRAS, bool STATE, bool DFOLD = false, bool KHILO = false, bool DUMP = false>
 __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA3& sm = *reinterpret_cast<SmemA3*>(smem_raw);
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
     const int tlo = chunk_lo(c);
     const int cnext = c + 1 < c1 ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
     PT3(0);
-    if ((MODE == GS_DX || STATE) && a.dump) {   // (compiled out of the forward scan) window-boundary image of the state in front of this chunk (sm.S, published before the last barrier)
+    if ((MODE == GS_DX || STATE || DUMP) && a.dump) {   // (compiled out of the forward scan) window-boundary image of the state in front of this chunk (sm.S, published before the last barrier)
       const int cid = rev ? nC - 1 - c : c;
       const bool here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
       if (here) {
@@ -1055,6 +1057,16 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   }
   const bool dfold = !a.D || a.Dsp == 0;   // one D per head (or none)
   if (a.mode == GS_Y && (a.Z.p || a.outx)) { if (dfold) OMK_A3(GS_Y, true, false, true, grid); else OMK_A3(GS_Y, true, false, false, grid); }
+  else if (a.mode == GS_Y && a.dump) {   // (ssd.hip only asks for dumps without gate / pre-gate copy / KHILO)
+    if (khilo) return OMK_EUNSUPPORTED;
+    if (dfold) {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, false, true, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+      OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, false, true, false, true>), grid, block, smem, stream, a);
+    } else {
+      if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, false, false, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+      OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, false, false, false, true>), grid, block, smem, stream, a);
+    }
+  }
   else if (a.mode == GS_Y) { if (dfold) OMK_A3(GS_Y, false, false, true, grid); else OMK_A3(GS_Y, false, false, false, grid); }
   else OMK_A3(GS_DX, false, false, false, grid);
 #undef OMK_A3

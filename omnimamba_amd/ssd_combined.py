@@ -28,10 +28,17 @@ def _last_contig(t):
     return t if t is None or t.stride(-1) == 1 else t.contiguous()
 
 
+def save_window_states_enabled() -> bool:
+    """OMK_SSD_SAVE_WINDOW_STATES=0: a training forward does not keep its window states (16 KB per head and 128 tokens); the
+    backward then recomputes them with a state pass over x, as upstream's backward recomputes its chunk states."""
+    return os.environ.get("OMK_SSD_SAVE_WINDOW_STATES", "1") != "0"
+
+
 def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=None, dt_softplus=False,
                  dt_limit=(0.0, _INF), return_final_states=False, want_out_x=False, chunk_size=256,
-                 force_generic=False):
-    """Raw (non-autograd) forward: returns (out, out_x | None, final_states | None)."""
+                 force_generic=False, save_window_states=False):
+    """Raw (non-autograd) forward: returns (out, out_x | None, final_states | None), with save_window_states=True a fourth
+    element: the opaque window-state tensor omk_ssd_scan_bwd takes (None when this forward cannot produce it)."""
     lib = get_lib()
     require_device(lib, x, dt, A, B, C, D, z, dt_bias, initial_states)
     x, B, C, z = _last_contig(x), _last_contig(B), _last_contig(C), _last_contig(z)
@@ -47,22 +54,30 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
     out = torch.empty(Bsz, L, H, P, dtype=x.dtype, device=x.device)
     out_x = torch.empty_like(out) if (want_out_x and z is not None) else None
     fin = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=x.device) if return_final_states else None
+    wstates = None
     if x.numel() > 0:
         p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), z=K.T(z), dt_bias=K.T(dt_bias),
                      initial_states=K.T(initial_states), out=K.T(out), out_x=K.T(out_x), final_states=K.T(fin),
                      dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]), dt_softplus=int(dt_softplus),
                      chunk_size=int(chunk_size), force_generic=int(force_generic))
         ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
+        if save_window_states:
+            nbytes = lib.omk_ssd_scan_fwd_window_states_bytes(K.C.byref(p))
+            if nbytes:
+                wstates = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=x.device)
+                p.window_states = K.T(wstates)
         with _prof.range_("ssd_scan_fwd"):
             K.run(lib, "omk_ssd_scan_fwd", p, x)
     elif fin is not None:
         fin.zero_() if initial_states is None else fin.copy_(initial_states)
+    if save_window_states:
+        return out, out_x, fin, wstates
     return out, out_x, fin
 
 
 def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
                  dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None,
-                 dx_out=None, dB_out=None, dC_out=None):
+                 dx_out=None, dB_out=None, dC_out=None, window_states=None):
     """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states).  `y` = the forward's pre-gate
     output (D*x included); with it the MFMA path applies."""
     lib = get_lib()
@@ -95,7 +110,7 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
         p = K.SsdBwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), dt_bias=K.T(dt_bias),
                      initial_states=K.T(initial_states), y=K.T(y), dout=K.T(dout), dfinal_states=K.T(dfinal_states), dx=K.T(dx),
                      ddt=K.T(ddt), dA=K.T(dA), dB=K.T(dB), dC=K.T(dC), dD=K.T(dD), ddt_bias=K.T(ddtb),
-                     dinitial_states=K.T(dinit), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
+                     dinitial_states=K.T(dinit), window_states=K.T(window_states), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
                      dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic))
         ws = K.workspace(lib, "omk_ssd_scan_bwd_workspace_bytes", p, x)  # noqa: F841
         with _prof.range_("ssd_scan_bwd"):
@@ -183,17 +198,19 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
         if seq_idx is not None or cu_seqlens is not None or return_varlen_states:
             raise NotImplementedError("seq_idx / cu_seqlens / varlen states never reach the mixer in OmniMamba "
                                       "(models/stage2/mixer_seq_simple.py:375,408-420)")
-        out, out_x, fin = ssd_scan_fwd(x, dt, A, B, C, D=D, z=z, dt_bias=dt_bias, initial_states=initial_states,
-                                       dt_softplus=dt_softplus, dt_limit=dt_limit,
-                                       return_final_states=return_final_states, want_out_x=True, chunk_size=chunk_size)
-        ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x if z is not None else out)
+        keep_ws = any(ctx.needs_input_grad) and save_window_states_enabled()
+        r = ssd_scan_fwd(x, dt, A, B, C, D=D, z=z, dt_bias=dt_bias, initial_states=initial_states, dt_softplus=dt_softplus,
+                         dt_limit=dt_limit, return_final_states=return_final_states, want_out_x=True, chunk_size=chunk_size,
+                         save_window_states=keep_ws)
+        (out, out_x, fin), wst = r[:3], (r[3] if keep_ws else None)
+        ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x if z is not None else out, wst)
         ctx.dt_softplus, ctx.dt_limit, ctx.chunk_size = dt_softplus, dt_limit, chunk_size
         ctx.return_final_states = return_final_states
         return (out, fin) if return_final_states else out
 
     @staticmethod
     def backward(ctx, dout, *args):
-        x, dt, A, B, C, D, z, dt_bias, initial_states, out_x = ctx.saved_tensors
+        x, dt, A, B, C, D, z, dt_bias, initial_states, out_x, wst = ctx.saved_tensors
         dfinal = args[0] if ctx.return_final_states and args else None
         dz = None
         if z is not None:
@@ -202,7 +219,7 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
             dout = (dout.float() * F.silu(zf)).to(x.dtype)
         g = ssd_scan_bwd(dout, x, dt, A, B, C, D=D, dt_bias=dt_bias, initial_states=initial_states,
                          dfinal_states=dfinal, dt_softplus=ctx.dt_softplus, dt_limit=ctx.dt_limit,
-                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None, y=out_x)
+                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None, y=out_x, window_states=wst)
         dinit = g["dinitial_states"]
         return (g["dx"], g["ddt"].to(dt.dtype), g["dA"].to(A.dtype), g["dB"].to(B.dtype), g["dC"].to(C.dtype), None,
                 None if D is None else g["dD"].to(D.dtype), dz,
@@ -260,10 +277,12 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
         use_norm = rmsnorm_weight is not None
         zz = z.reshape(Bsz, L, H, P) if z.is_contiguous() else z.unflatten(-1, (H, P))
-        y, y_x, fin = ssd_scan_fwd(x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)), Cm.unflatten(-1, (G, N)), D=D,
-                                   z=None if use_norm else zz, dt_bias=dt_bias, initial_states=initial_states,
-                                   dt_softplus=True, dt_limit=dt_limit, return_final_states=return_final_states,
-                                   want_out_x=True, chunk_size=chunk_size)
+        keep_ws = any(ctx.needs_input_grad) and save_window_states_enabled()
+        r = ssd_scan_fwd(x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)), Cm.unflatten(-1, (G, N)), D=D,
+                         z=None if use_norm else zz, dt_bias=dt_bias, initial_states=initial_states,
+                         dt_softplus=True, dt_limit=dt_limit, return_final_states=return_final_states,
+                         want_out_x=True, chunk_size=chunk_size, save_window_states=keep_ws)
+        (y, y_x, fin), wst = r[:3], (r[3] if keep_ws else None)
         y_pre = y if (use_norm or y_x is None) else y_x        # pre-gate / pre-norm scan output (D*x included)
         if use_norm:
             out_n = rmsnorm_fn(y.reshape(Bsz, L, d_ssm), rmsnorm_weight, None, z=z, eps=rmsnorm_eps,
@@ -282,14 +301,14 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         need_wo = outproj_weight is not None and ctx.needs_input_grad[14]
         ctx.save_for_backward(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, y_pre, rmsnorm_weight, outproj_weight,
                               outproj_bias, initial_states, xBC_c if keep else None,
-                              out_n if (keep and use_norm and need_wo) else None)
+                              out_n if (keep and use_norm and need_wo) else None, wst)
         ctx.cfg = (H, P, G, N, chunk_size, dt_limit, activation, rmsnorm_eps, norm_before_gate, return_final_states)
         return (out, fin) if return_final_states else out
 
     @staticmethod
     def backward(ctx, dout, *args):
         (zxbcdt, conv_w, conv_b, dt_bias, A, D, y_pre, norm_w, outproj_w, outproj_b, initial_states, xBC_saved,
-         on_saved) = ctx.saved_tensors
+         on_saved, wst) = ctx.saved_tensors
         H, P, G, N, chunk_size, dt_limit, activation, eps, nbg, ret_fin = ctx.cfg
         dfinal = args[0] if ret_fin and args else None
         Bsz, L, _ = zxbcdt.shape
@@ -361,7 +380,7 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
                          Cm.unflatten(-1, (G, N)), D=D, dt_bias=dt_bias, initial_states=initial_states,
                          dfinal_states=dfinal, dt_softplus=True, dt_limit=dt_limit, chunk_size=chunk_size,
                          need_dinit=initial_states is not None, y=y_pre, dx_out=dx_v.unflatten(-1, (H, P)),
-                         dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)))
+                         dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)), window_states=wst)
         ddt_v.copy_(g["ddt"])
         # ---- conv backward: dx lands in the xBC slice of dzxbcdt
         dw = torch.zeros(conv_w.shape, dtype=torch.float32, device=dev)

@@ -227,6 +227,43 @@ def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc, cp):
             assert e < tol[n], (n, e, cp)
 
 
+@pytest.mark.parametrize("L,H,G,with_init,minc", [(130, 2, 1, False, None), (300, 4, 2, True, None), (330, 2, 1, True, 2)])
+def test_ssd_bwd_with_window_states_saved_by_the_forward(dev, monkeypatch, L, H, G, with_init, minc):
+    """A training forward leaves the carried state in front of every 128-token window behind (OmkSsdFwd.window_states); the backward
+    that receives it skips its own state pass over x.  Same images from the same code: the gradients are IDENTICAL to the ones of
+    the recomputing backward (OMK_SSD_SAVE_WINDOW_STATES=0), the forward output identical to the forward without the dumps, and a
+    forward that cannot save them (gate requested) reports 0 bytes."""
+    if minc:
+        monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
+    import omnimamba_amd.ssd_combined as S
+    P, N = 64, 128
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=11)
+    A = -(torch.rand(H, generator=torch.Generator().manual_seed(3)) * 15 + 1)
+    if not with_init:
+        init = None
+    src = [x, dt, A, Bm, Cm, D, dtb, init]
+    gy = torch.randn(1, L, H, P, generator=torch.Generator().manual_seed(4)).bfloat16()
+    grads, outs = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMK_SSD_SAVE_WINDOW_STATES", mode)
+        leaves = [None if t is None else t.clone().to(dev).requires_grad_() for t in src]
+        xr, dtr, Ar, Br, Cr, Dr, dtbr, ir = leaves
+        y = S.mamba_chunk_scan_combined(xr, dtr, Ar, Br, Cr, 256, D=Dr, dt_bias=dtbr, initial_states=ir, dt_softplus=True)
+        y.backward(gy.to(dev))
+        grads[mode] = [None if t is None else t.grad.detach().cpu() for t in leaves]
+        outs[mode] = y.detach().cpu()
+    assert torch.equal(outs["1"], outs["0"])
+    for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "dt_bias", "init"], grads["1"], grads["0"]):
+        if a is not None:
+            assert torch.equal(a, b), n
+    # the raw call: the window-state tensor exists for the plain scan and not when a gate is asked for
+    d = lambda t: None if t is None else t.to(dev)
+    r = S.ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), D=d(D), dt_bias=d(dtb), dt_softplus=True, save_window_states=True)
+    assert r[3] is not None and r[3].numel() == ((L + 127) // 128) * H * 8192
+    r = S.ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), D=d(D), z=d(z), dt_bias=d(dtb), dt_softplus=True, save_window_states=True)
+    assert r[3] is None
+
+
 @pytest.mark.parametrize("L,H,G", [(200, 2, 1), (330, 4, 2)])
 def test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states(dev, monkeypatch, L, H, G):
     """OMK_SSD_PRECISE=1 (ssd_v6.hip, PRECISE): the bf16 copy of the carried state and the w_l K_l operand of the state update
