@@ -233,6 +233,7 @@ def test_ssd_bwd_with_window_states_saved_by_the_forward(dev, monkeypatch, L, H,
     that receives it skips its own state pass over x.  Same images from the same code: the gradients are IDENTICAL to the ones of
     the recomputing backward (OMK_SSD_SAVE_WINDOW_STATES=0), the forward output identical to the forward without the dumps, and a
     forward that cannot save them (gate requested) reports 0 bytes."""
+    monkeypatch.setenv("OMK_SSD_BWD_CP", "1")   # the path that reads window states (and is deterministic: exact comparison below)
     if minc:
         monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
     import omnimamba_amd.ssd_combined as S
