@@ -346,14 +346,15 @@ int omk_cross_entropy(const OmkCrossEntropy* p, omk_stream stream);
  * (argmax) and the top_k > 0 branch (top-k -> / temperature -> top-p filter of :64-76 -> multinomial), for 1 <= top_k <= 64.
  * One uniform per row from Philox4x32-10 keyed by (seed, row, *step_counter + offset): the reference draws with
  * torch.multinomial, so the ids agree in distribution (and exactly for top_k == 1), not stream for stream.  step_counter is a
- * device int64 the caller advances (inside its captured graph), NULL = 0.  The full-vocabulary branches (top_k == 0: top-p /
- * min-p over all logits) stay on the host library.                                                                            */
+ * device int64 the caller advances (inside its captured graph), NULL = 0.  top_k == 0 with top_p <= 0 or >= 1 is the plain
+ * multinomial of softmax(logits / temperature) over the whole vocabulary (:114-119 with an inactive filter: the default
+ * arguments of t2i_generate); a top-p cut or min_p over the whole vocabulary stays on the host library (OMK_EINVAL here).     */
 typedef struct {
   OmkTensor logits;        /* (batch, vocab) f32 / bf16 / f16, unit last stride */
   OmkTensor out_ids;       /* out (batch) int64, dense (dtype field ignored) */
   const void* step_counter; /* optional device int64 */
   uint64_t seed, offset;
-  int32_t top_k;           /* 1 .. 64 */
+  int32_t top_k;           /* 0 (whole vocabulary, no top-p cut) or 1 .. 64 */
   float top_p, temperature;
 } OmkSample;
 int omk_sample(const OmkSample* p, omk_stream stream);

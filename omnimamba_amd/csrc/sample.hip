@@ -5,6 +5,8 @@
 // sits inside the captured 1-token step (generation.SampleLoopGraph) and the per-step random stream comes from a device
 // counter the graph itself advances.
 //
+//   top_k == 0      the whole vocabulary, plain multinomial of softmax(logits / T) (the reference's default arguments of t2i_generate:
+//                   top_k = 0, top_p = 1.0); a top-p cut over the whole vocabulary needs a full sort and stays with the host library
 //   top_k == 1      argmax (lowest index among equal maxima)
 //   1 < top_k <= 64 the k largest logits by a 4-pass 8-bit radix select over order-preserving integer keys (histograms in LDS,
 //                   the row re-read from L2: 200 KB of fp32 at vocab 50 288), candidates gathered into LDS and sorted by one
@@ -76,6 +78,54 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       for (int k = 1; k < 4; k++) if (wmax[k] > m || (wmax[k] == m && wimax[k] < mi)) { m = wmax[k]; mi = wimax[k]; }
       a.out[row] = mi == 0x7fffffff ? 0 : mi;
     }
+    return;
+  }
+  if (a.top_k == 0) {
+    // full-vocabulary multinomial (the reference's top_k == 0 branch with top_p outside (0, 1): softmax(logits / T), one draw).
+    // Thread t owns the contiguous slice [t c, t c + c): block maximum, slice masses, an inclusive scan of the 256 masses (the scan
+    // values tile [0, total) exactly: end_t = start_{t + 1}), one Philox number scaled to the total, and the thread whose interval
+    // holds it walks its slice in index order -- the inverse CDF in index order.
+    __shared__ float endm[256];
+    __shared__ float wsum[4];
+    __shared__ int pick_s;
+    const int c = (V + 255) / 256, lo = tid * c, hi = lo + c < V ? lo + c : V;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, ld(i));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, shfl_xor(m, off));
+    if (lane == 0) wmax[wv] = m;
+    if (tid == 0) pick_s = 0;
+    block_sync();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float sc = a.inv_temp * LOG2E;
+    float mine = 0.f;
+    for (int i = lo; i < hi; i++) mine += exp2_fast((ld(i) - m) * sc);
+    const float incl = wave_incl_scan_add(mine);
+    if (lane == 63) wsum[wv] = incl;
+    block_sync();
+    float base = 0.f;
+    for (int k = 0; k < wv; k++) base += wsum[k];
+    endm[tid] = base + incl;
+    block_sync();
+    const float tot = endm[255], start = tid ? endm[tid - 1] : 0.f, end = endm[tid];
+    uint32_t cc[4] = {(uint32_t)row, 0u, 0u, 0u};
+    const unsigned long long step = (a.counter ? (unsigned long long)a.counter[0] : 0ull) + a.offset;
+    cc[1] = (uint32_t)step; cc[2] = (uint32_t)(step >> 32);
+    philox4x32(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    float u = (float)(cc[0] >> 8) * (1.0f / 16777216.0f) * tot;   // uniform in [0, tot)
+    if (u >= tot) u = tot * 0.99999994f;                            // (the product may round up to the total)
+    if (u >= start && u < end) {   // exactly one thread when 0 < tot < inf
+      float run = start; int got = lo;
+      for (int i = lo; i < hi; i++) {
+        const float e = exp2_fast((ld(i) - m) * sc);
+        if (e > 0.f) got = i;                                       // rounding inside the slice: the last token with mass
+        run += e;
+        if (run > u) break;
+      }
+      pick_s = got;
+    }
+    block_sync();
+    if (tid == 0) a.out[row] = pick_s;
     return;
   }
   const int K = a.top_k < V ? a.top_k : V;
@@ -186,7 +236,8 @@ extern "C" int omk_sample(const OmkSample* p, omk_stream stream) {
   OMK_REQUIRE(p->logits.ndim == 2 && p->logits.stride[1] == 1, "sample: logits must be (batch, vocab) with unit last stride");
   OMK_REQUIRE(p->out_ids.ndim == 1 && p->out_ids.shape[0] == p->logits.shape[0] && p->out_ids.stride[0] == 1, "sample: out_ids must be dense int64 (batch)");
   OMK_REQUIRE(p->logits.dtype == OMK_F32 || p->logits.dtype == OMK_BF16 || p->logits.dtype == OMK_F16, "sample: logits dtype");
-  OMK_REQUIRE(p->top_k >= 1 && p->top_k <= SAMPLE_KMAX, "sample: top_k must be in [1, %d] (the full-vocabulary branches stay on the host library)", SAMPLE_KMAX);
+  OMK_REQUIRE(p->top_k >= 0 && p->top_k <= SAMPLE_KMAX, "sample: top_k must be in [0, %d]", SAMPLE_KMAX);
+  OMK_REQUIRE(p->top_k > 0 || p->top_p <= 0.f || p->top_p >= 1.f, "sample: top_k == 0 (full vocabulary) is the plain multinomial only; a top-p cut over the whole vocabulary stays on the host library");
   OMK_REQUIRE(p->temperature > 0.f, "sample: temperature must be positive");
   OMK_REQUIRE(p->top_p <= 1.f, "sample: top-p should be in (0, 1]");
   if (p->logits.shape[0] == 0) return OMK_OK;

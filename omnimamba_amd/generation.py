@@ -57,10 +57,11 @@ def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
         return logits.argmax(dim=-1)
     if top_p > 0.0:
         assert top_p <= 1.0, "top-p should be in (0, 1]."
-    if top_k > 0 and logits.is_cuda and SMP.applies(logits, min(top_k, logits.size(-1))):
+    kk = min(top_k, logits.size(-1)) if top_k > 0 else 0
+    if logits.is_cuda and SMP.applies(logits, kk, min_p=min_p if top_k <= 0 else 0.0, top_p=top_p):
+        # 1 < top_k <= 64, or the whole vocabulary without a top-p / min-p cut (t2i_generate's default arguments: top_k 0, top_p 1.0)
         _draws += 1
-        return SMP.sample_device(logits, top_k=min(top_k, logits.size(-1)), top_p=top_p, temperature=temperature,
-                                 seed=torch.initial_seed(), offset=_draws)
+        return SMP.sample_device(logits, top_k=kk, top_p=top_p, temperature=temperature, seed=torch.initial_seed(), offset=_draws)
     if top_k > 0:
         top_k = min(top_k, logits.size(-1))
         vals, idx = torch.topk(logits, top_k, dim=-1)
@@ -229,7 +230,7 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     graph = None
     if hasattr(model, "prepare_decode"):
         model.prepare_decode(task)      # per-token-id tables of the embedding MLPs, built outside any graph capture
-    if (device_loop and cg and 1 <= top_k <= SMP.MAX_TOP_K and min_p == 0.0 and eos_token_id is None and teacher_outputs is None
+    if (device_loop and cg and (1 <= top_k <= SMP.MAX_TOP_K or (top_k == 0 and (top_p <= 0.0 or top_p >= 1.0))) and min_p == 0.0 and eos_token_id is None and teacher_outputs is None
             and vocab_size is None and trace is None):
         return _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k, top_p, temperature)
     if cg:

@@ -146,8 +146,9 @@ class OmniMambaPath(nn.Module):
         emb = emb + bb.pos_embed[:, : emb.shape[1]]
         max_length = self.llm_backbone.num_tokens + emb.shape[1]
         # graph: the sampling runs inside the captured step (generation.GreedyLoopGraph): argmax for top_k = 1 (same ids as the host
-        # loop), omk_sample (top-k / temperature / top-p / Philox draw in one launch) for 1 < top_k <= 64
+        # loop), omk_sample (top-k / temperature / top-p / Philox draw in one launch) for 1 < top_k <= 64 and for the whole vocabulary
+        # (top_k = 0 without a top-p cut: this function's own defaults)
         x = decode(text_ids, emb, self.llm_backbone.mamba, max_length, top_k=top_k, top_p=top_p, temperature=temperature,
-                   cg=fast, task="t2i", device_loop=fast and 1 <= top_k <= 64)
+                   cg=fast, task="t2i", device_loop=fast and (1 <= top_k <= 64 or (top_k == 0 and (top_p <= 0.0 or top_p >= 1.0))))
         self.llm_backbone.mamba._decoding_cache = None
         return x[: text_ids.shape[0], emb.shape[1]:]

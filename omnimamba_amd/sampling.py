@@ -12,14 +12,16 @@ from ._lib import get_lib
 MAX_TOP_K = 64
 
 
-def applies(logits: torch.Tensor, top_k: int, min_p: float = 0.0) -> bool:
-    """The HIP sampler covers the reference's top_k == 1 short cut and its top_k > 0 branch up to 64 candidates."""
+def applies(logits: torch.Tensor, top_k: int, min_p: float = 0.0, top_p: float = 0.0) -> bool:
+    """The HIP sampler covers the reference's top_k == 1 short cut, its top_k > 0 branch up to 64 candidates, and the plain
+    full-vocabulary multinomial (top_k == 0 with top_p outside (0, 1) and no min_p: t2i_generate's default arguments)."""
     try:
         lib = get_lib()
     except RuntimeError:
         return False
     on_lib_device = logits.is_cuda != bool(lib.omk_is_emulated())
-    return on_lib_device and 1 <= top_k <= MAX_TOP_K and logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    full = top_k == 0 and min_p <= 0.0 and (top_p <= 0.0 or top_p >= 1.0)
+    return on_lib_device and (1 <= top_k <= MAX_TOP_K or full) and logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (torch.float32, torch.bfloat16, torch.float16)
 
 
 def sample_device(logits: torch.Tensor, top_k: int = 1, top_p: float = 0.0, temperature: float = 1.0, seed: int = 0,

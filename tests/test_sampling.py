@@ -79,6 +79,44 @@ def test_topk_topp_distribution_matches_reference(dev, top_k, top_p, temp):
         assert not torch.equal(a, c)
 
 
+@pytest.mark.parametrize("temp,top_p", [(1.0, 1.0), (0.6, 0.0)])
+def test_full_vocabulary_multinomial_matches_reference(dev, temp, top_p):
+    """top_k == 0 with top_p outside (0, 1) -- the default arguments of the reference's t2i_generate (omnimamba.py:311) -- is the plain
+    multinomial of softmax(logits / T) over the whole vocabulary (generation.py:114-119): chi-square of 8192 / 2048 draws against those
+    probabilities, -inf logits never drawn, reproducible per (seed, counter); a top-p cut over the whole vocabulary is refused."""
+    from omnimamba_amd.sampling import applies, sample_device
+    g = torch.Generator().manual_seed(5)
+    V = 16384 if dev.type == "cuda" else 1500
+    row = torch.randn(V, generator=g) * 3.0
+    row[::7] = float("-inf")
+    p_ref = torch.softmax(row.double() / temp, -1)
+    nrow, nlaunch = (512, 16) if dev.type == "cuda" else (64, 32)
+    logits = row[None].repeat(nrow, 1).contiguous().to(dev)
+    assert applies(logits, 0, top_p=top_p) and not applies(logits, 0, top_p=0.5) and not applies(logits, 0, min_p=0.1, top_p=top_p)
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    counts = torch.zeros(V, dtype=torch.float64)
+    for i in range(nlaunch):
+        counter.fill_(i)
+        counts += torch.bincount(sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=77, step_counter=counter).cpu(), minlength=V).double()
+    n = nrow * nlaunch
+    assert counts.sum() == n and (counts[p_ref == 0] == 0).all()
+    exp = p_ref * n
+    big = exp >= 5
+    chi = (((counts[big] - exp[big]) ** 2) / exp[big]).sum().item()
+    dof = int(big.sum().item()) - 1
+    e, o = exp[~big].sum().item(), counts[~big].sum().item()
+    if e > 0:
+        chi += (o - e) ** 2 / e
+        dof += 1
+    assert chi < dof + 5 * math.sqrt(2 * max(dof, 1)) + 5, (chi, dof)
+    counter.fill_(2)
+    a = sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=77, step_counter=counter)
+    b = sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=77, step_counter=counter)
+    assert torch.equal(a, b) and not torch.equal(a, sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=78, step_counter=counter))
+    with pytest.raises(RuntimeError):
+        sample_device(logits, top_k=0, top_p=0.5)
+
+
 def test_ties_at_the_threshold_take_the_lowest_indices(dev):
     from omnimamba_amd.sampling import sample_device
     V = 2048
