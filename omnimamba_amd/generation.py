@@ -266,8 +266,17 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         lg = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
         return lg[..., :vocab_size] if vocab_size is not None else lg
 
+    # size of the task's position table (the reference's models cap it: 256 + 73 for T2I, 1500 for MMU, mixer_seq_simple.py:298-303).
+    # A step beyond it is an out-of-range gather on the device in the reference (a device-side assert); here the host loop knows the
+    # position and says so before anything is launched.
+    cfg_ = getattr(model, "cfg", None)
+    n_pos = None if cfg_ is None else getattr(cfg_, "t2i_positions" if task == "t2i" else "mmu_positions", None)
+
     def get_logits(tokens, embeddings):
         decoding = inference_params.seqlen_offset > 0
+        if decoding and n_pos is not None and inference_params.seqlen_offset >= n_pos:
+            raise IndexError(f"decode: position {inference_params.seqlen_offset} is outside the {task} position table of {n_pos} rows "
+                             "(StackConfig.{t2i,mmu}_positions; the reference's table has the same size)")
         pos = torch.full((batch_size, 1), inference_params.seqlen_offset, dtype=torch.long, device=dev) if decoding else None
         if trace is not None:
             trace.append((inference_params.seqlen_offset, None if pos is None else int(pos[0, 0])))
@@ -307,6 +316,10 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
     batch_size, seqlen_og = input_ids.shape
     dev = input_embeddings.device
     n_steps = max_length - 1 - seqlen_og
+    cfg_ = getattr(model, "cfg", None)
+    n_pos = None if cfg_ is None else getattr(cfg_, "t2i_positions" if task == "t2i" else "mmu_positions", None)
+    if n_pos is not None and max_length - 1 > n_pos:   # the loop runs to its end on the device: every position must be in the table
+        raise IndexError(f"decode: max_length {max_length} runs past the {task} position table of {n_pos} rows")
     cache = getattr(model, "_decoding_cache", None)
     seed = torch.initial_seed()
     key = ("device_loop", batch_size, max_length, n_steps, task, top_k, top_p, temperature, seed if top_k != 1 else 0)

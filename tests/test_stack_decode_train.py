@@ -95,6 +95,24 @@ def test_greedy_decode_trace_and_tokens(dev):
     assert torch.equal(full[:, Pn - 1:].argmax(-1).cpu(), toks.cpu())
 
 
+def test_decode_past_the_position_table_raises_on_the_host(dev):
+    """The reference's position tables are finite (256 + 73 rows for T2I, 1500 for MMU, mixer_seq_simple.py:298-303) and a decode
+    step beyond them is an out-of-range gather on the device there.  Here the host loop raises IndexError before the step is launched
+    (found on the MI355X: a 1500-token fp32 MMU prompt + 2 new tokens aborted the queue with a hardware exception)."""
+    from omnimamba_amd.generation import decode
+    from omnimamba_amd.stack import OmniMambaLM
+    torch.manual_seed(2)
+    cfg = tiny_cfg()
+    model = OmniMambaLM(cfg).to(dev).eval()
+    Pn = cfg.mmu_positions - 1
+    ids = torch.zeros(1, Pn, dtype=torch.long, device=dev)
+    emb = torch.randn(1, Pn, cfg.d_model).to(dev)
+    out = decode(ids, emb, model, Pn + 2, top_k=1, task="mmu")            # positions Pn (= table size - 1): the last legal step
+    assert out.shape == (1, Pn + 2)
+    with pytest.raises(IndexError):
+        decode(ids, emb, model, Pn + 3, top_k=1, task="mmu")              # one step further
+
+
 @pytest.mark.parametrize("task,Bsz", [("t2i", 1), ("mmu", 1), ("t2i", 3)])
 def test_fused_decode_step_equals_unfused(dev, task, Bsz, monkeypatch):
     """The one-launch add + norm + in_proj + LoRA and gated-norm + out_proj of the decode step (omk_norm_linear) against the
