@@ -152,7 +152,10 @@ __device__ __forceinline__ float src_at(const Src& s, int b, int t, int h, int g
   return F32 ? ((const float*)s.p)[o] : load_rt(s.p, o, s.dt);
 }
 
-template <int MODE, bool F32 = false>
+// NPT: state elements (consecutive k) per thread.  16 everywhere but in the fp32 specialisation of few sequences (one fp32 prompt of
+// the MMU path: B H = 64 sequences were 128 workgroups, one wave per SIMD on half the chip), which takes 8: twice the workgroups, half the
+// serial work per token and thread.
+template <int MODE, bool F32 = false, int NPT = GEN_NPT>
 __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   OMK_DYN_SMEM(smem);
   const int RW = 256 / TK;
@@ -170,12 +173,12 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   const int tid = threadIdx.x, r = tid / TK, ks = tid % TK;
   const int u = ub * RW + r;
   const bool live = u < a.DU;
-  const int k0 = ks * GEN_NPT;
+  const int k0 = ks * NPT;
   const float Ah = a.A[h];
   const float* dtp = a.dtp + ((int64_t)b * a.H + h) * a.L;
-  float s[GEN_NPT];
+  float s[NPT];
 #pragma unroll
-  for (int j = 0; j < GEN_NPT; j++) {
+  for (int j = 0; j < NPT; j++) {
     const int k = k0 + j;
     s[j] = (a.init && live && k < a.DK) ? load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)u * a.isu + (int64_t)k * a.isk, a.init_dt) : 0.f;
   }
@@ -183,13 +186,14 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   const int nT = (a.L + GEN_TT - 1) / GEN_TT;
   // F32 specialisation (launched only with DK = 128, TK = 8, RW = 32): the next tile's rows are fetched into registers while this
   // tile is computed -- 2 + 2 + 8 + 8 + 2 values per thread -- so the global round trips overlap the token loop
-  float pu[2], pz[2], pk[8], pq[8], pd = 0.f, pla = 0.f;
+  constexpr int CRW = 256 / (128 / NPT), NU = GEN_TT * CRW / 256;   // rows per workgroup, U / Z values per thread and tile (F32 form: DK = 128)
+  float pu[NU], pz[NU], pk[8], pq[8], pd = 0.f, pla = 0.f;
   auto fetch = [&](int ti_) {
     const int tile_ = a.reverse ? nT - 1 - ti_ : ti_, t0_ = tile_ * GEN_TT;
     const int nl_ = (a.L - t0_) < GEN_TT ? (a.L - t0_) : GEN_TT;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int i = tid + 256 * j, t = i / 32, uu = ub * 32 + (i % 32);
+    for (int j = 0; j < NU; j++) {
+      const int i = tid + 256 * j, t = i / CRW, uu = ub * CRW + (i % CRW);
       const bool ok = t < nl_ && uu < a.DU;
       const int tc = ok ? t0_ + t : 0, uc = ok ? uu : 0;                     // clamped: unconditional loads
       const float vu = src_at<true>(a.U, b, tc, h, g, uc);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; j++) { sU[tid + 256 * j] = pu[j]; sX[tid + 256 * j] = pz[j]; }
+    for (int j = 0; j < NU; j++) { sU[tid + 256 * j] = pu[j]; sX[tid + 256 * j] = pz[j]; }
 #pragma unroll
     for (int j = 0; j < 8; j++) { sK[tid + 256 * j] = pk[j]; sQ[tid + 256 * j] = pq[j]; }
     if (tid < GEN_TT) { sdec[tid] = expf(pla); sw[tid] = a.w_is_dt ? pd : 1.f; sdt[tid] = pd; }
@@ -272,23 +276,25 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
         const int t = a.reverse ? GEN_TT - 1 - tt : tt;
         const float dec = sdec[t], wu = sw[t] * sU[t * RW + r];
         float acc = 0.f;
-        if (k0 + GEN_NPT <= a.DK && (a.DK & 3) == 0) {
+        if (k0 + NPT <= a.DK && (a.DK & 3) == 0) {
           // the thread's 16 consecutive k as four 16-byte LDS reads per operand (row offsets are multiples of 16 bytes here; the
           // element-wise form below costs 32 ds_read_b32 per token and thread)
           const f32x4* kq = reinterpret_cast<const f32x4*>(sK + t * a.DK + k0);
           const f32x4* qq = reinterpret_cast<const f32x4*>(sQ + t * a.DK + k0);
+          float a4[4] = {0.f, 0.f, 0.f, 0.f};   // four partial sums: one accumulator would be a chain of NPT dependent FMAs per token
 #pragma unroll
-          for (int v = 0; v < GEN_NPT / 4; v++) {
+          for (int v = 0; v < NPT / 4; v++) {
             const f32x4 kv = kq[v], qv = qq[v];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               s[4 * v + e] = s[4 * v + e] * dec + wu * kv[e];
-              acc += s[4 * v + e] * qv[e];
+              a4[e] += s[4 * v + e] * qv[e];
             }
           }
+          acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         } else {
 #pragma unroll
-          for (int j = 0; j < GEN_NPT; j++) {
+          for (int j = 0; j < NPT; j++) {
             const int k = k0 + j;
             if (k < a.DK) {
               s[j] = s[j] * dec + wu * sK[t * a.DK + k];
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
   if (a.fin && live) {
     const float extra = a.fin_extra_decay ? expf(dtp[0] * Ah) : 1.f;
 #pragma unroll
-    for (int j = 0; j < GEN_NPT; j++) {
+    for (int j = 0; j < NPT; j++) {
       const int k = k0 + j;
       if (k < a.DK) a.fin[(int64_t)b * a.fsb + (int64_t)h * a.fsh + (int64_t)u * a.fsu + (int64_t)k * a.fsk] = s[j] * extra;
     }
@@ -358,6 +364,16 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
 
 int ssd_generic_launch(const GScan& g, omk_stream stream) {
   int TK = 1;
+  {   // fp32 forward of few sequences (see the kernel): 8 state elements per thread
+    bool f32 = g.U.dt == OMK_F32 && g.K.dt == OMK_F32 && g.Q.dt == OMK_F32 && (!g.Z.p || g.Z.dt == OMK_F32);
+    if (g.mode == GS_Y && f32 && g.DK == 128 && g.DU % 16 == 0 && (int64_t)g.B * g.H * (g.DU / 32) < 512) {
+      const int RW8 = 16;
+      dim3 grid8((unsigned)((int64_t)g.B * g.H * (g.DU / RW8))), block8(256);
+      const size_t smem8 = (size_t)(GEN_TT * (3 * RW8 + 2 * g.DK) + 3 * GEN_TT) * 4;
+      OMK_LAUNCH((ssd_generic_kernel<GS_Y, true, 8>), grid8, block8, smem8, stream, g, 16);
+      return OMK_OK;
+    }
+  }
   while (TK * GEN_NPT < g.DK) TK <<= 1;
   if (TK > 64) return fail(OMK_EUNSUPPORTED, "ssd generic scan: inner dim %d too large", g.DK);
   const int RW = 256 / TK;
