@@ -122,6 +122,16 @@ __device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
   for (int r = 0; r < 4; r++) d[r] = w.d32[l][r];
   return d;
 }
+__device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
+  emu::Wave& w = emu::cur_wave();
+  int l = emu::lane_id();
+  for (int r = 0; r < 4; r++) w.c32[l][r] = c[r];
+  w.c32[l][4] = a; w.c32[l][5] = b;
+  emu::wave_collective(emu::op_mfma16_f32);
+  f32x4 d;
+  for (int r = 0; r < 4; r++) d[r] = w.d32[l][r];
+  return d;
+}
 // ds_read_b64_tr_b16: lane passes the address of ITS 8 bytes; gets column (lane&15) of the 4x16 block that its
 // 16-lane group fetched (rows = lanes t/4, columns = 4*(t%4)+e).
 __device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
@@ -150,6 +160,9 @@ __device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) 
 __device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x4_f32: fp32 operands (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]), 32 cycles per SIMD: the
+// fp32 matrix rate of this chip equals its fp32 VALU rate -- what the instruction buys is 1024 MACs per issue slot instead of 64
+__device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ s16x4 lds_read_tr16_b64(const uint16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }

@@ -551,6 +551,8 @@ static int run_scan(const GScan& g, int force_generic, omk_stream stream) {
   if (!force_generic) {
     int rc = ssd_mfma_launch(g, stream);
     if (rc != OMK_EUNSUPPORTED) return rc;
+    rc = ssd_f32_mfma_launch(g, stream);   // fp32 activations (the reference's inference default): ssd_f32.hip
+    if (rc != OMK_EUNSUPPORTED) return rc;
   }
   return ssd_generic_launch(g, stream);
 }

@@ -95,6 +95,7 @@ inline size_t ssd_seg_bytes(int BH, int L) {
 }
 
 int ssd_generic_launch(const GScan& g, omk_stream stream);
+int ssd_f32_mfma_launch(const GScan& g, omk_stream stream);   // fp32 activations on the fp32 matrix instruction (forward y only); OMK_EUNSUPPORTED otherwise
 // returns OMK_EUNSUPPORTED (without touching the error text) when the shape/dtype/layout is outside the MFMA kernel
 int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 1: only answer whether it applies
 // split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the

@@ -253,6 +253,22 @@ inline void op_mfma16(Wave& w) {
   for (int l = 0; l < WAVE; l++)
     for (int r = 0; r < 4; r++) w.d32[l][r] = C[(l >> 4) * 4 + r][l & 15];
 }
+// v_mfma_f32_16x16x4_f32 (fp32 operands, one block): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D[row=(l>>4)*4+r][col=l&15];
+// the operands arrive in c32[l][4] (A) and c32[l][5] (B)
+inline void op_mfma16_f32(Wave& w) {
+  static float A[16][4], B[4][16], C[16][16];
+  for (int l = 0; l < WAVE; l++) { A[l & 15][l >> 4] = w.c32[l][4]; B[l >> 4][l & 15] = w.c32[l][5]; }
+  for (int l = 0; l < WAVE; l++)
+    for (int r = 0; r < 4; r++) C[(l >> 4) * 4 + r][l & 15] = w.c32[l][r];
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 16; j++) {
+      float acc = C[i][j];
+      for (int k = 0; k < 4; k++) acc = fmaf(A[i][k], B[k][j], acc);
+      C[i][j] = acc;
+    }
+  for (int l = 0; l < WAVE; l++)
+    for (int r = 0; r < 4; r++) w.d32[l][r] = C[(l >> 4) * 4 + r][l & 15];
+}
 // ds_read_b64_tr_b16: within each 16-lane group, lane t fetches 4 x 16 bit at its own address (M_t);
 // result lane t, element j = M_{4j + t/4}[t % 4]  (column t of the 4x16 block the group fetched).
 inline void op_tr16(Wave& w) {

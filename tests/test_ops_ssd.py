@@ -40,6 +40,36 @@ def test_ssd_generic_fwd(dev, dtype, L, H, P, N, G):
     assert rel(out, o0) < tol and rel(out_x, ox0) < tol and rel(fin, f0) < 3e-5
 
 
+@pytest.mark.parametrize("L,H,P,G,with_z,with_init,dhp", [(150, 2, 64, 1, True, True, False), (16, 4, 64, 2, False, False, False),
+                                                          (37, 2, 32, 1, True, False, True), (1, 2, 64, 1, False, True, False)])
+def test_ssd_f32_mfma_fwd(dev, monkeypatch, L, H, P, G, with_z, with_init, dhp):
+    """fp32 activations (the reference's inference default) take the fp32 matrix-instruction kernel (csrc/ssd_f32.hip: chunks of 16
+    tokens, a head cut into 16-column workgroups, no operand rounding): same accuracy class as the token-by-token generic kernel --
+    y, the pre-gate copy and the final state against the fp64 recurrence at 3e-5; ragged lengths, one token, gate, initial state,
+    D per head and per (head, column), two groups.  OMK_SSD_F32_MFMA=0 gives the generic kernel: the two agree to 2e-5."""
+    from omnimamba_amd.ssd_combined import ssd_scan_fwd
+    N = 128
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, torch.float32, seed=9)
+    if dhp:
+        D = torch.randn(H, P, generator=torch.Generator().manual_seed(2))
+    if not with_z:
+        z = None
+    if not with_init:
+        init = None
+    d = lambda t: None if t is None else t.to(dev)
+    kw = dict(D=d(D), z=d(z), dt_bias=d(dtb), initial_states=d(init), dt_softplus=True, dt_limit=(0.0, 3.0), return_final_states=True, want_out_x=True)
+    out, out_x, fin = ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), **kw)
+    o0, f0 = O.ssd_ref_sequential(x, dt, A, Bm, Cm, D=D, z=z, dt_bias=dtb, initial_states=init, dt_softplus=True, dt_limit=(0.0, 3.0),
+                                  return_final_states=True, compute_dtype=torch.float64)
+    assert out.dtype == torch.float32 and rel(out, o0) < 3e-5 and rel(fin, f0) < 3e-5
+    if with_z:
+        ox0 = O.ssd_ref_sequential(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, initial_states=init, dt_softplus=True, dt_limit=(0.0, 3.0), compute_dtype=torch.float64)
+        assert rel(out_x, ox0) < 3e-5
+    monkeypatch.setenv("OMK_SSD_F32_MFMA", "0")
+    out_g, _, fin_g = ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), **kw)
+    assert rel(out, out_g.cpu()) < 2e-5 and rel(fin, fin_g.cpu()) < 2e-5 and not torch.equal(out.cpu(), out_g.cpu())
+
+
 @pytest.mark.parametrize("L,H,P,N,G,dhp", [(29, 4, 8, 16, 2, False), (18, 2, 16, 8, 1, True)])
 def test_ssd_generic_bwd(dev, L, H, P, N, G, dhp, monkeypatch):
     import omnimamba_amd.ssd_combined as S
