@@ -416,7 +416,9 @@ def main():
                              "; the forward also leaves its window states behind for the backward: +256 MiB of writes that are not algorithmic bytes; the plain forward of this shape is scan_target.B8_L4096)"
                              if save_ws else ")"),
                          "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
-                         "traffic": traffic["fwd"][0], "traffic_source": traffic["fwd"][1],
+                         # (the counters of the file are of the plain forward; the window states are one more write of 16 KB per head and 128 tokens)
+                         "traffic": None if traffic["fwd"][0] is None else traffic["fwd"][0] + (B_LOCAL * ((SEQ + 127) // 128) * H * 16384 if save_ws else 0),
+                         "traffic_source": None if traffic["fwd"][1] is None else traffic["fwd"][1] + ("; + the window states this launch writes, by size" if save_ws else ""),
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
             "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + " + ("" if save_ws else "state-only forward pass + ") + "dx scan with window-state dumps + ssd_cp_kernel + folds + finish" + (
                                  "; forward window states saved by the training forward)" if save_ws else ")"),
