@@ -397,7 +397,7 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
     a.fsb = p->final_states.stride[0]; a.fsc = p->final_states.stride[1]; a.fsl = p->final_states.stride[2];
   }
   if ((int64_t)a.B * a.C * a.L == 0) return OMK_OK;
-  const bool fast = p->x.dtype != OMK_F32 && cl_fast_ok(p->x, a.C) && cl_fast_ok(p->out, a.C);
+  const bool fast = cl_fast_ok(p->x, a.C) && cl_fast_ok(p->out, a.C);   // (fp32 too: the prefill of the reference's fp32 inference ran the scalar kernel at 0.85 TB/s)
   if (fast) {
     // 4 channels (8 bytes) per lane and 8 tokens per load group: 100 VGPRs / 4 waves per SIMD measured fastest on the
     // 1.3B shape (141 us vs 171 us for 8 channels per lane, which needs 158 VGPRs)
@@ -411,7 +411,8 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
     if (p->x.dtype == OMK_BF16) {
       if (tl == 128) CONV_FWD_V(bf16_t, 4, 128, 8); else if (tl == 64) CONV_FWD_V(bf16_t, 4, 64, 8); else if (tl == 16) CONV_FWD_V(bf16_t, 4, 16, 8);
       else CONV_FWD_V(bf16_t, 4, 32, 8);
-    } else CONV_FWD_V(f16_t, 4, 32, 8);
+    } else if (p->x.dtype == OMK_F32) { if (tl == 64) CONV_FWD_V(float, 4, 64, 8); else CONV_FWD_V(float, 4, 32, 8); }
+    else CONV_FWD_V(f16_t, 4, 32, 8);
 #undef CONV_FWD_V
   } else {
     int64_t n = (int64_t)a.B * a.C * a.L;
