@@ -133,6 +133,25 @@ def selscan_cfg1(dev):
         e1.record()
         torch.cuda.synchronize()
         out[f"hip_B{rep * Bsz}"]["fwd_bwd_ms"] = round(e0.elapsed_time(e1) / n, 4)
+        if rep > 1:
+            # the same tensors as channel-last (B, L, D) views -- what the Mamba-1 module holds after its in_proj, the north star's
+            # "(B, L, D) laid out for coalesced HBM loads": read and written as they lie by the lanes-are-channels sweep (selscan.hip)
+            cl = [t.transpose(1, 2).contiguous().transpose(1, 2) if t.dim() == 3 else t for t in g]
+            got_cl = selective_scan_fn(cl[0], cl[1], cl[2], cl[3], cl[4], cl[5], cl[6], cl[7], True)
+            assert got_cl.stride(1) == 1 and torch.allclose(got_cl, got, rtol=1e-4, atol=1e-4)
+            for _ in range(5):
+                selective_scan_fn(cl[0], cl[1], cl[2], cl[3], cl[4], cl[5], cl[6], cl[7], True)
+            torch.cuda.synchronize()
+            n = 50
+            e0.record()
+            for _ in range(n):
+                selective_scan_fn(cl[0], cl[1], cl[2], cl[3], cl[4], cl[5], cl[6], cl[7], True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            out[f"hip_B{rep * Bsz}_channel_last"] = {"value": round(rep * Bsz * L * Dm / (ms * 1e-3) / 1e6, 1), "unit": "M-elements/s", "launch_ms": round(ms, 4),
+                                                     "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
+                                                     "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return out
 
 

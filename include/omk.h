@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 4
+#define OMK_ABI_VERSION 5
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -179,10 +179,15 @@ typedef struct {
   OmkTensor last_state; /* optional out (B, D, N) f32 */
   OmkTensor pass_states;/* optional out (B, D, ceil(L / 512), N) f32, contiguous: the state in front of every 512-token pass of the
                            chunked scan -- hand it to omk_selective_scan_bwd and the backward skips its state-only forward pass.
-                           Needs L-contiguous u / delta / z / out / B / C and L >= 64 (OMK_EUNSUPPORTED otherwise). */
+                           Needs L-contiguous u / delta / z / out / B / C and L >= 64, or form 2 below (OMK_EUNSUPPORTED otherwise). */
   int32_t delta_softplus;
 } OmkSelScanFwd;
 int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream);
+/* Which form omk_selective_scan_fwd takes for these tensors (nothing is launched): 2 = lanes-are-channels sweep (channel-last (B, L, D)
+ * or L-contiguous storage, d_state <= 16, variable B / C of u's dtype, and enough (batch, 64-channel tile) waves to fill the chip --
+ * or L < 64), 1 = chunked associative scan (L-contiguous rows, lanes = time), 0 = per-channel sequential kernel; < 0: omk_status.
+ * A host that holds channel-last views asks before it decides to make L-contiguous copies (omnimamba_amd/selective_scan.py). */
+int omk_selective_scan_fwd_form(const OmkSelScanFwd* p);
 
 typedef struct {
   OmkTensor u, delta, A, Bm, Cm, D, z, delta_bias; /* as forward */

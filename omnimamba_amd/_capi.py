@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 4
+OMK_ABI_VERSION = 5
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
@@ -96,7 +96,7 @@ SYMBOLS = [
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
-    "omk_selective_scan_fwd", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
+    "omk_selective_scan_fwd", "omk_selective_scan_fwd_form", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd_window_states_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
     "omk_cross_entropy", "omk_lora_up_bwd_parts", "omk_sample",
 ]
@@ -113,6 +113,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
         fn = getattr(lib, s)  # raises AttributeError when a declared symbol is missing
         if s.endswith("_workspace_bytes") or s.endswith("_window_states_bytes"):
             fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p]
+        elif s == "omk_selective_scan_fwd_form":
+            fn.restype = C.c_int
             fn.argtypes = [C.c_void_p]
         elif s == "omk_lora_up_bwd_parts":
             fn.restype = C.c_int

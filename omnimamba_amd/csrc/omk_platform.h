@@ -171,6 +171,19 @@ __device__ __forceinline__ float atomic_add_f32(float* p, float v) { return unsa
 __device__ __forceinline__ void lds_add_f32(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
+// Order the LDS traffic of ONE wave: what its lanes wrote before is visible to the reads of any of its lanes behind.  The LDS executes a
+// wave's instructions in order, so only the compiler has to be told (a fence at wavefront scope costs no instruction; __syncthreads of a
+// one-wave workgroup would also wait for every global load and store in flight -- vmcnt(0) -- and end any prefetch).
+#ifdef OMK_EMU
+__device__ __forceinline__ void wave_lds_sync() { (void)emu::ballot(1); }   // the lanes are fibers: meet
+#else
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 template <class T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
@@ -239,6 +252,13 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
 #define OMK_OPAQUE(x) do { } while (0)
 #else
 #define OMK_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+// The same for a wave-uniform value (stays in an SGPR): a running scalar offset is advanced by one add per use instead of being
+// re-derived as base + k * step with every k * step hoisted into a register of its own.
+#ifdef OMK_EMU
+#define OMK_OPAQUE_S(x) do { } while (0)
+#else
+#define OMK_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #endif
 // Static issue priority of the wave (0 .. 3) from here on.
 #ifdef OMK_EMU

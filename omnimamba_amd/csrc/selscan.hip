@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "omk_common.h"
+#include "ssd_tiles.h"
 
 namespace omk {
 
@@ -23,6 +24,7 @@ struct SsArgs {
   int64_t usb, usd, usl, dsb, dsd, dsl, zsb, zsd, zsl, osb, osd, osl;
   int64_t Asd, Asn, Bsb, Bsg, Bsn, Bsl, Csb, Csg, Csn, Csl;   // for constant B/C: Bsg = stride over d, Bsn over n
   int B, Dm, L, N, G, DT, softplus, Bvar, Cvar, adt, bdt, cdt, ddt, dbdt;
+  uint32_t xu, xd, xz, xo, xB, xC;   // lanes = channels form: bytes one batch element (B / C: one (batch, group)) spans -- buffer ranges
 };
 
 template <class T, int TL = SS_TL>
@@ -511,6 +513,232 @@ __global__ __launch_bounds__(512) void selscan_fwd_shared_kernel(SsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward for MANY sequences: lanes = CHANNELS, one sweep (selscan_fwd_lanes_kernel).
+//
+// With B * D / 64 >= a few hundred waves the chip is full without cutting time into chunks, and the recurrence can run
+// the way it is written: one wave = 64 adjacent channels of one (batch, group), a lane keeps the d_state <= 16 states of ITS channel
+// in registers as 8 packed pairs and walks the tokens once -- per token and pair one v_pk_mul (delta A2), two v_exp, one v_pk_mul
+// (delta u B), one v_pk_fma (state), one v_pk_fma (y): 3 issue slots per (token, state) element where the chunked form (fold + wave scan +
+// second sweep) needs 10.  B_t / C_t are the same for every lane: staged per block of 16 tokens into a wave-private [token][state] LDS
+// tile and read back as broadcasts.  Storage:
+//   channel-last (B, L, D) -- "(B, L, D) laid out for coalesced HBM loads": a token's 64 channels are one 256-byte row (fp32), the lane
+//     loads ITS element straight into the register the sweep consumes, and re-issues the load of the same token slot of the NEXT block
+//     as soon as the value is consumed (a block time in flight, no second register set, no LDS); y goes out the same way
+//   L-contiguous (B, D, L), upstream's layout: 16 tokens x 64 channels tiles transposed through LDS on the way in and out (row stride 68
+//     floats: the 16-token x 4-channel footprint of one load instruction hits 64 different banks)
+// All global traffic through buffer resources (ssd_tiles.h): the lane part of an address is a 32-bit constant, the token part a
+// scalar, and whatever lies behind the end of the batch element's range reads as zero / is dropped.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SCL_TB = 16, SCL_S = 68, SCL_SB = 20;
+constexpr uint32_t SCL_OOR = 0x80000000u;   // lane offset behind every range (ranges are < 2^31 bytes): loads return 0, stores are dropped
+
+template <class T, bool LC>
+__global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
+  __shared__ __attribute__((aligned(16))) float sB[SCL_TB * SCL_SB];
+  __shared__ __attribute__((aligned(16))) float sC[SCL_TB * SCL_SB];
+  __shared__ float tu[LC ? SCL_TB * SCL_S : 1], td[LC ? SCL_TB * SCL_S : 1], tz[LC ? SCL_TB * SCL_S : 1], to[LC ? SCL_TB * SCL_S : 1];
+  constexpr uint32_t ES = sizeof(T);
+  constexpr float LN2 = 0.6931471805599453f;
+  const int lane = threadIdx.x;
+  const int dpg = a.Dm / a.G, tpg = (dpg + 63) / 64;
+  const int tg = blockIdx.x % tpg, g = (blockIdx.x / tpg) % a.G, b = blockIdx.x / (tpg * a.G);
+  const int d0 = g * dpg + tg * 64;
+  const int nd = (dpg - tg * 64) < 64 ? (dpg - tg * 64) : 64;
+  const bool live = lane < nd;
+  const int d = d0 + (live ? lane : 0);
+  const int r4 = lane >> 4, t16 = lane & 15;
+  f32x2 A2[8], x2[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    A2[j][0] = 2 * j < a.N ? load_rt(a.A, (int64_t)d * a.Asd + (int64_t)(2 * j) * a.Asn, a.adt) * LOG2E : 0.f;
+    A2[j][1] = 2 * j + 1 < a.N ? load_rt(a.A, (int64_t)d * a.Asd + (int64_t)(2 * j + 1) * a.Asn, a.adt) * LOG2E : 0.f;
+    x2[j] = f32x2{0.f, 0.f};
+  }
+  const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+  const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+  const bool hasz = a.z != nullptr;
+  const BufRes Ur = make_buf((const T*)a.u + (int64_t)b * a.usb, a.xu), Dr = make_buf((const T*)a.delta + (int64_t)b * a.dsb, a.xd);
+  const BufRes Zr = make_buf(hasz ? (const T*)a.z + (int64_t)b * a.zsb : nullptr, hasz ? a.xz : 0u);
+  const BufRes Or = make_buf((T*)a.out + (int64_t)b * a.osb, a.xo);
+  const BufRes Br = make_buf((const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg, a.xB);
+  const BufRes Cr = make_buf((const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg, a.xC);
+  const uint32_t usl = (uint32_t)a.usl, dsl = (uint32_t)a.dsl, zsl = (uint32_t)a.zsl, osl = (uint32_t)a.osl;
+  const uint32_t usd = (uint32_t)a.usd, dsd = (uint32_t)a.dsd, zsd = (uint32_t)a.zsd, osd = (uint32_t)a.osd;
+  // ---- B / C rows of a block: 16 tokens x 16 states = four elements per lane and array.  The lane's 16-lane group follows whichever
+  // of (state, token) has unit stride; states >= d_state are zeros in LDS (their A2 is 0: x stays 0, y gets nothing)
+  const bool bl = a.Bsl == 1, cl = a.Csl == 1;
+  const uint32_t bvo = ES * (bl ? (uint32_t)r4 * (uint32_t)a.Bsn + (uint32_t)t16 * (uint32_t)a.Bsl : (uint32_t)t16 * (uint32_t)a.Bsn + (uint32_t)r4 * (uint32_t)a.Bsl);
+  const uint32_t cvo = ES * (cl ? (uint32_t)r4 * (uint32_t)a.Csn + (uint32_t)t16 * (uint32_t)a.Csl : (uint32_t)t16 * (uint32_t)a.Csn + (uint32_t)r4 * (uint32_t)a.Csl);
+  const uint32_t bks = ES * 4u * (uint32_t)(bl ? a.Bsn : a.Bsl), cks = ES * 4u * (uint32_t)(cl ? a.Csn : a.Csl);
+  const int blo = bl ? t16 * SCL_SB + r4 : r4 * SCL_SB + t16, bls = bl ? 4 : 4 * SCL_SB;
+  const int clo = cl ? t16 * SCL_SB + r4 : r4 * SCL_SB + t16, cls = cl ? 4 : 4 * SCL_SB;
+  uint32_t pb[4], pc[4];
+  auto fetch_bc = [&](int l0) {
+    const uint32_t sb0 = ES * (uint32_t)l0 * (uint32_t)a.Bsl, sc0 = ES * (uint32_t)l0 * (uint32_t)a.Csl;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      pb[k] = buf_ld_raw<T>(Br, bvo, sb0 + (uint32_t)k * bks);
+      pc[k] = buf_ld_raw<T>(Cr, cvo, sc0 + (uint32_t)k * cks);
+    }
+  };
+  auto commit_bc = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool okb = (bl ? r4 + 4 * k : t16) < a.N, okc = (cl ? r4 + 4 * k : t16) < a.N;
+      sB[blo + k * bls] = okb ? raw_to_f32<T>(pb[k]) : 0.f;
+      sC[clo + k * cls] = okc ? raw_to_f32<T>(pc[k]) : 0.f;
+    }
+  };
+  // ---- one token of the lane's channel: row = the token's slot in the B / C tile; a slot behind the end of the sequence (valid = false:
+  // its loads came back as zeros) is the identity step delta = 0 -- no branch around the body, whose loads the compiler then counts exactly
+  auto token = [&](float uu, float draw, float zv, int row, bool valid) -> float {
+    float dl = draw + db;
+    if (a.softplus) dl = dl > 20.f ? dl : LN2 * log2_fast(1.f + exp2_fast(dl * LOG2E));
+    dl = valid ? dl : 0.f;
+    const float du = dl * uu;
+    // real register pairs: as {v, v} the compiler feeds v_pk_* the low half twice out of (v, whatever register follows) -- and when that
+    // neighbour is the destination of a load still in flight, every packed op waits for the load
+    f32x2 dl2 = {dl, dl}, du2 = {du, du};
+    OMK_OPAQUE(dl2); OMK_OPAQUE(du2);
+    f32x2 ya = {0.f, 0.f}, yb = {0.f, 0.f};
+    const f32x4* rb = reinterpret_cast<const f32x4*>(&sB[row * SCL_SB]);
+    const f32x4* rc = reinterpret_cast<const f32x4*>(&sC[row * SCL_SB]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b4 = rb[q], c4 = rc[q];
+      {
+        const f32x2 e = dl2 * A2[2 * q];
+        const f32x2 av = {exp2_fast(e[0]), exp2_fast(e[1])};
+        x2[2 * q] = av * x2[2 * q] + du2 * f32x2{b4[0], b4[1]};
+        ya = f32x2{c4[0], c4[1]} * x2[2 * q] + ya;
+      }
+      {
+        const f32x2 e = dl2 * A2[2 * q + 1];
+        const f32x2 av = {exp2_fast(e[0]), exp2_fast(e[1])};
+        x2[2 * q + 1] = av * x2[2 * q + 1] + du2 * f32x2{b4[2], b4[3]};
+        yb = f32x2{c4[2], c4[3]} * x2[2 * q + 1] + yb;
+      }
+    }
+    const f32x2 ys = ya + yb;
+    float y = fmaf(Dv, uu, ys[0] + ys[1]);
+    if (hasz) y *= zv * rcp_fast(1.f + exp2_fast(-zv * LOG2E));
+    return y;
+  };
+  auto checkpoint = [&](int l0) {   // state in front of token l0 (a multiple of a.TLB): what the chunked backward restarts from
+    if (a.ckpt && live && (l0 % a.TLB) == 0) {
+      float* cp = a.ckpt + (((int64_t)b * a.Dm + d) * a.nTB + l0 / a.TLB) * a.N;
+#pragma unroll
+      for (int n = 0; n < 16; n++)
+        if (n < a.N) cp[n] = x2[n >> 1][n & 1];
+    }
+  };
+
+  if (!LC) {
+    // ---- channel-last: registers only.  (z absent: the range of Zr is empty, its loads return zeros without touching memory)
+    const uint32_t uvo = live ? ES * (uint32_t)(d0 + lane) * usd : SCL_OOR, dvo = live ? ES * (uint32_t)(d0 + lane) * dsd : SCL_OOR;
+    const uint32_t zvo = (live && hasz) ? ES * (uint32_t)(d0 + lane) * zsd : SCL_OOR, ovo = live ? ES * (uint32_t)(d0 + lane) * osd : SCL_OOR;
+    const uint32_t ustep = ES * usl, dstep = ES * dsl, zstep = hasz ? ES * zsl : 0u, ostep = ES * osl;
+    uint32_t pu[SCL_TB], pd[SCL_TB], pz[SCL_TB];
+    uint32_t su = 0u, sd = 0u, sz = 0u, so = 0u;   // running scalar offsets: the loads are one block ahead of the stores
+#pragma unroll
+    for (int k = 0; k < SCL_TB; k++) {
+      pu[k] = buf_ld_raw<T>(Ur, uvo, su);
+      pd[k] = buf_ld_raw<T>(Dr, dvo, sd);
+      pz[k] = buf_ld_raw<T>(Zr, zvo, sz);
+      su += ustep; sd += dstep; sz += zstep;
+      OMK_OPAQUE_S(su); OMK_OPAQUE_S(sd); OMK_OPAQUE_S(sz);
+    }
+    fetch_bc(0);
+    OMK_VM_DRAIN();   // (nothing of the prologue pending at the loop header: the loop's own wait counts stay exact)
+    for (int l0 = 0; l0 < a.L; l0 += SCL_TB) {
+      wave_lds_sync();   // the previous block's broadcast reads before the new rows
+      commit_bc();
+      wave_lds_sync();
+      checkpoint(l0);
+#pragma unroll
+      for (int k = 0; k < SCL_TB; k++) {
+        if (k == SCL_TB / 2) fetch_bc(l0 + SCL_TB);   // half a block ahead: 32 younger operations, inside what s_waitcnt can count
+        const float y = token(raw_to_f32<T>(pu[k]), raw_to_f32<T>(pd[k]), raw_to_f32<T>(pz[k]), k, l0 + k < a.L);
+        // the same slot of the next block (behind the end: zeros) into the registers the token just released -- issued BEHIND their
+        // last use: with the old and the new value alive together the loop-carried slot becomes a copy at the back edge, and the copy
+        // a wait for (nearly) every load of the block
+        OMK_SCHED_FENCE();
+        pu[k] = buf_ld_raw<T>(Ur, uvo, su);
+        pd[k] = buf_ld_raw<T>(Dr, dvo, sd);
+        pz[k] = buf_ld_raw<T>(Zr, zvo, sz);
+        su += ustep; sd += dstep; sz += zstep;
+        OMK_OPAQUE_S(su); OMK_OPAQUE_S(sd); OMK_OPAQUE_S(sz);
+        buf_st_t<T>(Or, y, ovo, so);          // (behind the end of the sequence: behind the range, dropped)
+        so += ostep;
+        OMK_OPAQUE_S(so);
+      }
+    }
+  } else {
+    // ---- L-contiguous: load instruction k of a block covers channels r4 + 4 k, tokens t16 (64-byte pieces of four rows)
+    const uint32_t uvo = ES * ((uint32_t)(d0 + r4) * usd + (uint32_t)t16), dvo = ES * ((uint32_t)(d0 + r4) * dsd + (uint32_t)t16);
+    const uint32_t zvo = hasz ? ES * ((uint32_t)(d0 + r4) * zsd + (uint32_t)t16) : SCL_OOR, ovo = ES * ((uint32_t)(d0 + r4) * osd + (uint32_t)t16);
+    const int tlo = t16 * SCL_S + r4;   // tile element [token t16][channel r4 + 4 k]
+    uint32_t pu[SCL_TB], pd[SCL_TB], pz[SCL_TB];
+    const uint32_t ustep = ES * 4u * usd, dstep = ES * 4u * dsd, zstep = hasz ? ES * 4u * zsd : 0u, ostep = ES * 4u * osd;
+    auto fetch_tiles = [&](int l0) {
+      uint32_t su = ES * (uint32_t)l0, sd = su, sz = hasz ? su : 0u;
+#pragma unroll
+      for (int k = 0; k < SCL_TB; k++) {
+        pu[k] = buf_ld_raw<T>(Ur, uvo, su);
+        pd[k] = buf_ld_raw<T>(Dr, dvo, sd);
+        pz[k] = buf_ld_raw<T>(Zr, zvo, sz);
+        su += ustep; sd += dstep; sz += zstep;
+        OMK_OPAQUE_S(su); OMK_OPAQUE_S(sd); OMK_OPAQUE_S(sz);
+      }
+    };
+    fetch_tiles(0);
+    fetch_bc(0);
+    for (int l0 = 0; l0 < a.L; l0 += SCL_TB) {
+      const int nl = (a.L - l0) < SCL_TB ? (a.L - l0) : SCL_TB;
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < SCL_TB; k++) {
+        tu[tlo + 4 * k] = raw_to_f32<T>(pu[k]);
+        td[tlo + 4 * k] = raw_to_f32<T>(pd[k]);
+        if (hasz) tz[tlo + 4 * k] = raw_to_f32<T>(pz[k]);
+      }
+      commit_bc();
+      fetch_tiles(l0 + SCL_TB);
+      fetch_bc(l0 + SCL_TB);
+      wave_lds_sync();
+      checkpoint(l0);
+      if (nl == SCL_TB) {   // a full block as one straight run of 16 tokens (the tile reads of a token overlap its neighbours' arithmetic)
+#pragma unroll
+        for (int t = 0; t < SCL_TB; t++) {
+          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, t, true);
+          to[t * SCL_S + lane] = y;
+        }
+      } else {
+        for (int t = 0; t < nl; t++) {
+          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, t, true);
+          to[t * SCL_S + lane] = y;
+        }
+      }
+      wave_lds_sync();
+      const bool tok = l0 + t16 < a.L;
+      uint32_t so = ES * (uint32_t)l0;
+#pragma unroll
+      for (int k = 0; k < SCL_TB; k++) {
+        const bool ok = tok && r4 + 4 * k < nd;
+        buf_st_t<T>(Or, to[tlo + 4 * k], ok ? ovo : SCL_OOR, so);
+        so += ostep;
+        OMK_OPAQUE_S(so);
+      }
+    }
+  }
+  if (a.last && live) {
+#pragma unroll
+    for (int n = 0; n < 16; n++)
+      if (n < a.N) a.last[((int64_t)b * a.Dm + d) * a.N + n] = x2[n >> 1][n & 1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward.  With a_t = exp(delta_t A), the adjoint g_t of the state x_t runs backwards in time:
 //   g_t = C_t dy_t + a_{t+1} g_{t+1}                       dy_t = dout_t * silu(z_t) (or dout_t)
 //   dA   += g_t x_{t-1} delta_t a_t          ddelta_t = sum_n g_t (x_{t-1} A a_t + B_t u_t)   (* softplus' when enabled)
@@ -993,8 +1221,42 @@ static int ss_fill(SsArgs& a, const OmkTensor& u, const OmkTensor& delta, const 
   return OMK_OK;
 }
 
+// The lanes = channels sweep (selscan_fwd_lanes_kernel) takes the call when it applies and the batch fills the chip by itself:
+// returns 0 (no), 2 (channel-last storage) or 3 (L-contiguous storage) and fills the buffer ranges.
+static int ss_lanes_form(SsArgs& a, int udt) {
+  if (!a.out || !a.Bvar || !a.Cvar || a.N > 16 || a.bdt != udt || a.cdt != udt) return 0;
+  if (a.ckpt && (a.TLB % SCL_TB) != 0) return 0;
+  const bool z = a.z != nullptr;
+  const bool cl = a.usd == 1 && a.dsd == 1 && (!z || a.zsd == 1) && a.osd == 1;
+  const bool lc = a.usl == 1 && a.dsl == 1 && (!z || a.zsl == 1) && a.osl == 1;
+  if (!cl && !lc) return 0;
+  const int64_t es = (int64_t)dtype_size(udt), lim = (int64_t)1 << 31;
+  auto span = [&](int64_t sd, int64_t sl, int64_t nd) -> int64_t { return (sd < 0 || sl < 0) ? lim : es * ((nd + 64) * sd + ((int64_t)a.L + 64) * sl); };
+  const int64_t su = span(a.usd, a.usl, a.Dm), sdl = span(a.dsd, a.dsl, a.Dm), sz = z ? span(a.zsd, a.zsl, a.Dm) : 0, so = span(a.osd, a.osl, a.Dm);
+  const int64_t sb = span(a.Bsn, a.Bsl, 16), sc = span(a.Csn, a.Csl, 16);
+  if (su >= lim || sdl >= lim || sz >= lim || so >= lim || sb >= lim || sc >= lim) return 0;
+  const char* e = getenv("OMK_SELSCAN_LANES");
+  if (e && atoi(e) == 0) return 0;
+  const int dpg = a.Dm / a.G;
+  const int64_t nw = (int64_t)a.B * a.G * ((dpg + 63) / 64);
+  // few sequences: time has to be cut (the chunked scan).  Measured crossovers at L 1024, D 768 (tools/bench_selscan.py): channel-last
+  // storage from ~200 waves (the alternative pays L-contiguous copies), L-contiguous storage from one wave per SIMD
+  if (!(e && atoi(e) == 1) && nw < (cl ? 192 : 1024) && a.L >= 64) return 0;
+  auto ext = [&](int64_t sd, int64_t sl, int64_t nd) -> uint32_t { return (uint32_t)(es * ((nd - 1) * sd + ((int64_t)a.L - 1) * sl + 1)); };
+  a.xu = ext(a.usd, a.usl, a.Dm); a.xd = ext(a.dsd, a.dsl, a.Dm); a.xz = z ? ext(a.zsd, a.zsl, a.Dm) : 0u; a.xo = ext(a.osd, a.osl, a.Dm);
+  a.xB = ext(a.Bsn, a.Bsl, a.N); a.xC = ext(a.Csn, a.Csl, a.N);
+  return cl ? 2 : 3;
+}
+
 // pass_ckpt: first pass of the chunked backward (a.ckpt = state in front of every 512-token pass, no output)
 static int ss_launch_fwd(SsArgs& a, int udt, omk_stream stream, bool pass_ckpt = false) {
+  if (const int form = pass_ckpt ? 0 : ss_lanes_form(a, udt)) {
+    const int dpg = a.Dm / a.G;
+    dim3 grid((unsigned)((int64_t)a.B * a.G * ((dpg + 63) / 64))), block(64);
+    if (form == 2) OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_lanes_kernel<T, false>), grid, block, 0, stream, a));
+    else OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_lanes_kernel<T, true>), grid, block, 0, stream, a));
+    return OMK_OK;
+  }
   // L-contiguous storage (upstream's layout): the chunked associative scan, one wave per (batch, channel)
   const bool lcontig = pass_ckpt || (a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.out && a.osl == 1 && (!a.Bvar || a.Bsl == 1) &&
                                      (!a.Cvar || a.Csl == 1) && (!a.ckpt || a.TLB == SSR_TP) && a.L >= 64 && !getenv("OMK_SELSCAN_SEQ"));
@@ -1056,13 +1318,27 @@ extern "C" int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream)
     const int nP = (a.L + SSR_TP - 1) / SSR_TP;
     OMK_REQUIRE(p->pass_states.dtype == OMK_F32 && is_dense(p->pass_states) && numel(p->pass_states) == (int64_t)a.B * a.Dm * nP * a.N,
                 "selective_scan_fwd: pass_states must be contiguous f32 (B, D, ceil(L / 512), N)");
-    if (!(a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.osl == 1 && (!a.Bvar || a.Bsl == 1) && (!a.Cvar || a.Csl == 1) && a.L >= 64) ||
-        getenv("OMK_SELSCAN_SEQ"))
-      return fail(OMK_EUNSUPPORTED, "selective_scan_fwd: pass_states need L-contiguous u / delta / z / out / B / C and L >= 64");
     a.ckpt = (float*)p->pass_states.data; a.TLB = SSR_TP; a.nTB = nP;
+    if (!ss_lanes_form(a, p->u.dtype) &&
+        (!(a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.osl == 1 && (!a.Bvar || a.Bsl == 1) && (!a.Cvar || a.Csl == 1) && a.L >= 64) ||
+         getenv("OMK_SELSCAN_SEQ")))
+      return fail(OMK_EUNSUPPORTED, "selective_scan_fwd: pass_states need L-contiguous u / delta / z / out / B / C and L >= 64");
   }
   if ((rc = ss_launch_fwd(a, p->u.dtype, stream))) return rc;
   return finish_launch("selective_scan_fwd");
+}
+
+extern "C" int omk_selective_scan_fwd_form(const OmkSelScanFwd* p) {
+  if (!p || !present(p->out)) return fail(OMK_EINVAL, "selective_scan_fwd_form: out required");
+  SsArgs a = {};
+  int rc = ss_fill(a, p->u, p->delta, p->A, p->Bm, p->Cm, p->D, p->z, p->delta_bias, p->delta_softplus, "selective_scan_fwd_form");
+  if (rc) return rc;
+  a.out = p->out.data; a.osb = p->out.stride[0]; a.osd = p->out.stride[1]; a.osl = p->out.stride[2];
+  if (present(p->pass_states)) { a.ckpt = (float*)p->pass_states.data; a.TLB = SSR_TP; }
+  if (ss_lanes_form(a, p->u.dtype)) return 2;
+  const bool lcontig = a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.osl == 1 && (!a.Bvar || a.Bsl == 1) && (!a.Cvar || a.Csl == 1) &&
+                       a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
+  return lcontig ? 1 : 0;
 }
 
 extern "C" size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p) {

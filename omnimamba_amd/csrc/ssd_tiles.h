@@ -57,6 +57,48 @@ __device__ __forceinline__ void buf_st_f32(const BufRes& b, float v, uint32_t vo
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b.r, (int)voff, (int)soff, 0);
 #endif
 }
+// 16-bit elements (bf16 / f16 storage): the raw bits
+__device__ __forceinline__ uint16_t buf_ld_u16(const BufRes& b, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o >= b.nbytes) return 0;
+  return *reinterpret_cast<const uint16_t*>(b.base + o);
+#else
+  return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(b.r, (int)voff, (int)soff, 0);
+#endif
+}
+__device__ __forceinline__ void buf_st_u16(const BufRes& b, uint16_t v, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o < b.nbytes) *reinterpret_cast<uint16_t*>(const_cast<char*>(b.base) + o) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b16(v, b.r, (int)voff, (int)soff, 0);
+#endif
+}
+// raw bits of one element of storage type T (the conversion stays with the consumer: a load is not waited for where it is issued)
+template <class T> __device__ __forceinline__ uint32_t buf_ld_raw(const BufRes& b, uint32_t voff, uint32_t soff) {
+  if (sizeof(T) == 4) return __builtin_bit_cast(uint32_t, buf_ld_f32(b, voff, soff));
+  return buf_ld_u16(b, voff, soff);
+}
+template <class T> __device__ __forceinline__ float raw_to_f32(uint32_t r);
+template <> __device__ __forceinline__ float raw_to_f32<float>(uint32_t r) { return __builtin_bit_cast(float, r); }
+template <> __device__ __forceinline__ float raw_to_f32<bf16_t>(uint32_t r) { return __builtin_bit_cast(float, r << 16); }
+template <> __device__ __forceinline__ float raw_to_f32<f16_t>(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
+// one element of storage type T as fp32 / fp32 to one element of T
+template <class T> __device__ __forceinline__ float buf_ld_t(const BufRes& b, uint32_t voff, uint32_t soff);
+template <> __device__ __forceinline__ float buf_ld_t<float>(const BufRes& b, uint32_t voff, uint32_t soff) { return buf_ld_f32(b, voff, soff); }
+template <> __device__ __forceinline__ float buf_ld_t<bf16_t>(const BufRes& b, uint32_t voff, uint32_t soff) { return bf16_to_f32(buf_ld_u16(b, voff, soff)); }
+template <> __device__ __forceinline__ float buf_ld_t<f16_t>(const BufRes& b, uint32_t voff, uint32_t soff) {
+  const uint16_t h = buf_ld_u16(b, voff, soff);
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+template <class T> __device__ __forceinline__ void buf_st_t(const BufRes& b, float v, uint32_t voff, uint32_t soff);
+template <> __device__ __forceinline__ void buf_st_t<float>(const BufRes& b, float v, uint32_t voff, uint32_t soff) { buf_st_f32(b, v, voff, soff); }
+template <> __device__ __forceinline__ void buf_st_t<bf16_t>(const BufRes& b, float v, uint32_t voff, uint32_t soff) { buf_st_u16(b, f32_to_bf16(v), voff, soff); }
+template <> __device__ __forceinline__ void buf_st_t<f16_t>(const BufRes& b, float v, uint32_t voff, uint32_t soff) {
+  const _Float16 h = (_Float16)v;
+  buf_st_u16(b, __builtin_bit_cast(uint16_t, h), voff, soff);
+}
 __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
   const uint32_t o = voff + soff;

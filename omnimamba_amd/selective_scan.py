@@ -6,6 +6,7 @@ Mirrors ``mamba_ssm.ops.selective_scan_interface.selective_scan_fn`` (importable
 """
 from __future__ import annotations
 
+import ctypes as _C
 import os
 
 import torch
@@ -28,22 +29,33 @@ class SelectiveScanFn(torch.autograd.Function):
             z = z.to(u.dtype)
         B4 = B.unsqueeze(1) if B.dim() == 3 else B
         C4 = C.unsqueeze(1) if C.dim() == 3 else C
-        if u.shape[-1] >= 64:
-            # the chunked associative scan wants L-contiguous rows (lanes = time).  The Mamba-1 module hands over channel-last
-            # views of its (B, L, 2 D) projection: one copy pass here costs far less than the per-channel sequential kernel
+        Bsz, Dm, L = u.shape
+        out = None
+        if u.stride(1) == 1 and Dm > 1 and u.numel() > 0:
+            # channel-last views of a (B, L, D) projection (what the Mamba-1 module holds).  With enough sequences the lanes-are-channels
+            # sweep reads them as they lie (omk_selective_scan_fwd_form == 2, selscan.hip); the output then is channel-last as well
+            o = torch.empty(Bsz, L, Dm, dtype=u.dtype, device=u.device).transpose(1, 2)
+            probe = K.SelScanFwd(u=K.T(u), delta=K.T(delta), A=K.T(A), Bm=K.T(B4), Cm=K.T(C4), D=K.T(D), z=K.T(z),
+                                 delta_bias=K.T(delta_bias), out=K.T(o), last_state=K.T(None), pass_states=K.T(None),
+                                 delta_softplus=int(delta_softplus))
+            if lib.omk_selective_scan_fwd_form(_C.byref(probe)) == 2:
+                out = o
+        if out is None and L >= 64:
+            # the chunked associative scan wants L-contiguous rows (lanes = time): one copy pass here costs far less than the per-channel
+            # sequential kernel
             u, delta = (t if t.stride(-1) == 1 else t.contiguous() for t in (u, delta))
             z = z if z is None or z.stride(-1) == 1 else z.contiguous()
             B4 = B4 if B4.dim() != 4 or B4.stride(-1) == 1 else B4.contiguous()
             C4 = C4 if C4.dim() != 4 or C4.stride(-1) == 1 else C4.contiguous()
-        out = torch.empty_like(u)
-        Bsz, Dm, L = u.shape
+        if out is None:
+            out = torch.empty_like(u)
         last = torch.empty(Bsz, Dm, A.shape[1], dtype=torch.float32, device=u.device) if return_last_state else None
         Af = A.float() if A.dtype != torch.float32 else A     # bound to a local: the kernel reads it after this line
         # a backward will follow and the chunked form applies: keep the state in front of every 512-token pass (B D L / 512 N floats) --
         # the backward then needs no second forward pass
         ps = None
         if (L >= 64 and any(ctx.needs_input_grad) and B4.dim() == 4 and C4.dim() == 4 and B4.dtype == u.dtype and C4.dtype == u.dtype and
-                (Dm // B4.shape[1]) % 8 == 0 and all(t is None or t.stride(-1) == 1 for t in (u, delta, z, B4, C4)) and
+                (Dm // B4.shape[1]) % 8 == 0 and (out.stride(1) == 1 or all(t is None or t.stride(-1) == 1 for t in (u, delta, z, B4, C4))) and
                 not os.environ.get("OMK_SELSCAN_SEQ") and not os.environ.get("OMK_SELSCAN_NO_PASS_STATES")):
             # = the conditions of the chunked backward (selscan.hip); without the tensor the backward runs a state-only forward pass first
             ps = torch.empty(Bsz, Dm, (L + 511) // 512, A.shape[1], dtype=torch.float32, device=u.device)
@@ -67,8 +79,12 @@ class SelectiveScanFn(torch.autograd.Function):
         lib = get_lib()
         u, delta, A, B4, C4, D, z, delta_bias, ps = ctx.saved_tensors
         dout = dout.to(u.dtype)
-        if u.stride(-1) == 1 and dout.stride(-1) != 1:
-            dout = dout.contiguous()      # the gradient of a channel-last consumer: the chunked scan wants rows along L
+        if u.shape[-1] >= 64:
+            # (the forward may have read channel-last views as they lay: the chunked backward wants rows along L)
+            u, delta, dout = (t if t.stride(-1) == 1 else t.contiguous() for t in (u, delta, dout))
+            z = z if z is None or z.stride(-1) == 1 else z.contiguous()
+            B4 = B4 if B4.dim() != 4 or B4.stride(-1) == 1 else B4.contiguous()
+            C4 = C4 if C4.dim() != 4 or C4.stride(-1) == 1 else C4.contiguous()
         Af = A.float() if A.dtype != torch.float32 else A
         du, ddelta = torch.empty_like(u), torch.empty_like(delta)
         dz = None if z is None else torch.empty_like(z)

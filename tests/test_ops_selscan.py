@@ -44,6 +44,70 @@ def test_selective_scan_fwd(dev, dtype, layout, Dm, L, N, G, bvar):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["bdl", "bld"])
+@pytest.mark.parametrize("bc_layout", ["nl", "ln"])
+@pytest.mark.parametrize("Dm,L,N,G,with_z,softplus", [(70, 45, 16, 1, True, True), (12, 33, 8, 2, False, True), (130, 100, 5, 1, True, False),
+                                                      (64, 16, 16, 1, True, True), (96, 530, 16, 2, True, True)])
+def test_selective_scan_fwd_lanes_are_channels(dev, monkeypatch, dtype, layout, bc_layout, Dm, L, N, G, with_z, softplus):
+    """The one-sweep form for many sequences (selscan_fwd_lanes_kernel: a lane owns a channel, B_t / C_t broadcast from a wave-private LDS
+    tile), forced onto small shapes: channel-last storage read as it lies (registers only) and L-contiguous storage through the
+    transposing tiles; ragged channel tiles (70 = 64 + 6, groups of 6 / 48), ragged last block, odd d_state, B / C with either of
+    (state, token) contiguous; last state and the pass states the chunked backward restarts from."""
+    from omnimamba_amd.selective_scan import selective_scan_fn
+    from omnimamba_amd import _capi as K
+    from omnimamba_amd._lib import get_lib
+    monkeypatch.setenv("OMK_SELSCAN_LANES", "1")
+    torch.manual_seed(3)
+    Bsz = 3
+
+    def mk(scale=1.0, rand=False):
+        t = ((torch.rand(Bsz, L, Dm) if rand else torch.randn(Bsz, L, Dm)) * scale).to(dtype)
+        if layout == "bld":
+            return t.transpose(1, 2), t.to(dev).transpose(1, 2)
+        c = t.transpose(1, 2).contiguous()
+        return c, c.to(dev)
+
+    def mkbc():
+        t = torch.randn(Bsz, G, L, N).to(dtype)
+        if bc_layout == "ln":
+            return t.transpose(2, 3), t.to(dev).transpose(2, 3)
+        c = t.transpose(2, 3).contiguous()
+        return c, c.to(dev)
+
+    (u, ud), (delta, dd), (z, zd) = mk(), mk(0.5, True), mk()
+    if not with_z:
+        z = zd = None
+    A = -(torch.rand(Dm, N) + 0.1)
+    (Bm, Bd), (Cm, Cd) = mkbc(), mkbc()
+    D, db = torch.randn(Dm), torch.randn(Dm) * 0.1
+    lib = get_lib()
+    Ad, Dd, dbd = A.to(dev), D.to(dev), db.to(dev)   # (locals: a descriptor holds a pointer, not a reference)
+    o = torch.empty(Bsz, L, Dm, dtype=dtype, device=dev).transpose(1, 2) if layout == "bld" else torch.empty_like(ud)
+    import ctypes
+    probe = K.SelScanFwd(u=K.T(ud), delta=K.T(dd), A=K.T(Ad), Bm=K.T(Bd), Cm=K.T(Cd), D=K.T(None), z=K.T(zd), delta_bias=K.T(None),
+                         out=K.T(o), last_state=K.T(None), pass_states=K.T(None), delta_softplus=int(softplus))
+    assert lib.omk_selective_scan_fwd_form(ctypes.byref(probe)) == 2
+    out, last = selective_scan_fn(ud, dd, Ad, Bd, Cd, Dd, zd, dbd, softplus, True)
+    o0, l0 = O.selective_scan_ref(u, delta, A, Bm.contiguous(), Cm.contiguous(), D, z, db, softplus, True)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert out.shape == u.shape and rel(out, o0) < tol and rel(last, l0) < 2e-5
+    if layout == "bld":
+        assert out.stride(1) == 1   # read and written as it lies: no L-contiguous copies
+    # pass states (state in front of every 512-token pass) straight through the C ABI
+    nP = (L + 511) // 512
+    ps = torch.full((Bsz, Dm, nP, N), float("nan"), dtype=torch.float32, device=dev)
+    o2 = torch.empty_like(out)
+    p = K.SelScanFwd(u=K.T(ud), delta=K.T(dd), A=K.T(Ad), Bm=K.T(Bd), Cm=K.T(Cd), D=K.T(Dd), z=K.T(zd), delta_bias=K.T(dbd),
+                     out=K.T(o2), last_state=K.T(None), pass_states=K.T(ps), delta_softplus=int(softplus))
+    K.run(lib, "omk_selective_scan_fwd", p, ud)
+    assert torch.equal(o2.cpu(), out.cpu()) and bool((ps[:, :, 0] == 0).all())
+    if nP > 1:
+        _, l512 = O.selective_scan_ref(u[..., :512], delta[..., :512], A, Bm.contiguous()[..., :512], Cm.contiguous()[..., :512], D,
+                                       None if z is None else z[..., :512], db, softplus, True)
+        assert rel(ps[:, :, 1], l512) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout,Dm,L,N,G,bvar,with_z,softplus", [("bdl", 70, 45, 16, 1, True, True, True), ("bld", 12, 33, 8, 2, True, False, True),
                                                                   ("bdl", 6, 20, 4, 1, False, True, False), ("bld", 130, 37, 16, 1, True, True, True),
                                                                   # L >= 64, L-contiguous, 8 | channels per group: the chunked scan in both directions
