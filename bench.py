@@ -275,7 +275,26 @@ def decode_1p3b(dev):
            "time_to_first_token_ms": round(ttft * 1e3, 3), "ms_per_token": round(ms_tok, 4), "tokens_per_s": round(1e3 / ms_tok, 1),
            "total_ms": round(best * 1e3, 2), "weights_GBs": round(n_param * 4 / (ms_tok * 1e-3) / 1e9, 1),
            "frac_of_hbm_peak": round(n_param * 4 / (ms_tok * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "params": n_param, "dtype": "f32"}
-    del model
+    # the VQ decode tail behind the 256 ids (mamba_vlm.py:104-108; VQ-16 geometry, random weights): ids -> 3 x 256 x 256 pixels
+    from omnimamba_amd.vq_tail import VQDecodeTail
+    tail = VQDecodeTail().to(dev).eval()
+    img_ids = seq[:, P:].clamp(0, 16383)
+
+    def t_ms(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        out["vq_tail_ms"] = {"eager_f32": round(t_ms(lambda: tail.decode_to_img(img_ids)), 3),
+                             "graph_f32": round(t_ms(lambda: tail.graphed(img_ids)), 3),
+                             "graph_bf16": round(t_ms(lambda: tail.graphed(img_ids, torch.bfloat16)), 3),
+                             "params": sum(p.numel() for p in tail.parameters())}
+    del model, tail
     torch.cuda.empty_cache()
     return out
 

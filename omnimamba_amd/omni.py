@@ -5,7 +5,8 @@ synthetic BASELINE configs 4 / 5 and for checkpoint compatibility (SURVEY.md sec
 Only what drives the Mamba-2 path is here: projector MLP, embedding of the two task sequences, position tables, shifted
 cross-entropy, greedy T2I generation.  The frozen vision towers and the VQ-VAE are inputs / outputs of the path and are
 replaced by synthetic tensors: ``images_feat`` (B, 729, 2176) stands for ``vision_backbone(pixel_values)`` and the 256
-sampled codes are returned instead of ``vqvae.decode_code`` (out of scope).
+sampled codes are returned instead of ``vqvae.decode_code`` unless ``attach_vq_tail()`` put the decode half of the tokenizer in place
+(omnimamba_amd/vq_tail.py; the vision towers and the VQ encoder stay out: SURVEY.md section 2.1 rows 13, 18).
 
 State-dict keys: ``llm_backbone.mamba.*`` and ``projector.projector.{0,2,4}.*`` exactly as ``OmniMamba.state_dict()``
 writes them; ``load_reference_state_dict`` drops the ``vision_backbone.`` / ``llm_backbone.vqvae.`` entries of a full
@@ -86,8 +87,24 @@ class OmniMambaPath(nn.Module):
         return self.llm_backbone.mamba.backbone
 
     def load_reference_state_dict(self, state_dict, strict=True):
+        vq = {k[len("llm_backbone.vqvae."):]: v for k, v in state_dict.items() if k.startswith("llm_backbone.vqvae.")}
         sd = {k: v for k, v in state_dict.items() if not (k.startswith("vision_backbone.") or k.startswith("llm_backbone.vqvae."))}
+        tail = getattr(self.llm_backbone, "vqvae", None)
+        if tail is not None:
+            if vq:
+                tail.load_reference_state_dict(vq, strict=strict)
+            sd.update({"llm_backbone.vqvae." + k: v for k, v in tail.state_dict().items()})
         return self.load_state_dict(sd, strict=strict)
+
+    def attach_vq_tail(self, tail=None):
+        """The decode half of the frozen VQ-16 tokenizer where the reference keeps it (``llm_backbone.vqvae``, mamba_vlm.py:19,55-69):
+        ``t2i_generate(..., decode_images=True)`` then ends in pixels like omnimamba.py:334-336.  Optional -- without it the path returns
+        the sampled ids and its state dict has the reference's MambaLMHeadModel keys only."""
+        from .vq_tail import VQDecodeTail
+        p = next(self.llm_backbone.mamba.parameters())
+        tail = VQDecodeTail() if tail is None else tail
+        self.llm_backbone.vqvae = tail.to(p.device).eval().requires_grad_(False)
+        return self.llm_backbone.vqvae
 
     # ---- sequence construction (omnimamba.py:190-218,253-307)
     def _sp(self, name, like):
@@ -140,7 +157,7 @@ class OmniMambaPath(nn.Module):
 
     # ---- T2I generation (omnimamba.py:311-337 minus the VQ decoder network)
     @torch.no_grad()
-    def t2i_generate(self, text_ids, temperature=1.0, top_k=0, top_p=1.0, fast=True):
+    def t2i_generate(self, text_ids, temperature=1.0, top_k=0, top_p=1.0, fast=True, decode_images=False, image_dtype=None):
         bb = self.backbone
         emb = bb.caption_embed(self.llm_backbone.embed_input_ids(text_ids), train=False)
         emb = emb + bb.pos_embed[:, : emb.shape[1]]
@@ -151,4 +168,10 @@ class OmniMambaPath(nn.Module):
         x = decode(text_ids, emb, self.llm_backbone.mamba, max_length, top_k=top_k, top_p=top_p, temperature=temperature,
                    cg=fast, task="t2i", device_loop=fast and (1 <= top_k <= 64 or (top_k == 0 and (top_p <= 0.0 or top_p >= 1.0))))
         self.llm_backbone.mamba._decoding_cache = None
-        return x[: text_ids.shape[0], emb.shape[1]:]
+        tokens = x[: text_ids.shape[0], emb.shape[1]:]
+        if not decode_images:
+            return tokens
+        tail = getattr(self.llm_backbone, "vqvae", None)
+        if tail is None:
+            raise RuntimeError("t2i_generate(decode_images=True) needs attach_vq_tail() first")
+        return tail.graphed(tokens, image_dtype) if fast else tail.decode_to_img(tokens, image_dtype)   # mamba_vlm.py:104-108

@@ -12,6 +12,9 @@ own Python from /root/reference, which never travels to the GPU box):
                        PyTorch, no kernel under test): state dict of a 2-layer MambaLMHeadModel, Block.forward
                        (hidden, residual), logits of both tasks, and the greedy generate() id sequence with the
                        (seqlen_offset, position_ids) trace of every model call (SURVEY.md section 8c ii-iv)
+  vq_tail_reference.npz  the reference's UNMODIFIED llamagen_tokenizer/tokenizer_image/vq_model.py classes (VectorQuantizer, Decoder at
+                       a small width, a 1x1 post_quant_conv) composed the way VQModel.decode_code composes them: state dict, sampled
+                       ids, the codebook entries and the decoded image -- pins omnimamba_amd.vq_tail.VQDecodeTail
 """
 import importlib.util
 import os
@@ -167,8 +170,51 @@ def reference_model():
     print("state dict keys:", [k[3:] for k in out if k.startswith("sd.")])
 
 
+def vq_tail_reference():
+    spec = importlib.util.spec_from_file_location("ref_vq_model", "/root/reference/llamagen_tokenizer/tokenizer_image/vq_model.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_vq_model"] = mod
+    spec.loader.exec_module(mod)
+    torch.manual_seed(0)
+    cfg = dict(codebook_size=96, codebook_embed_dim=8, z_channels=32, ch=32, ch_mult=(1, 2), num_res_blocks=1)
+    quantize = mod.VectorQuantizer(cfg["codebook_size"], cfg["codebook_embed_dim"], 0.25, 0.0, True, True)
+    post_quant_conv = torch.nn.Conv2d(cfg["codebook_embed_dim"], cfg["z_channels"], 1)
+    decoder = mod.Decoder(z_channels=cfg["z_channels"], ch=cfg["ch"], ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"])
+    with torch.no_grad():
+        # the trained codebook is not unit-norm in storage (get_codebook_entry normalises on every call): make that visible, and
+        # move the GroupNorm affines / biases off their 1 / 0 initialisation
+        quantize.embedding.weight.mul_(1.0 + torch.rand(cfg["codebook_size"], 1))
+        for n, p in decoder.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    quantize.eval(); decoder.eval()
+    B, side = 2, 4
+    ids = torch.randint(0, cfg["codebook_size"], (B, side * side))
+    shape = [B, cfg["codebook_embed_dim"], side, side]
+    with torch.no_grad():
+        zq = quantize.get_codebook_entry(ids.reshape(-1), shape, True)          # VQModel.decode_code (vq_model.py:52-55)
+        img = decoder(post_quant_conv(zq))
+    out = {"ids": ids.numpy(), "zq": zq.numpy(), "img": img.numpy(),
+           "cfg": np.array([cfg["codebook_size"], cfg["codebook_embed_dim"], cfg["z_channels"], cfg["ch"], cfg["num_res_blocks"], *cfg["ch_mult"]])}
+    for k, v in quantize.state_dict().items():
+        out["sd.quantize." + k] = v.numpy()
+    for k, v in post_quant_conv.state_dict().items():
+        out["sd.post_quant_conv." + k] = v.numpy()
+    for k, v in decoder.state_dict().items():
+        out["sd.decoder." + k] = v.numpy()
+    # key names of the full-size tokenizer (VQ_16: what vq_ds16_t2i.pt holds), shapes only: a (n_keys, 4) table in name order
+    full = mod.VQ_16()
+    names = sorted(k for k in full.state_dict().keys())
+    out["vq16.nkeys"] = np.array([len(names)])
+    for i, k in enumerate(names):
+        out[f"vq16.shape.{k}"] = np.array(list(full.state_dict()[k].shape), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "vq_tail_reference.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lora", "ops", "model"]
+    which = sys.argv[1:] or ["lora", "ops", "model", "vq"]
+    if "vq" in which:
+        vq_tail_reference()
     if "lora" in which:
         lora_reference()
     if "ops" in which:
