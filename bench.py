@@ -294,6 +294,8 @@ def decode_1p3b(dev):
                              "graph_f32": round(t_ms(lambda: tail.graphed(img_ids)), 3),
                              "graph_bf16": round(t_ms(lambda: tail.graphed(img_ids, torch.bfloat16)), 3),
                              "params": sum(p.numel() for p in tail.parameters())}
+        tail.set_channels_last(True)
+        out["vq_tail_ms"]["graph_bf16_channels_last"] = round(t_ms(lambda: tail.graphed(img_ids, torch.bfloat16)), 3)
     del model, tail
     torch.cuda.empty_cache()
     return out

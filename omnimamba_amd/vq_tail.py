@@ -125,6 +125,7 @@ class VQDecodeTail(nn.Module):
                 self.quantize.embedding.weight.copy_(F.normalize(self.quantize.embedding.weight, p=2, dim=-1))
         self.post_quant_conv = nn.Conv2d(codebook_embed_dim, z_channels, 1)
         self.decoder = _Decoder(z_channels, ch, ch_mult, num_res_blocks, out_channels, dropout_p)
+        self.channels_last = False   # set_channels_last(): NHWC weights and activations (measured: no gain on this network, see the header)
         self._cb = None        # (key, normalised codebook)
         self._graph = None     # (key, graph, static ids, static image)
 
@@ -151,7 +152,8 @@ class VQDecodeTail(nn.Module):
 
     def decode(self, quant, dtype: Optional[torch.dtype] = None):
         """post_quant_conv -> decoder (vq_model.py:52-55).  ``dtype`` (bf16 / fp16): autocast the convolutions on the GPU."""
-        quant = quant.contiguous(memory_format=torch.channels_last) if quant.dim() == 4 else quant
+        if quant.dim() == 4:
+            quant = quant.contiguous(memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
         if dtype is not None and quant.is_cuda:
             with torch.autocast("cuda", dtype=dtype):
                 return self.decoder(self.post_quant_conv(quant))
@@ -167,14 +169,21 @@ class VQDecodeTail(nn.Module):
         e = self.quantize.embedding.embedding_dim
         return self.decode_code(index.reshape(-1), shape=[index.shape[0], e, side, side], dtype=dtype)
 
+    def set_channels_last(self, on: bool = True):
+        self.channels_last = bool(on)
+        self.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+        self._graph = None
+        return self
+
     # ---- the whole tail as one graph replay (fixed batch / token count / dtype; frozen weights)
-    @torch.no_grad()
+    # (inference mode, not just no_grad: when the process's first capture -- the decode loop's -- ran under it, the generator's graph
+    # state tensors are inference tensors, and a later capture outside inference mode cannot update them)
+    @torch.inference_mode()
     def graphed(self, index, dtype: Optional[torch.dtype] = None):
         if not index.is_cuda:
             return self.decode_to_img(index, dtype)
-        key = (tuple(index.shape), index.dtype, index.device, dtype, self.quantize.embedding.weight._version)
+        key = (tuple(index.shape), index.dtype, index.device, dtype, self.channels_last)
         if self._graph is None or self._graph[0] != key:
-            self.to(memory_format=torch.channels_last)
             ids = index.clone()
             side = torch.cuda.Stream(device=index.device)
             side.wait_stream(torch.cuda.current_stream(index.device))
