@@ -76,9 +76,11 @@ class Mamba(nn.Module):
         x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, activation=self.activation)
         x_dbl = self.x_proj(x.transpose(1, 2).reshape(-1, self.d_inner))
         dt, B, C = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
-        dt = (self.dt_proj.weight @ dt.t()).reshape(self.d_inner, batch, seqlen).transpose(0, 1).contiguous()
-        B = B.reshape(batch, seqlen, self.d_state).transpose(1, 2).contiguous()
-        C = C.reshape(batch, seqlen, self.d_state).transpose(1, 2).contiguous()
+        # channel-last like x and z (views of token-major GEMM outputs, no copies): with enough sequences the scan reads them as they
+        # lie (selscan.hip, lanes = channels); otherwise selective_scan_fn makes the L-contiguous copies the chunked scan wants
+        dt = F.linear(dt, self.dt_proj.weight).view(batch, seqlen, self.d_inner).transpose(1, 2)
+        B = B.reshape(batch, seqlen, self.d_state).transpose(1, 2)
+        C = C.reshape(batch, seqlen, self.d_state).transpose(1, 2)
         y = selective_scan_fn(x, dt, A, B, C, self.D.float(), z=z, delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
                               return_last_state=ssm_state is not None)
         if ssm_state is not None:

@@ -171,16 +171,18 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     w = conv1d_weight.squeeze(1) if conv1d_weight.dim() == 3 else conv1d_weight
     x = causal_conv1d_fn(x, w, conv1d_bias, activation="silu")
     x_dbl = F.linear(x.transpose(1, 2).reshape(-1, d_inner), x_proj_weight.to(x.dtype))                 # (batch * L, dt_rank + 2 d_state)
-    delta = (delta_proj_weight.to(x.dtype) @ x_dbl[:, :dt_rank].t()).reshape(d_inner, -1, L).transpose(0, 1)   # (batch, d_inner, L)
+    # delta, B, C stay channel-last views of token-major GEMM outputs (like x and z): no copies here -- selective_scan_fn reads them
+    # as they lie when the batch fills the chip (lanes = channels) and makes its own L-contiguous copies otherwise
+    delta = F.linear(x_dbl[:, :dt_rank], delta_proj_weight.to(x.dtype)).view(-1, L, d_inner).transpose(1, 2)   # (batch, d_inner, L)
     if B is None:
         B = x_dbl[:, dt_rank:dt_rank + d_state]
         if B_proj_bias is not None:
             B = B + B_proj_bias.to(B.dtype)
-        B = B.reshape(-1, L, d_state).transpose(1, 2).contiguous()                                           # (batch, d_state, L)
+        B = B.reshape(-1, L, d_state).transpose(1, 2)                                                        # (batch, d_state, L)
     if C is None:
         C = x_dbl[:, -d_state:]
         if C_proj_bias is not None:
             C = C + C_proj_bias.to(C.dtype)
-        C = C.reshape(-1, L, d_state).transpose(1, 2).contiguous()
-    y = selective_scan_fn(x, delta.contiguous(), A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+        C = C.reshape(-1, L, d_state).transpose(1, 2)
+    y = selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
     return F.linear(y.transpose(1, 2), out_proj_weight.to(y.dtype), None if out_proj_bias is None else out_proj_bias.to(y.dtype))
