@@ -8,10 +8,12 @@ Reference: ``MambaVLM.decode_to_img`` (/root/reference/models/mamba_vlm.py:104-1
 ``quant_conv.*`` / ``quantize.codebook_used``).
 
 It is a convolutional network behind the hot path, not a scan: the kernels are the library's (MIOpen convolutions, the fused attention of
-``scaled_dot_product_attention``).  What is decided here is how it runs on the MI355X: channels-last activations (the layout MIOpen's
-MFMA convolutions take without transposes), bf16 autocast on request, the l2-normalised codebook cached per weight version (the
-reference normalises all 16 384 rows on every call), and the whole tail replayable as one hipGraph for a fixed batch (``graphed``):
-58 launches of a few microseconds each are otherwise launch-bound at batch 1.
+``scaled_dot_product_attention``).  What is decided here is how it runs on the MI355X, by measurement (`bench.py` -> `decode_1p3b.vq_tail_ms`,
+batch 1, 256 ids -> 3 x 256 x 256, 42.6 M parameters): eager fp32 6.4 ms, one hipGraph replay (``graphed``) 6.25 ms, replay under bf16 autocast
+5.8 ms, bf16 + channels-last 6.6 ms -- the convolutions at 128^2 / 256^2 pixels are the time, not the 60 launches, and NHWC buys nothing
+from the library here, so NCHW is the default and channels-last an option (``set_channels_last``).  Against the 440 ms of the 256-token
+decode loop in front of it the tail is 1.4 % of a generated image.  The l2-normalised codebook is cached per weight version (the
+reference normalises all 16 384 rows on every call).
 """
 from __future__ import annotations
 
