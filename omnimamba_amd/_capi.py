@@ -25,16 +25,17 @@ def T(t: Optional[torch.Tensor]) -> OmkTensor:
     o = OmkTensor()
     if t is None:
         return o
-    if t.dtype not in _DT:
+    dt = _DT.get(t.dtype)
+    if dt is None:
         raise TypeError(f"unsupported dtype {t.dtype} (f32/bf16/f16, u8/bool masks only)")
-    if t.dim() > OMK_MAX_DIMS:
+    n = t.dim()
+    if n > OMK_MAX_DIMS:
         raise ValueError("too many dims")
-    o.data = t.data_ptr()
-    o.dtype = _DT[t.dtype]
-    o.ndim = t.dim()
-    for i in range(t.dim()):
-        o.shape[i] = t.shape[i]
-        o.stride[i] = t.stride(i)
+    # (slice assignment: one ctypes call per array instead of two per dimension -- a descriptor is 1.3 us instead of 3.7, and a
+    # small launch such as BASELINE configs[0] at batch 2 is bound by the ten of them its wrapper builds)
+    o.data, o.dtype, o.ndim = t.data_ptr(), dt, n
+    o.shape[:n] = t.shape
+    o.stride[:n] = t.stride()
     return o
 
 
