@@ -58,7 +58,10 @@ class _FusedLinearCE(torch.autograd.Function):
             raise TypeError(f"fused_linear_cross_entropy: labels must be int64 (the kernel reads 8-byte ids), got {labels1d.dtype}")
         labels1d = labels1d.contiguous()
         T, V = h.shape[0], w.shape[0]
-        counted = (labels1d != IGNORE_ID).sum().to(torch.float32)
+        # the mean runs over exactly the rows the kernel scores: ids outside [0, V) (which torch's cross_entropy rejects with a device
+        # assert) get neither loss nor gradient there, so they do not enter the denominator either.  No counted row at all: 0, where
+        # torch returns NaN -- a batch of nothing but ignored labels does not poison an accumulated training loss.
+        counted = ((labels1d >= 0) & (labels1d < w.shape[0])).sum().to(torch.float32)      # (IGNORE_ID = -100 lies outside)
         inv = (1.0 / counted.clamp_min(1.0)).reshape(1)              # device scalar: no host sync
         need_dh, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dh = torch.empty_like(h) if need_dh else None

@@ -53,6 +53,30 @@ def test_fused_linear_cross_entropy_matches_materialised(dev, train_w, monkeypat
         assert w.grad is None
 
 
+def test_fused_linear_cross_entropy_edges(dev):
+    """Ids outside [0, V) are scored like ignored ones AND left out of the mean (torch asserts on them); nothing to score: loss 0."""
+    from omnimamba_amd import fused_ce
+    torch.manual_seed(2)
+    T, d, V = 40, 16, 96
+    h0, w0 = torch.randn(T, d), torch.randn(V, d) * 0.5
+    labels = torch.randint(0, V, (T,))
+    labels[3], labels[9], labels[11] = V + 5, -3, -100
+    h = h0.clone().to(dev).requires_grad_()
+    loss = fused_ce.fused_linear_cross_entropy(h, w0.to(dev), labels.to(dev))
+    loss.backward()
+    clean = labels.clone()
+    clean[3] = clean[9] = -100
+    hr = h0.clone().requires_grad_()
+    l0 = F.cross_entropy(F.linear(hr, w0), clean, ignore_index=-100)
+    l0.backward()
+    assert rel(loss.detach(), l0.detach()) < 1e-5 and rel(h.grad, hr.grad) < 1e-4
+    assert float(h.grad[[3, 9, 11]].abs().max()) == 0.0
+    none = fused_ce.fused_linear_cross_entropy(h0.to(dev), w0.to(dev), torch.full((T,), -100).to(dev))
+    assert float(none) == 0.0
+    with pytest.raises(TypeError):
+        fused_ce.fused_linear_cross_entropy(h0.to(dev), w0.to(dev), labels.to(dev).int())
+
+
 @pytest.mark.gpu
 def test_fused_linear_cross_entropy_bf16_autocast_lm_head_size():
     """The MMU head at its real width (50 288) under bf16 autocast, two blocks: loss and gradients vs the materialised form."""
