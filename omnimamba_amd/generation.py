@@ -219,19 +219,52 @@ class GreedyLoopGraph:
         return self.tokens[:, :n_steps].clone()
 
 
+@dataclass
+class DecodeOutput:
+    """What ``generate(return_dict_in_generate=True)`` hands back (the reference returns transformers' Greedy / Sample
+    DecoderOnlyOutput, generation.py:254-255: the two fields its callers read)."""
+    sequences: torch.Tensor
+    scores: Optional[tuple] = None
+
+
+class GenerationMixin:
+    """``model.generate(...)`` as the reference's scripts call it on ``llm_backbone.mamba`` (models/stage2/generation.py:269-293;
+    scripts/inference_mmu.py:84-94, omnimamba.py:322-330): a thin front of ``decode`` -- same argument names and defaults, the
+    token matrix by default, ``DecodeOutput`` with ``return_dict_in_generate=True`` (scores only with ``output_scores=True``)."""
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        raise NotImplementedError
+
+    def generate(self, input_ids, input_embeddings, max_length, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0, eos_token_id=None,
+                 return_dict_in_generate=False, output_scores=False, cond=None, **kwargs):
+        if cond is not None:
+            raise NotImplementedError("cond is never passed by OmniMamba (always None: omnimamba.py:322-330, inference_mmu.py:84-94)")
+        sc = [] if output_scores else None
+        seqs = decode(input_ids, input_embeddings, self, max_length, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temperature,
+                      eos_token_id=eos_token_id, scores=sc, **kwargs)
+        if not return_dict_in_generate:
+            return seqs
+        return DecodeOutput(sequences=seqs, scores=None if sc is None else tuple(sc))
+
+
 @torch.inference_mode()
 def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0,
-           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None, device_loop=False):
-    """Prefill with ``input_embeddings`` (batch, seqlen_og, d), then sample until ``seqlen_offset >= max_length - 1`` (or
-    EOS).  Returns the token matrix (batch, seqlen_og + n_sampled): prompt ids followed by the sampled ids.
-    ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact."""
+           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None, device_loop=False, scores=None):
+    """Prefill with ``input_embeddings`` (batch, prompt positions, d), then sample until ``seqlen_offset >= max_length - 1`` (or
+    EOS).  Returns the token matrix (batch, input_ids.shape[1] + n_sampled): the given prompt ids followed by the sampled ids.
+    ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact;
+    ``scores`` (optional list) the logits every sampled token was drawn from (the reference's ``output.scores``)."""
     batch_size, seqlen_og = input_ids.shape
+    # the prompt the model SEES is the embedding sequence: the reference advances seqlen_offset by its length (generation.py:236-245,
+    # `sequences = [input_embeddings]`), which is longer than input_ids when image embeddings were spliced in (scripts/inference_mmu.py:
+    # 4 + question ids against 4 + 729 + question positions); input_ids only lead the returned matrix
+    seqlen_pr = input_embeddings.shape[1]
     dev = input_embeddings.device
     graph = None
     if hasattr(model, "prepare_decode"):
         model.prepare_decode(task)      # per-token-id tables of the embedding MLPs, built outside any graph capture
     if (device_loop and cg and (1 <= top_k <= SMP.MAX_TOP_K or (top_k == 0 and (top_p <= 0.0 or top_p >= 1.0))) and min_p == 0.0 and eos_token_id is None and teacher_outputs is None
-            and vocab_size is None and trace is None):
+            and vocab_size is None and trace is None and scores is None):
         return _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k, top_p, temperature)
     if cg:
         # the reference's cache rule (generation.py:308-369): one set of state tensors and one graph memory pool, thrown away
@@ -242,9 +275,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         p0 = next(iter(model.parameters()))
         if (cache is None or cache.get("kind") != "host" or (cache["device"], cache["dtype"]) != (p0.device, p0.dtype)
                 or batch_size != cache["max_batch_size"] or max_length > cache["max_seqlen"]):
-            ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
+            ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_pr,
                                  key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, p0.dtype),
-                                 lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
+                                 lengths_per_sample=torch.full((batch_size,), seqlen_pr, dtype=torch.int32, device=dev))
             cache = {"kind": "host", "device": p0.device, "dtype": p0.dtype, "max_batch_size": batch_size, "max_seqlen": max_length,
                      "ip": ip, "mempool": torch.cuda.graphs.graph_pool_handle(), "graphs": {}}
             model._decoding_cache = cache
@@ -252,9 +285,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
             cache["graphs"][batch_size, 1, task] = StepGraph(model, cache["ip"], batch_size, cache["max_seqlen"], task, mempool=cache["mempool"])
         inference_params, graph = cache["ip"], cache["graphs"][batch_size, 1, task]
         inference_params.reset(max_length, batch_size)
-        pkey = ("prefill", batch_size, seqlen_og, task, input_embeddings.dtype)
-        if _prefill_graph_ok(seqlen_og) and pkey not in cache["graphs"]:
-            cache["graphs"][pkey] = PrefillGraph(model, cache["ip"], batch_size, seqlen_og, input_embeddings.shape[-1], task,
+        pkey = ("prefill", batch_size, seqlen_pr, task, input_embeddings.dtype)
+        if _prefill_graph_ok(seqlen_pr) and pkey not in cache["graphs"]:
+            cache["graphs"][pkey] = PrefillGraph(model, cache["ip"], batch_size, seqlen_pr, input_embeddings.shape[-1], task,
                                                  input_embeddings.dtype, mempool=cache["mempool"])
             inference_params.reset(max_length, batch_size)
         prefill_graph = cache["graphs"].get(pkey)
@@ -297,11 +330,13 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         return inference_params.seqlen_offset >= max_length - 1
 
     seqs = input_ids
-    last, first, n_in = None, True, seqlen_og
+    last, first, n_in = None, True, seqlen_pr
     while not should_stop(last):
         lg = get_logits(None, input_embeddings) if first else get_logits(last, None)
         inference_params.seqlen_offset += n_in
         first, n_in = False, 1
+        if scores is not None:
+            scores.append(lg.clone() if graph is not None else lg)     # (a captured step returns its static output buffer)
         if teacher_outputs is not None and teacher_outputs.shape[1] > inference_params.seqlen_offset:
             tok = teacher_outputs[:, inference_params.seqlen_offset]
         else:
@@ -313,9 +348,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
 
 def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k=1, top_p=0.0, temperature=1.0):
     """Prefill (eager, fills the caches), then max_length - P - 1 replays of GreedyLoopGraph."""
-    batch_size, seqlen_og = input_ids.shape
+    batch_size, seqlen_pr = input_ids.shape[0], input_embeddings.shape[1]   # (the embedding sequence is the prompt: see decode)
     dev = input_embeddings.device
-    n_steps = max_length - 1 - seqlen_og
+    n_steps = max_length - 1 - seqlen_pr
     cfg_ = getattr(model, "cfg", None)
     n_pos = None if cfg_ is None else getattr(cfg_, "t2i_positions" if task == "t2i" else "mmu_positions", None)
     if n_pos is not None and max_length - 1 > n_pos:   # the loop runs to its end on the device: every position must be in the table
@@ -325,14 +360,14 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
     key = ("device_loop", batch_size, max_length, n_steps, task, top_k, top_p, temperature, seed if top_k != 1 else 0)
     if cache is None or cache.get("kind") != "device_loop" or cache.get("key") != key:
         dtype = next(iter(model.parameters())).dtype
-        ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_og,
+        ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_pr,
                              key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
-                             lengths_per_sample=torch.full((batch_size,), seqlen_og, dtype=torch.int32, device=dev))
+                             lengths_per_sample=torch.full((batch_size,), seqlen_pr, dtype=torch.int32, device=dev))
         cache = {"kind": "device_loop", "key": key, "ip": ip,
                  "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed)}
-        if _prefill_graph_ok(seqlen_og):
+        if _prefill_graph_ok(seqlen_pr):
             ip.reset(max_length, batch_size)
-            cache["prefill"] = PrefillGraph(model, ip, batch_size, seqlen_og, input_embeddings.shape[-1], task, input_embeddings.dtype)
+            cache["prefill"] = PrefillGraph(model, ip, batch_size, seqlen_pr, input_embeddings.shape[-1], task, input_embeddings.dtype)
         model._decoding_cache = cache
     ip, graph = cache["ip"], cache["graph"]
     ip.reset(max_length, batch_size)
@@ -344,9 +379,9 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
         lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
     first = (lg0.argmax(dim=-1, keepdim=True) if top_k == 1 else
              SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=0).unsqueeze(1))
-    ip.seqlen_offset = seqlen_og
+    ip.seqlen_offset = seqlen_pr
     seqs = torch.cat([input_ids, first], dim=1)
     if n_steps > 0:
-        seqs = torch.cat([seqs, graph.run(first, seqlen_og, n_steps)], dim=1)
-        ip.seqlen_offset = seqlen_og + n_steps
+        seqs = torch.cat([seqs, graph.run(first, seqlen_pr, n_steps)], dim=1)
+        ip.seqlen_offset = seqlen_pr + n_steps
     return seqs

@@ -155,6 +155,20 @@ class OmniMambaPath(nn.Module):
         zq = emb[indices.reshape(-1)]
         return zq.reshape(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous()
 
+    # ---- MMU generation (scripts/inference_mmu.py:55-95: the prompt the script assembles by hand, then mamba.generate)
+    @torch.no_grad()
+    def mmu_generate(self, images_feat, input_ids, max_length=2048, eos_token_id=None, temperature=1.0, top_k=1, top_p=0.0, cg=True):
+        """<|mmu|> <|soi|> [projector(images_feat)] <|eoi|> <|sot|> question ids -> the reference's greedy continuation.  Returns the
+        token matrix the script decodes: the 4 + len(question) prompt ids followed by the generated ids (the image positions carry no
+        ids, as in the script)."""
+        ids = torch.cat([self._sp("<|mmu|>", input_ids), self._sp("<|soi|>", input_ids), self._sp("<|eoi|>", input_ids),
+                         self._sp("<|sot|>", input_ids), input_ids], dim=1)
+        txt = self.llm_backbone.embed_input_ids(ids)
+        img = self.projector(images_feat).to(txt.dtype)
+        emb = torch.cat((txt[:, :2], img, txt[:, 2:]), dim=1)
+        return self.llm_backbone.mamba.generate(input_ids=ids, input_embeddings=emb, cond=None, eos_token_id=eos_token_id, max_length=max_length,
+                                                temperature=temperature, top_p=top_p, top_k=top_k, cg=cg, task="mmu")
+
     # ---- T2I generation (omnimamba.py:311-337 minus the VQ decoder network)
     @torch.no_grad()
     def t2i_generate(self, text_ids, temperature=1.0, top_k=0, top_p=1.0, fast=True, decode_images=False, image_dtype=None):

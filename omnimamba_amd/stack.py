@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from . import lora_add as LA
 from . import lora_ext as LE
 from . import norm_linear as NL
+from .generation import GenerationMixin
 from .layer_norm import RMSNorm, layer_norm_fn
 from .linear import _WGradFn, linear
 from .mamba2 import Mamba2
@@ -329,8 +330,8 @@ class MixerStack(nn.Module):
                              residual_in_fp32=self.cfg.residual_in_fp32, is_rms_norm=True)
 
 
-class OmniMambaLM(nn.Module):
-    """backbone + tied heads (reference MambaLMHeadModel, mixer_seq_simple.py:443-524)."""
+class OmniMambaLM(nn.Module, GenerationMixin):
+    """backbone + tied heads (reference MambaLMHeadModel, mixer_seq_simple.py:443-524: an nn.Module with the GenerationMixin)."""
 
     def __init__(self, cfg: StackConfig, device=None, dtype=None):
         super().__init__()

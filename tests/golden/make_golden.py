@@ -146,7 +146,10 @@ def reference_model():
         out["fwd.mmu_logits"] = model(None, emb, task="mmu").mmu_logits.numpy()
 
     # (iii) greedy generate(): ids + the integer trace of every model call
-    for task, Bsz, Pn, max_len in (("t2i", 2, 5, 5 + 8), ("mmu", 1, 7, 16)):
+    # (last case, drawn after the others so that their numbers do not move: FEWER prompt ids than prompt positions, the shape of
+    # scripts/inference_mmu.py -- 4 + question ids against 4 + image + question embeddings; decode() advances by the embedding length)
+    for task, Bsz, Pn, max_len, n_ids in (("t2i", 2, 5, 5 + 8, 5), ("mmu", 1, 7, 16, 7), ("mmu_spliced", 1, 9, 16, 4)):
+        key, task = task, task.split("_")[0]
         trace = []
         orig = model.backbone.forward
 
@@ -155,14 +158,14 @@ def reference_model():
                           -1 if input_ids is None else int(input_ids.shape[1])))
             return orig(input_ids, input_embeddings, position_ids, cond, task, inference_params=inference_params, **kw)
         model.backbone.forward = spy
-        ids = torch.zeros(Bsz, Pn, dtype=torch.long)
+        ids = torch.zeros(Bsz, n_ids, dtype=torch.long)
         pemb = torch.randn(Bsz, Pn, 32)
         res = model.generate(input_ids=ids, input_embeddings=pemb, cond=None, max_length=max_len, temperature=1.0, top_p=0.0,
                              top_k=1, cg=False, task=task, return_dict_in_generate=True, output_scores=True)
         model.backbone.forward = orig
-        out.update({f"gen.{task}.prompt_emb": pemb.numpy(), f"gen.{task}.sequences": res.sequences.numpy(),
-                    f"gen.{task}.trace": np.array(trace, dtype=np.int64), f"gen.{task}.max_length": np.array(max_len),
-                    f"gen.{task}.scores": torch.stack(res.scores, 1).numpy()})
+        out.update({f"gen.{key}.prompt_emb": pemb.numpy(), f"gen.{key}.sequences": res.sequences.numpy(),
+                    f"gen.{key}.trace": np.array(trace, dtype=np.int64), f"gen.{key}.max_length": np.array(max_len),
+                    f"gen.{key}.scores": torch.stack(res.scores, 1).numpy()})
         top2 = torch.stack(res.scores, 1).topk(2, dim=-1).values
         print(task, "ids", res.sequences.tolist(), "min top-1/top-2 logit margin", float((top2[..., 0] - top2[..., 1]).min()))
     np.savez_compressed(os.path.join(HERE, "reference_model.npz"), **out)

@@ -252,3 +252,23 @@ def test_image_token_embedding_table_for_decode():
     assert all("_omk" not in k for k in m.state_dict())
     m.train()
     assert m(ids).requires_grad                                                             # training: never the table
+
+
+def test_mmu_generate_assembles_the_scripts_prompt(dev):
+    """scripts/inference_mmu.py:55-95: <|mmu|> <|soi|> [image embeddings] <|eoi|> <|sot|> question -> mamba.generate(task='mmu'); the ids
+    are the ones decode() gives for the hand-assembled embeddings, the prompt ids lead the returned matrix."""
+    from omnimamba_amd.generation import decode
+    torch.manual_seed(4)
+    model = tiny_path("inference").to(dev)
+    q = torch.randint(0, 50, (2, 5), device=dev)
+    feat = torch.randn(2, 5, 12, device=dev)
+    got = model.mmu_generate(feat, q, max_length=24, cg=False)
+    ids = torch.cat([torch.full((2, 1), TINY_SPECIAL[k], device=dev) for k in ("<|mmu|>", "<|soi|>", "<|eoi|>", "<|sot|>")] + [q], dim=1)
+    txt = model.llm_backbone.embed_input_ids(ids)
+    emb = torch.cat((txt[:, :2], model.projector(feat), txt[:, 2:]), dim=1)
+    trace = []
+    want = decode(ids, emb, model.llm_backbone.mamba, 24, top_k=1, task="mmu", cg=False, trace=trace)
+    assert torch.equal(got[:, :9], ids) and torch.equal(got, want)
+    # the model saw 4 + 5 image + 5 question = 14 prompt positions: offsets / position ids continue from 14 (generation.py:236-245 of the
+    # reference advances by the EMBEDDING length), and 24 - 1 - 14 + 1 = 10 ids are sampled behind the 9 prompt ids
+    assert trace == [(0, None)] + [(o, o) for o in range(14, 23)] and got.shape[1] == 9 + 10
