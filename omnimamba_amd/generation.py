@@ -6,6 +6,7 @@ which the omk_* kernels allow because they never allocate, synchronise or read h
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -249,11 +250,19 @@ class GenerationMixin:
 
 @torch.inference_mode()
 def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0,
-           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None, device_loop=False, scores=None):
+           eos_token_id=None, teacher_outputs=None, vocab_size=None, cg=False, task="t2i", trace=None, device_loop=False, scores=None,
+           repetition_penalty=1.0, enable_timing=False, streamer=None):
     """Prefill with ``input_embeddings`` (batch, prompt positions, d), then sample until ``seqlen_offset >= max_length - 1`` (or
     EOS).  Returns the token matrix (batch, input_ids.shape[1] + n_sampled): the given prompt ids followed by the sampled ids.
     ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact;
     ``scores`` (optional list) the logits every sampled token was drawn from (the reference's ``output.scores``)."""
+    if repetition_penalty != 1.0:
+        # (never passed by OmniMamba; the reference's branch also appends every sampled id twice to the returned matrix, generation.py:246-252)
+        raise NotImplementedError("repetition_penalty != 1.0 is not supported")
+    if streamer is not None:
+        streamer.put(input_ids.cpu())
+        device_loop = False                       # a streamer wants every id as it is sampled: host loop
+    t_start = time.perf_counter() if enable_timing else None
     batch_size, seqlen_og = input_ids.shape
     # the prompt the model SEES is the embedding sequence: the reference advances seqlen_offset by its length (generation.py:236-245,
     # `sequences = [input_embeddings]`), which is longer than input_ids when image embeddings were spliced in (scripts/inference_mmu.py:
@@ -343,6 +352,14 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
             tok = sample(lg, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temperature)
         last = tok.unsqueeze(1)
         seqs = torch.cat([seqs, last], dim=1)
+        if streamer is not None:
+            streamer.put(last.cpu())
+    if streamer is not None:
+        streamer.end()
+    if enable_timing:
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        print(f"Prompt processing + decoding time: {(time.perf_counter() - t_start) * 1e3:.0f}ms")     # (generation.py:262-264)
     return seqs
 
 

@@ -40,6 +40,24 @@ class _LLMBackbone(nn.Module):
     def embed_input_ids(self, input_ids):
         return self.mamba.get_input_embeddings()(input_ids)
 
+    def forward(self, x, c, cond=None, task="t2i"):
+        """``MambaVLM.forward`` (models/mamba_vlm.py:88-102) as the reference's ``OmniMamba.forward`` calls it (omnimamba.py:275,305):
+        embeddings x, labels c -> (shifted logits flattened to (tokens, vocab), shifted labels flattened).  The materialised-logits
+        form; ``OmniMambaPath.forward`` takes the fused linear + cross-entropy instead and never builds this tensor."""
+        if cond is not None:
+            raise NotImplementedError("cond is always None in OmniMamba (omnimamba.py:275,305)")
+        out = self.mamba(input_ids=None, input_embeddings=x, cond=None, task=task)
+        logits = out.t2i_logits if task == "t2i" else out.mmu_logits
+        return logits[..., :-1, :].reshape(-1, logits.shape[-1]), c[..., 1:].reshape(-1)
+
+    @torch.no_grad()
+    def decode_to_img(self, index):
+        """models/mamba_vlm.py:104-108 (needs ``OmniMambaPath.attach_vq_tail()``: the decode half of the VQ tokenizer)."""
+        tail = getattr(self, "vqvae", None)
+        if tail is None:
+            raise RuntimeError("decode_to_img needs OmniMambaPath.attach_vq_tail() first")
+        return tail.decode_to_img(index)
+
 
 def shifted_ce(hidden, head_weight, labels, loss_impl=None):
     """mamba_vlm.py:88-102 + omnimamba.py:276-279,305-306: logits[..., :-1, :] against labels[..., 1:], mean over the

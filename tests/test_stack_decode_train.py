@@ -272,3 +272,19 @@ def test_mmu_generate_assembles_the_scripts_prompt(dev):
     # the model saw 4 + 5 image + 5 question = 14 prompt positions: offsets / position ids continue from 14 (generation.py:236-245 of the
     # reference advances by the EMBEDDING length), and 24 - 1 - 14 + 1 = 10 ids are sampled behind the 9 prompt ids
     assert trace == [(0, None)] + [(o, o) for o in range(14, 23)] and got.shape[1] == 9 + 10
+
+
+def test_llm_backbone_forward_is_the_references_shifted_logits(dev):
+    """mamba_vlm.py:88-102: (embeddings, labels) -> (logits[..., :-1, :] flattened, labels[..., 1:] flattened); its cross-entropy is the
+    loss OmniMambaPath.forward forms without materialising the logits."""
+    torch.manual_seed(6)
+    model = tiny_path("inference").to(dev)
+    ids, cap = torch.randint(0, 40, (2, 8), device=dev), torch.randint(0, 50, (2, 6), device=dev)
+    emb, labels = model.t2i_sequence(ids, cap)
+    with torch.no_grad():
+        logits, target = model.llm_backbone(emb, labels, cond=None, task="t2i")
+        full = model.llm_backbone.mamba(None, emb, task="t2i").t2i_logits
+    assert logits.shape == (2 * (emb.shape[1] - 1), full.shape[-1]) and target.shape == (2 * (emb.shape[1] - 1),)
+    assert torch.equal(logits, full[:, :-1].reshape(-1, full.shape[-1])) and torch.equal(target, labels[:, 1:].reshape(-1))
+    with pytest.raises(RuntimeError):
+        model.llm_backbone.decode_to_img(ids)
