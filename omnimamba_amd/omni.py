@@ -137,22 +137,33 @@ class OmniMambaPath(nn.Module):
         labels = torch.cat([ign(caption_ids.shape[1] - 1), image_ids, ign(1)], dim=1)
         return emb + bb.pos_embed[:, : emb.shape[1]], labels
 
-    def mmu_sequence(self, images_feat, input_ids, labels):
-        """images_feat None = a text-only batch: zero image embeddings of img_sq_len positions (omnimamba.py:222-250)."""
+    def mmu_sequence(self, images_feat, input_ids, labels, multimodal_indices=None):
+        """images_feat None = a text-only batch: zero image embeddings of img_sq_len positions (omnimamba.py:222-250).
+        multimodal_indices (the reference's batch key, omnimamba.py:281-301): the rows that carry an image; the others get the zero
+        embeddings of the text-only form.  (The reference moves the image rows to the front of the batch; the loss is a mean over
+        tokens, so the rows stay where they are here.)"""
         ids = torch.cat([self._sp("<|mmu|>", input_ids), self._sp("<|soi|>", input_ids), self._sp("<|eoi|>", input_ids),
                          self._sp("<|sot|>", input_ids), input_ids], dim=1)
         txt = self.llm_backbone.embed_input_ids(ids)
-        if images_feat is not None:
-            img = self.projector(images_feat)
+        n_rows = ids.shape[0]
+        if images_feat is not None and multimodal_indices is not None and len(multimodal_indices) == 0:
+            images_feat = None
+        if images_feat is None:
+            img = torch.zeros(n_rows, self.backbone.img_sq_len, txt.shape[-1], device=txt.device, dtype=txt.dtype)
+        elif multimodal_indices is not None and len(multimodal_indices) < n_rows:
+            idx = torch.as_tensor(multimodal_indices, device=txt.device, dtype=torch.long)
+            some = self.projector(images_feat[idx] if images_feat.shape[0] == n_rows else images_feat)
+            img = torch.zeros(n_rows, some.shape[1], txt.shape[-1], device=txt.device, dtype=some.dtype).index_copy(0, idx, some)
         else:
-            img = torch.zeros(ids.shape[0], self.backbone.img_sq_len, txt.shape[-1], device=txt.device, dtype=txt.dtype)
+            img = self.projector(images_feat)
         emb = torch.cat((txt[:, :2], img.to(txt.dtype), txt[:, 2:]), dim=1)
         ign = lambda n: torch.full((ids.shape[0], n), IGNORE_ID, dtype=torch.long, device=ids.device)
         return emb, torch.cat([ign(2), ign(img.shape[1]), ign(2), labels.to(ids.device)], dim=1)
 
     def forward(self, inputs, task="t2i"):
         """inputs: {'t2i_flow': {'inputs': image ids (B, n_img), 'caption_ids': (B, Lc)},
-                    'mmu_flow': {'images_feat': (B, 729, 2176) | None, 'input_ids': (B, T), 'labels': (B, T)}} -> loss."""
+                    'mmu_flow': {'images_feat': (B, 729, 2176) | None, 'input_ids': (B, T), 'labels': (B, T),
+                                 'multimodal_indices': optional rows that carry an image}} -> loss."""
         lm = self.llm_backbone.mamba
         if task == "t2i":
             f = inputs["t2i_flow"]
@@ -160,7 +171,7 @@ class OmniMambaPath(nn.Module):
             hidden = lm.backbone(None, emb, None, "t2i")
             return shifted_ce(hidden, lm.img_head.weight, labels, self.loss_impl)
         f = inputs["mmu_flow"]
-        emb, labels = self.mmu_sequence(f.get("images_feat"), f["input_ids"], f["labels"])
+        emb, labels = self.mmu_sequence(f.get("images_feat"), f["input_ids"], f["labels"], f.get("multimodal_indices"))
         hidden = lm.backbone(None, emb, None, "mmu")
         return shifted_ce(hidden, lm.lm_head.weight, labels, self.loss_impl)
 
@@ -168,7 +179,7 @@ class OmniMambaPath(nn.Module):
     def codebook_entries(codebook, indices, shape, l2_norm=True):
         """The entry of the VQ tail: `quantize.get_codebook_entry` (llamagen_tokenizer/tokenizer_image/vq_model.py:261-277,
         reached from mamba_vlm.py:104-108 with shape [B, 8, 16, 16]): l2-normalised codebook rows of the sampled ids as a
-        channel-first latent.  The convolutional decoder behind it is out of scope."""
+        channel-first latent.  (The whole tail incl. the convolutional decoder: omnimamba_amd/vq_tail.py, attach_vq_tail().)"""
         emb = F.normalize(codebook, p=2, dim=-1) if l2_norm else codebook
         zq = emb[indices.reshape(-1)]
         return zq.reshape(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous()

@@ -288,3 +288,21 @@ def test_llm_backbone_forward_is_the_references_shifted_logits(dev):
     assert torch.equal(logits, full[:, :-1].reshape(-1, full.shape[-1])) and torch.equal(target, labels[:, 1:].reshape(-1))
     with pytest.raises(RuntimeError):
         model.llm_backbone.decode_to_img(ids)
+
+
+def test_mixed_mmu_batch_text_only_rows_get_zero_image_embeddings(dev):
+    """omnimamba.py:281-301: `multimodal_indices` names the rows with an image; the loss of the mixed batch is the token mean over the
+    image rows run with their features and the text-only rows run with zero image embeddings."""
+    torch.manual_seed(8)
+    model = tiny_path("inference").to(dev)
+    ids, labels = torch.randint(0, 50, (3, 6), device=dev), torch.randint(0, 50, (3, 6), device=dev)
+    feat = torch.randn(3, 5, 12, device=dev)
+    with torch.no_grad():
+        mixed = model({"mmu_flow": {"images_feat": feat, "input_ids": ids, "labels": labels, "multimodal_indices": torch.tensor([0, 2])}}, task="mmu")
+        emb, lab = model.mmu_sequence(feat, ids, labels, torch.tensor([0, 2]))
+        e_img, _ = model.mmu_sequence(feat[[0, 2]], ids[[0, 2]], labels[[0, 2]])
+        e_txt, _ = model.mmu_sequence(None, ids[[1]], labels[[1]])
+        none = model({"mmu_flow": {"images_feat": feat, "input_ids": ids, "labels": labels, "multimodal_indices": torch.tensor([], dtype=torch.long)}}, task="mmu")
+        text = model({"mmu_flow": {"images_feat": None, "input_ids": ids, "labels": labels}}, task="mmu")
+    assert torch.allclose(emb[[0, 2]], e_img) and torch.allclose(emb[[1]], e_txt) and float(emb[1, 2:7].abs().max()) == 0.0
+    assert torch.isfinite(mixed) and rel(none, text) < 1e-6
