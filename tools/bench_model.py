@@ -45,6 +45,31 @@ def bench_decode(args, dev):
                       "eager_ms_per_token": round(out["eager"] / new * 1e3, 3) if "eager" in out else None}), flush=True)
 
 
+def bench_decode_mmu(args, dev):
+    """MMU generation the way scripts/inference_mmu.py runs it: <|mmu|> <|soi|> [729 projected image positions] <|eoi|> <|sot|> + a 47-token
+    question = 780 prompt positions (but 51 prompt ids), greedy, hipGraph replay of the step, fp32 weights; 128 new tokens."""
+    from omnimamba_amd.omni import OmniMambaPath
+    torch.manual_seed(0)
+    cfg = StackConfig.omnimamba_1_3b()
+    model = OmniMambaPath(cfg, stage="inference", device=dev, dtype=torch.float32)
+    B, Q, new = args.batch, 47, 128
+    q = torch.randint(0, 50000, (B, Q), device=dev)
+    feat = torch.randn(B, 729, cfg.fused_vision_dim, device=dev)
+    P = 4 + 729 + Q
+    res = {}
+    for n in (1, new):
+        model.mmu_generate(feat, q, max_length=P + n, cg=True)                # warm-up (captures)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seq = model.mmu_generate(feat, q, max_length=P + n, cg=True)
+        torch.cuda.synchronize()
+        res[n] = time.perf_counter() - t0
+        assert seq.shape == (B, 4 + Q + n)
+    print(json.dumps({"workload": "OmniMamba-1.3B MMU generation (scripts/inference_mmu.py shape)", "batch": B, "prompt_positions": P,
+                      "prompt_ids": 4 + Q, "new_tokens": new, "time_to_first_token_ms": round(res[1] * 1e3, 2),
+                      "ms_per_token": round((res[new] - res[1]) / (new - 1) * 1e3, 3), "dtype": "f32"}), flush=True)
+
+
 def bench_train(args, dev, rank, world):
     """configs[3]/[4]-style Stage-2 step: one T2I + one MMU forward, one backward, clip, AdamW; bf16 autocast over fp32
     master weights; DDP over RCCL when world > 1."""
@@ -93,13 +118,14 @@ def main():
     ap.add_argument("--stage", default="finetune")
     ap.add_argument("--tasks", default="t2i,mmu", help="t2i,mmu (stage 2) or mmu (stage-1 MMU pretrain, BASELINE configs[3])")
     ap.add_argument("--eager-too", action="store_true")
+    ap.add_argument("--task", default="t2i", choices=["t2i", "mmu"], help="decode: T2I (configs[2]) or the MMU generation of scripts/inference_mmu.py")
     ap.add_argument("--weights", choices=["f32", "bf16"], default="f32")
     args = ap.parse_args()
     rank, local, world = init_distributed()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if args.what == "decode":
-        bench_decode(args, dev)
+        (bench_decode_mmu if args.task == "mmu" else bench_decode)(args, dev)
     else:
         bench_train(args, dev, rank, world)
 
