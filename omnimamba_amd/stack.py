@@ -352,6 +352,61 @@ class OmniMambaLM(nn.Module, GenerationMixin):
     def get_input_embeddings(self):
         return self.backbone.embedding
 
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_input_embeddings(self, value):
+        self.backbone.embedding = value
+
+    def resize_token_embeddings(self, new_num_tokens=None, pad_to_multiple_of=None):
+        """mixer_seq_simple.py:562-676, reached from OmniMamba.__init__ (omnimamba.py:103: `len(tokenizer)` padded to
+        `pad_vocab_size_multiple`): a new table of the padded size with the old rows copied and the added rows N(0, 0.02), heads tied again.
+        Same size -> the old table, untouched (the case of the shipped checkpoints: 50 287 tokens padded to 50 288)."""
+        old = self.get_input_embeddings()
+        if new_num_tokens is None and pad_to_multiple_of is None:
+            return old
+        n_new = old.weight.shape[0] if new_num_tokens is None else int(new_num_tokens)
+        if pad_to_multiple_of is not None:
+            if not isinstance(pad_to_multiple_of, int):
+                raise ValueError(f"pad_to_multiple_of must be an integer, got {pad_to_multiple_of!r}")
+            n_new = -(-n_new // pad_to_multiple_of) * pad_to_multiple_of
+        n_old, d = old.weight.shape
+        if n_new != n_old:
+            new = nn.Embedding(n_new, d, device=old.weight.device, dtype=old.weight.dtype)
+            with torch.no_grad():
+                nn.init.normal_(new.weight, std=0.02)
+                new.weight[: min(n_old, n_new)] = old.weight[: min(n_old, n_new)]
+            new.weight.requires_grad_(old.weight.requires_grad)
+            self.set_input_embeddings(new)
+            self.lm_head = nn.Linear(d, n_new, bias=False, device=old.weight.device, dtype=old.weight.dtype)
+            self.cfg.vocab_size, self._decoding_cache = n_new, None
+            if n_new % self.cfg.pad_vocab_size_multiple:
+                self.cfg.pad_vocab_size_multiple = 1          # (resized without padding: the table IS the vocabulary)
+        self.tie_weights()
+        return self.get_input_embeddings()
+
+    # ---- a directory with config.json + pytorch_model.bin (mixer_seq_simple.py:526-549; no hub access here: local paths only)
+    def save_pretrained(self, save_directory):
+        import json
+        from dataclasses import asdict
+        os.makedirs(save_directory, exist_ok=True)
+        torch.save(self.state_dict(), os.path.join(save_directory, "pytorch_model.bin"))
+        with open(os.path.join(save_directory, "config.json"), "w") as fh:
+            json.dump(asdict(self.cfg), fh, indent=4)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name, device=None, dtype=None, strict=True, **kwargs):
+        import json
+        if not os.path.isdir(pretrained_model_name):
+            raise FileNotFoundError(f"{pretrained_model_name}: a local directory with config.json and pytorch_model.bin is expected (no hub access)")
+        with open(os.path.join(pretrained_model_name, "config.json")) as fh:
+            raw = json.load(fh)
+        known = {f.name for f in StackConfig.__dataclass_fields__.values()}
+        model = cls(StackConfig(**{k: v for k, v in raw.items() if k in known}), device=device, dtype=dtype, **kwargs)
+        sd = torch.load(os.path.join(pretrained_model_name, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd, strict=strict)
+        return model
+
     def prepare_decode(self, task="t2i"):
         """Called by generation.decode before the first step (and before any graph capture): per-token-id table of the image-token
         embedding MLP for the T2I loop (its inputs are sampled VQ ids)."""

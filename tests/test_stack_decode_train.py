@@ -306,3 +306,24 @@ def test_mixed_mmu_batch_text_only_rows_get_zero_image_embeddings(dev):
         text = model({"mmu_flow": {"images_feat": None, "input_ids": ids, "labels": labels}}, task="mmu")
     assert torch.allclose(emb[[0, 2]], e_img) and torch.allclose(emb[[1]], e_txt) and float(emb[1, 2:7].abs().max()) == 0.0
     assert torch.isfinite(mixed) and rel(none, text) < 1e-6
+
+
+def test_resize_token_embeddings_and_pretrained_directory(tmp_path):
+    """mixer_seq_simple.py:526-676: save_pretrained / from_pretrained through a directory; resize_token_embeddings pads, keeps the old
+    rows, re-ties the head, and is a no-op at the same padded size (the shipped checkpoints' case, omnimamba.py:103)."""
+    from omnimamba_amd.stack import OmniMambaLM
+    torch.manual_seed(9)
+    m = OmniMambaLM(tiny_cfg())
+    assert m.get_output_embeddings() is m.lm_head and m.lm_head.weight is m.get_input_embeddings().weight
+    old = m.get_input_embeddings()
+    w0 = old.weight.detach().clone()
+    assert m.resize_token_embeddings(60, pad_to_multiple_of=16) is old            # 60 -> 64 = the table's size: untouched
+    new = m.resize_token_embeddings(70, pad_to_multiple_of=16)
+    assert new.weight.shape == (80, 32) and torch.equal(new.weight[:64], w0) and m.lm_head.weight is new.weight
+    assert m.cfg.vocab_size == 80 and float(new.weight[64:].std()) < 0.05
+    m.save_pretrained(tmp_path / "ck")
+    m2 = OmniMambaLM.from_pretrained(str(tmp_path / "ck"))
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys())
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    with pytest.raises(FileNotFoundError):
+        OmniMambaLM.from_pretrained("state-spaces/mamba2-1.3b")
