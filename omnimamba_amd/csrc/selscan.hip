@@ -591,7 +591,16 @@ __global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
   };
   // ---- one token of the lane's channel: row = the token's slot in the B / C tile; a slot behind the end of the sequence (valid = false:
   // its loads came back as zeros) is the identity step delta = 0 -- no branch around the body, whose loads the compiler then counts exactly
-  auto token = [&](float uu, float draw, float zv, int row, bool valid) -> float {
+  struct Rows { f32x4 b[4], c[4]; };   // B_t / C_t of one token as the broadcast reads deliver them
+  auto read_rows = [&](int row) -> Rows {
+    Rows r;
+    const f32x4* rb = reinterpret_cast<const f32x4*>(&sB[row * SCL_SB]);
+    const f32x4* rc = reinterpret_cast<const f32x4*>(&sC[row * SCL_SB]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { r.b[q] = rb[q]; r.c[q] = rc[q]; }
+    return r;
+  };
+  auto token = [&](float uu, float draw, float zv, const Rows& rows, bool valid) -> float {
     float dl = draw + db;
     if (a.softplus) dl = dl > 20.f ? dl : LN2 * log2_fast(1.f + exp2_fast(dl * LOG2E));
     dl = valid ? dl : 0.f;
@@ -601,11 +610,9 @@ __global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
     f32x2 dl2 = {dl, dl}, du2 = {du, du};
     OMK_OPAQUE(dl2); OMK_OPAQUE(du2);
     f32x2 ya = {0.f, 0.f}, yb = {0.f, 0.f};
-    const f32x4* rb = reinterpret_cast<const f32x4*>(&sB[row * SCL_SB]);
-    const f32x4* rc = reinterpret_cast<const f32x4*>(&sC[row * SCL_SB]);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const f32x4 b4 = rb[q], c4 = rc[q];
+      const f32x4 b4 = rows.b[q], c4 = rows.c[q];
       {
         const f32x2 e = dl2 * A2[2 * q];
         const f32x2 av = {exp2_fast(e[0]), exp2_fast(e[1])};
@@ -655,10 +662,16 @@ __global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
       commit_bc();
       wave_lds_sync();
       checkpoint(l0);
+      // the rows of token k + 1 are requested in front of token k's arithmetic (the scheduling fence behind it would otherwise pin every
+      // token's eight LDS reads right in front of their use: counters showed 24 % of the wave's cycles in s_waitcnt, one wave per SIMD)
+      Rows rows = read_rows(0);
 #pragma unroll
       for (int k = 0; k < SCL_TB; k++) {
         if (k == SCL_TB / 2) fetch_bc(l0 + SCL_TB);   // half a block ahead: 32 younger operations, inside what s_waitcnt can count
-        const float y = token(raw_to_f32<T>(pu[k]), raw_to_f32<T>(pd[k]), raw_to_f32<T>(pz[k]), k, l0 + k < a.L);
+        Rows next = rows;
+        if (k + 1 < SCL_TB) next = read_rows(k + 1);
+        const float y = token(raw_to_f32<T>(pu[k]), raw_to_f32<T>(pd[k]), raw_to_f32<T>(pz[k]), rows, l0 + k < a.L);
+        rows = next;
         // the same slot of the next block (behind the end: zeros) into the registers the token just released -- issued BEHIND their
         // last use: with the old and the new value alive together the loop-carried slot becomes a copy at the back edge, and the copy
         // a wait for (nearly) every load of the block
@@ -710,12 +723,12 @@ __global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
       if (nl == SCL_TB) {   // a full block as one straight run of 16 tokens (the tile reads of a token overlap its neighbours' arithmetic)
 #pragma unroll
         for (int t = 0; t < SCL_TB; t++) {
-          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, t, true);
+          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, read_rows(t), true);
           to[t * SCL_S + lane] = y;
         }
       } else {
         for (int t = 0; t < nl; t++) {
-          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, t, true);
+          const float y = token(tu[t * SCL_S + lane], td[t * SCL_S + lane], hasz ? tz[t * SCL_S + lane] : 0.f, read_rows(t), true);
           to[t * SCL_S + lane] = y;
         }
       }
