@@ -29,6 +29,15 @@
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
 
+#ifdef OMK_A5_NOFENCE
+#undef OMK_SCHED_FENCE
+#define OMK_SCHED_FENCE() do { } while (0)
+#endif
+
+#ifndef OMK_A5_ABL
+#define OMK_A5_ABL 0
+#endif
+
 namespace omk {
 
 constexpr int QA5 = 64;    // tokens staged per barrier
@@ -36,7 +45,8 @@ struct SmemA5 {
   uint16_t K[2][QA5 * 128];       // kx3 swizzle
   uint16_t Q[2][QA5 * 128];       // kx3 swizzle
   uint16_t U[2][2][QA5 * 64];     // [buffer][head of the pair], ux3 swizzle
-  float cs[2][2][QA5], lw[2][2][QA5], rl[2][2][QA5], ws[2][2][QA5], dtl[2][2][QA5];   // [buffer][head][chunk row]
+  f32x2 rv[2][2][QA5];            // [buffer][head][chunk row]: {cs, rl} of the row
+  float lw[2][2][QA5], ws[2][2][QA5], dtl[2][2][QA5];
   float dec[2][2][4];             // decay over sub-chunk j
   float Dv[2][64];
 };
@@ -112,11 +122,10 @@ __global__ __launch_bounds__(512) void ssd_a5_kernel(GScan a) {
     const float e15 = wave_read_lane(cs, 15), e31 = wave_read_lane(cs, 31), e47 = wave_read_lane(cs, 47), e63 = wave_read_lane(cs, 63);
     const float csb = g16 == 0 ? 0.f : (g16 == 1 ? e15 : (g16 == 2 ? e31 : e47));   // prefix in front of the lane's sub-chunk
     const float cse = g16 == 0 ? e15 : (g16 == 1 ? e31 : (g16 == 2 ? e47 : e63));   // prefix at its end
-    sm.cs[buf][hh][lane] = cs;
+    sm.rv[buf][hh][lane] = f32x2{cs, exp2_fast(cs - csb)};
+    if (MODE == GS_DX) sm.dtl[buf][hh][lane] = rdt;
     sm.lw[buf][hh][lane] = log2_fast(rwv) - cs;
-    sm.rl[buf][hh][lane] = exp2_fast(cs - csb);
     sm.ws[buf][hh][lane] = rwv * exp2_fast(cse - cs);
-    sm.dtl[buf][hh][lane] = rdt;
     if (t16 == 15) sm.dec[buf][hh][g16] = exp2_fast(cse - csb);
   };
 
@@ -171,13 +180,163 @@ __global__ __launch_bounds__(512) void ssd_a5_kernel(GScan a) {
   f32x4 Du = {0.f, 0.f, 0.f, 0.f};
   if (!DFOLD) Du = *reinterpret_cast<const f32x4*>(&sm.Dv[hh][16 * w + 4 * g16]);
 
-  OMK_VM_DRAIN();
+  // ---- the sub-chunk pipeline.  A sub-chunk is two phases: (1) S_in^T Q^T and G (8 MFMAs on the Q / K row fragments), (2) state
+  // update, M build, U^T M^T and the output rows (9 MFMAs on the transposed K fragments, the U fragment and the token scalars).  The
+  // operands of phase 2 are requested in front of phase 1 of the same sub-chunk, the row fragments of the NEXT sub-chunk in front of
+  // phase 2 (into the registers phase 1 has just released), so every LDS read has a phase of matrix work between request and use.
+  // The one barrier of a chunk sits inside its last sub-chunk: behind the last request for the current buffers, in front of the
+  // first request for the next ones.
+  struct FragA { u32x4 qf[4], kf[4]; };
+  struct FragB { s16x4 uf, kt[8]; f32x2 rv; f32x4 lw4, ws4; float dec, dts; u32x2 xr; };
+  auto load_rows = [&](FragA& f, int buf, int j) {
+    if (OMK_A5_ABL & 1) { asm volatile("" : "+v"(f.qf[0]), "+v"(f.qf[1]), "+v"(f.qf[2]), "+v"(f.qf[3]), "+v"(f.kf[0]), "+v"(f.kf[1]), "+v"(f.kf[2]), "+v"(f.kf[3])); return; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) f.qf[i] = ld16(&sm.Q[buf][o_rd[i] + 16 * 128 * j]);
+#ifdef OMK_A5_SKIPM
+    if (j == 0)
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; i++) f.kf[i] = ld16(&sm.K[buf][o_rd[i] + 16 * 128 * j]);
+  };
+  auto load_cols = [&](FragB& f, int buf, int j) {
+    if (OMK_A5_ABL & 1) {
+      asm volatile("" : "+v"(f.uf), "+v"(f.rv), "+v"(f.lw4), "+v"(f.ws4), "+v"(f.dec));
+#pragma unroll
+      for (int t = 0; t < 8; t++) asm volatile("" : "+v"(f.kt[t]));
+      return;
+    }
+    f.rv = sm.rv[buf][hh][16 * j + t16];
+    f.ws4 = *reinterpret_cast<const f32x4*>(&sm.ws[buf][hh][16 * j + 4 * g16]);
+    f.uf = lds_read_tr16_b64(&sm.U[buf][hh][o_uf + 16 * 64 * j]);   // U[16 j + 4 g16 + e][16 w + t16]
+    f.dec = sm.dec[buf][hh][j];
+#pragma unroll
+    for (int t = 0; t < 8; t++) f.kt[t] = lds_read_tr16_b64(&sm.K[buf][o_kt[t >> 1] + 4 * (t & 1) + 16 * 128 * j]);
+    f.lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[buf][hh][16 * j + 4 * g16]);
+    if (!DFOLD) f.xr = *reinterpret_cast<const u32x2*>(&sm.U[buf][hh][o_xu + 16 * 64 * j]);
+    if (MODE == GS_DX) f.dts = sm.dtl[buf][hh][16 * j + t16];
+  };
+  f32x4 accA, gt;
+  auto phase1 = [&](const FragA& f, int j, bool dump_here, uint16_t* dp) {
+    // (a) S_in^T Q^T: the bf16 pack of the accumulator slice is the A operand;  (b) G^T[s][l] of the diagonal block
+    accA = f32x4{0.f, 0.f, 0.f, 0.f}; gt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u32x4 sp;
+      sp[0] = pack_bf16x2(accS[2 * i][0], accS[2 * i][1]);
+      sp[1] = pack_bf16x2(accS[2 * i][2], accS[2 * i][3]);
+      sp[2] = pack_bf16x2(accS[2 * i + 1][0], accS[2 * i + 1][1]);
+      sp[3] = pack_bf16x2(accS[2 * i + 1][2], accS[2 * i + 1][3]);
+      if (DUMP && j == 0 && dump_here) st16(dp + su * 128 + (((4 * i + g16) ^ swzK(su)) << 3), sp);
+#ifdef OMK_A5_SKIPM   // experiment (wrong results): what sharing M between the waves of a head could buy
+      if (j == 0)
+#endif
+      gt = mfma16x16x32_bf16(as_s16x8(f.kf[i]), as_s16x8(f.qf[i]), gt);
+      accA = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.qf[i]), accA);
+    }
+  };
+  auto phase2 = [&](const FragB& f, int j, int tlo) {
+    // ---- (c) state update: S = dec S + K^T (ws U), the scaled U rows as bf16 hi + lo
+    {
+      float us[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) us[e] = bf16_to_f32((uint16_t)f.uf[e]) * f.ws4[e];
+      u32x4 ub;
+#pragma unroll
+      for (int p2 = 0; p2 < 2; p2++) {
+        const uint32_t hi = pack_bf16x2(us[2 * p2], us[2 * p2 + 1]);
+        ub[p2] = hi;
+#ifdef OMK_A5_NOLO
+        ub[2 + p2] = 0u;
+#else
+        ub[2 + p2] = pack_bf16x2(us[2 * p2] - bf_lo(hi), us[2 * p2 + 1] - bf_hi(hi));
+#endif
+      }
+      s16x4 uh, ul;
+      uh[0] = (short)(ub[0] & 0xffffu); uh[1] = (short)(ub[0] >> 16); uh[2] = (short)(ub[1] & 0xffffu); uh[3] = (short)(ub[1] >> 16);
+      ul[0] = (short)(ub[2] & 0xffffu); ul[1] = (short)(ub[2] >> 16); ul[2] = (short)(ub[3] & 0xffffu); ul[3] = (short)(ub[3] >> 16);
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+#ifdef OMK_A5_NODECAY
+        accS[t] = mfma16x16x16_bf16(f.kt[t], uh, accS[t]);
+#else
+        accS[t] = mfma16x16x16_bf16(f.kt[t], uh, accS[t] * f.dec);
+#endif
+#ifndef OMK_A5_NOLO
+        accS[t] = mfma16x16x16_bf16(f.kt[t], ul, accS[t]);
+#endif
+      }
+    }
+    // ---- (b) M^T (decay, mask, hi + lo) -> U^T M^T
+    float v[4];
+#ifdef OMK_A5_SKIPM
+    if (j != 0) { v[0] = gt[0]; v[1] = gt[1]; v[2] = gt[2]; v[3] = gt[3]; } else
+#endif
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      v[r] = gt[r] * exp2_fast(f.rv[0] + f.lw4[r]);
+      if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh : 0.f);
+      else v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+    }
+    u32x4 mm;
+#ifdef OMK_A5_SKIPM
+    if (j != 0) mm = __builtin_bit_cast(u32x4, f.lw4); else
+#endif
+#pragma unroll
+    for (int p2 = 0; p2 < 2; p2++) {
+      const uint32_t hi = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
+      mm[p2] = hi;
+      mm[2 + p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi), v[2 * p2 + 1] - bf_hi(hi));
+    }
+    s16x4 mh, ml;
+    mh[0] = (short)(mm[0] & 0xffffu); mh[1] = (short)(mm[0] >> 16); mh[2] = (short)(mm[1] & 0xffffu); mh[3] = (short)(mm[1] >> 16);
+    ml[0] = (short)(mm[2] & 0xffffu); ml[1] = (short)(mm[2] >> 16); ml[2] = (short)(mm[3] & 0xffffu); ml[3] = (short)(mm[3] >> 16);
+    f32x4 accB = mfma16x16x16_bf16(f.uf, mh, f32x4{0.f, 0.f, 0.f, 0.f});
+    accB = mfma16x16x16_bf16(f.uf, ml, accB);
+    // ---- output rows: the lane's row l = 16 j + t16, columns 16 w + 4 g16 + r
+    f32x4 o = accA * f.rv[1] + accB;
+    const int erow = rowtok(16 * j + t16);
+    if (!DFOLD) {
+      const float dts = MODE == GS_DX ? f.dts : 1.f;
+      o = o * dts + Du * f32x4{bf_lo(f.xr[0]), bf_hi(f.xr[0]), bf_lo(f.xr[1]), bf_hi(f.xr[1])};
+    }
+    const uint32_t eoff = (uint32_t)(erow * osl + 16 * w + 4 * g16);
+    if (MODE == GS_Y && EXTRAS && tlo + erow < a.L) {
+      if (oxb) {
+        u32x2 ox = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(oxb + (int64_t)tlo * osl + eoff) = ox;
+      }
+      if (zb) {
+        const u32x2 zr = *reinterpret_cast<const u32x2*>(zb + (int64_t)tlo * zsl + erow * zsl + 16 * w + 4 * g16);
+        o[0] *= silu_fast(bf_lo(zr[0])); o[1] *= silu_fast(bf_hi(zr[0]));
+        o[2] *= silu_fast(bf_lo(zr[1])); o[3] *= silu_fast(bf_hi(zr[1]));
+      }
+    }
+    const u32x2 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    if (!(OMK_A5_ABL & 16)) buf_st8(Or, ov, 2u * eoff, 2u * (uint32_t)(tlo * osl));
+    else asm volatile("" :: "v"(ov));
+  };
+
+#ifdef OMK_PHASE_PROF   // developer build (tools/phase_prof_a5.py): s_memtime deltas per phase, workgroup 0
+  uint64_t pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+#define PT5(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+  uint64_t tprev = prof ? clock64_() : 0;
+  const uint64_t t_core0 = tprev, t_ref0 = prof ? __builtin_readsteadycounter() : 0;
+#else
+#define PT5(i) do { } while (0)
+#endif
+#ifdef OMK_A5_PRIO
+  if (wave >= 4) OMK_SET_PRIO(1);
+#endif
+  FragA fa;
+  FragB fb0, fb1;   // two sets, static names: sub-chunk parity
+  load_rows(fa, 0, 0);
+  load_cols(fb0, 0, 0);
+  stlo = chunk_lo(c0 + 1 < c1 ? c0 + 1 : c0);
+  prefetch();
   for (int c = c0; c < c1; c++) {
     const int cur = (c - c0) & 1, nxt = cur ^ 1;
     const int tlo = chunk_lo(c);
-    const int cnext = c + 1 < c1 ? c + 1 : c;   // the last iteration re-stages its own chunk: no branch around loads
-    stlo = chunk_lo(cnext);
-    prefetch();
     bool dump_here = false;
     uint16_t* dp = nullptr;
     if (DUMP && a.dump) {   // window-boundary image of the state in front of this chunk, the [u][k] kx3 image ssd_cp.hip reads
@@ -187,101 +346,44 @@ __global__ __launch_bounds__(512) void ssd_a5_kernel(GScan a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      // ---- fragments of the sub-chunk's 16 rows
-      u32x4 qf[4], kf[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) qf[i] = ld16(&sm.Q[cur][o_rd[i] + 16 * 128 * j]);
-#pragma unroll
-      for (int i = 0; i < 4; i++) kf[i] = ld16(&sm.K[cur][o_rd[i] + 16 * 128 * j]);
-      const s16x4 uf = lds_read_tr16_b64(&sm.U[cur][hh][o_uf + 16 * 64 * j]);   // U[16 j + 4 g16 + e][16 w + t16]
-      // ---- (a) S_in^T Q^T: the bf16 pack of the accumulator slice is the A operand
-      f32x4 accA = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        u32x4 sp;
-        sp[0] = pack_bf16x2(accS[2 * i][0], accS[2 * i][1]);
-        sp[1] = pack_bf16x2(accS[2 * i][2], accS[2 * i][3]);
-        sp[2] = pack_bf16x2(accS[2 * i + 1][0], accS[2 * i + 1][1]);
-        sp[3] = pack_bf16x2(accS[2 * i + 1][2], accS[2 * i + 1][3]);
-        if (DUMP && j == 0 && dump_here) st16(dp + su * 128 + (((4 * i + g16) ^ swzK(su)) << 3), sp);
-        accA = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(qf[i]), accA);
+      FragB& fb = (j & 1) ? fb1 : fb0;
+      FragB& fbn = (j & 1) ? fb0 : fb1;
+      PT5(0);
+      phase1(fa, j, dump_here, dp);
+      OMK_SCHED_FENCE();
+      PT5(2);
+      if (j < 3) { load_rows(fa, cur, j + 1); load_cols(fbn, cur, j + 1); }
+      else {
+        // stage the next chunk (requested an iteration ago), its scalars, the one barrier of the chunk
+        if (!(OMK_A5_ABL & 2)) commit(nxt);
+        if (w == 0) scalars(nxt);
+        PT5(4);
+        if (!(OMK_A5_ABL & 8)) block_sync();
+        PT5(5);
+        load_rows(fa, nxt, 0);
+        load_cols(fbn, nxt, 0);
+        stlo = chunk_lo(c + 2 < c1 ? c + 2 : c1 - 1);   // (the last iterations re-stage the last chunk: no branch around loads)
+        if (!(OMK_A5_ABL & 4)) prefetch();
       }
-      // ---- (b) diagonal block: G^T[s][l] -> M^T (decay, mask, hi + lo) -> U^T M^T
-      f32x4 gt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(kf[i]), as_s16x8(qf[i]), gt);
-      const float cs_l = sm.cs[cur][hh][16 * j + t16];
-      const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[cur][hh][16 * j + 4 * g16]);
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        v[r] = gt[r] * exp2_fast(cs_l + lw4[r]);
-        if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh : 0.f);
-        else v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
-      }
-      u32x4 mm;
-#pragma unroll
-      for (int p2 = 0; p2 < 2; p2++) {
-        const uint32_t hi = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
-        mm[p2] = hi;
-        mm[2 + p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi), v[2 * p2 + 1] - bf_hi(hi));
-      }
-      s16x8 uu;
-      uu[0] = uf[0]; uu[1] = uf[1]; uu[2] = uf[2]; uu[3] = uf[3]; uu[4] = uf[0]; uu[5] = uf[1]; uu[6] = uf[2]; uu[7] = uf[3];
-      const f32x4 accB = mfma16x16x32_bf16(uu, as_s16x8(mm), f32x4{0.f, 0.f, 0.f, 0.f});
-      // ---- output rows: the lane's row l = 16 j + t16, columns 16 w + 4 g16 + r
-      {
-        const float rl_l = sm.rl[cur][hh][16 * j + t16];
-        f32x4 o = accA * rl_l + accB;
-        const int erow = rowtok(16 * j + t16);
-        if (!DFOLD) {
-          const float dts = MODE == GS_DX ? sm.dtl[cur][hh][16 * j + t16] : 1.f;
-          const u32x2 xr = *reinterpret_cast<const u32x2*>(&sm.U[cur][hh][o_xu + 16 * 64 * j]);
-          o = o * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
-        }
-        const uint32_t eoff = (uint32_t)(erow * osl + 16 * w + 4 * g16);
-        if (MODE == GS_Y && EXTRAS && tlo + erow < a.L) {
-          if (oxb) {
-            u32x2 ox = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(oxb + (int64_t)tlo * osl + eoff) = ox;
-          }
-          if (zb) {
-            const u32x2 zr = *reinterpret_cast<const u32x2*>(zb + (int64_t)tlo * zsl + erow * zsl + 16 * w + 4 * g16);
-            o[0] *= silu_fast(bf_lo(zr[0])); o[1] *= silu_fast(bf_hi(zr[0]));
-            o[2] *= silu_fast(bf_lo(zr[1])); o[3] *= silu_fast(bf_hi(zr[1]));
-          }
-        }
-        const u32x2 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-        buf_st8(Or, ov, 2u * eoff, 2u * (uint32_t)(tlo * osl));
-      }
-      // ---- (c) state update: S = dec S + K^T (ws U), the scaled U rows as bf16 hi + lo
-      {
-        const f32x4 ws4 = *reinterpret_cast<const f32x4*>(&sm.ws[cur][hh][16 * j + 4 * g16]);
-        float us[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) us[e] = bf16_to_f32((uint16_t)uf[e]) * ws4[e];
-        u32x4 ub;
-#pragma unroll
-        for (int p2 = 0; p2 < 2; p2++) {
-          const uint32_t hi = pack_bf16x2(us[2 * p2], us[2 * p2 + 1]);
-          ub[p2] = hi;
-          ub[2 + p2] = pack_bf16x2(us[2 * p2] - bf_lo(hi), us[2 * p2 + 1] - bf_hi(hi));
-        }
-        const float dec = sm.dec[cur][hh][j];
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-          const s16x4 kt = lds_read_tr16_b64(&sm.K[cur][o_kt[t >> 1] + 4 * (t & 1) + 16 * 128 * j]);
-          s16x8 kk;
-          kk[0] = kt[0]; kk[1] = kt[1]; kk[2] = kt[2]; kk[3] = kt[3]; kk[4] = kt[0]; kk[5] = kt[1]; kk[6] = kt[2]; kk[7] = kt[3];
-          accS[t] = mfma16x16x32_bf16(kk, as_s16x8(ub), accS[t] * dec);
-        }
-      }
+      OMK_SCHED_FENCE();
+      PT5(3);
+#if defined(OMK_A5_PAD) && OMK_A5_PAD == 1
+      asm volatile(".rept 100\n s_nop 0\n .endr" ::: "memory");
+#elif defined(OMK_A5_PAD) && OMK_A5_PAD == 2
+      { int dmy = lane; asm volatile(".rept 100\n v_mov_b32 %0, %0\n .endr" : "+v"(dmy)); }
+#elif defined(OMK_A5_PAD) && OMK_A5_PAD == 3
+      { int dmy = lane, dm2 = tid; asm volatile(".rept 50\n v_mov_b32 %0, %0\n v_mov_b32 %1, %1\n .endr" : "+v"(dmy), "+v"(dm2)); }
+#endif
+      phase2(fb, j, tlo);
+      OMK_SCHED_FENCE();
     }
-    // ---- stage the next chunk, its scalars, one barrier
-    commit(nxt);
-    if (w == 0) scalars(nxt);
-    block_sync();
   }
+#ifdef OMK_PHASE_PROF
+  PT5(0);
+  if (prof) { pt[10] = clock64_() - t_core0; pt[11] = __builtin_readsteadycounter() - t_ref0; }
+  if (prof && lane == 0)
+    for (int i = 0; i < 12; i++) a.prof[wave * 12 + i] = pt[i];
+#endif
   if (a.fin && seg == a.nseg - 1) {
     const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
 #pragma unroll
