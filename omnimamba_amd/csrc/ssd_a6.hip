@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 4; r++) Du[r] = load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)(16 * w + 4 * g16 + r) * a.Dsp, a.D_dt);
   }
 
-  // ---- M tiles of one chunk (buffers kb: K / Q / scalars, mb: tiles).  Wave roles: w = 0 tile (0, 0) of sub-chunk 0, w = 3 of
-  // sub-chunk 1; w = 1 / 2 tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds
+  // ---- M tiles of one chunk (buffers kb: K / Q / scalars, mb: tiles).  Wave roles: w = 0 none (it computes the token scalars),
+  // w = 3 the tiles (0, 0) of both sub-chunks, w = 1 / 2 the tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds
   // s = 4 g16 + r of its own l = t16.
   auto krow = [&](int kb, int row0, int i) -> u32x4 {   // K[row0 + t16][32 i + 8 g16 .. + 7] out of the half-swapped tile
     const u32x2 lo = *reinterpret_cast<const u32x2*>(&sm.K[kb][o_kr[i] + 128 * row0]);
@@ -204,8 +204,10 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     }
   };
   auto build_tiles = [&](int kb, int mb) {
-    const int jj = w >> 1;   // w = 0, 1: sub-chunk 0; w = 2, 3: sub-chunk 1
-    if (w == 0 || w == 3) {
+    if (w == 0) return;   // (the wave that computes the token scalars)
+    if (w == 3) {
+#pragma unroll
+     for (int jj = 0; jj < 2; jj++) {
       const int r0 = 32 * jj;
       f32x4 gt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       uint32_t hi[2], lo[2];
       decay_tile(gt, cs_l, lw4, true, hi, lo);
       sm.M[mb][hh][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+     }
     } else {
+      const int jj = w - 1;
       const int r0 = 32 * jj;
       f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -396,6 +400,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     if (c + 1 < c1) build_tiles(kb1, ub1);
     if (!(OMK_A6_ABL & 2)) { commit_kq(kb2); commit_u(ub1); }
     if (w == 0) scalars(kb2);
+#ifndef OMK_A6_LATEPF
+    if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }   // a whole iteration ahead of their commit
+#endif
     OMK_SCHED_FENCE();
     // ---- sub-chunk 1; the barrier of the chunk behind its last request for the current buffers
     load_cols(fc, kb0, ub0, 1);
@@ -404,7 +411,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     if (!(OMK_A6_ABL & 8)) block_sync();
     load_rows(fr, kb1, 0);
+#ifdef OMK_A6_LATEPF
     if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }
+#endif
     OMK_SCHED_FENCE();
     phase2(fc, 1, tlo);
     OMK_SCHED_FENCE();
