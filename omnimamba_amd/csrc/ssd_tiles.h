@@ -108,6 +108,48 @@ __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff,
 #endif
 }
 
+// ---- LDS-DMA (buffer_load ... lds): the 64 lanes of a wave fetch 16 (4) bytes each from the resource and the memory pipeline writes
+// them to LDS at lds_base + 16 (4) * lane -- no staging registers, no ds_write pass.  lds_base must be wave-uniform; the request
+// counts on vmcnt like any load, and NOTHING orders a later ds_read behind it except the issuing wave's own s_waitcnt vmcnt (plus a
+// barrier for the other waves).  Rows behind the end of the buffer arrive as zeros.
+__device__ __forceinline__ void buf_ld16_lds(const BufRes& b, void* lds_base, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (o < b.nbytes) v = *reinterpret_cast<const u32x4*>(b.base + o);
+  *reinterpret_cast<u32x4*>((char*)lds_base + 16 * lane_id()) = v;
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+__device__ __forceinline__ void buf_ld4_lds(const BufRes& b, void* lds_base, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  uint32_t v = 0u;
+  if (o < b.nbytes) v = *reinterpret_cast<const uint32_t*>(b.base + o);
+  *reinterpret_cast<uint32_t*>((char*)lds_base + 4 * lane_id()) = v;
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_base, 4, (int)voff, (int)soff, 0, 0);
+#endif
+}
+// the wave's vector-memory operations except the N youngest have completed (in-order completion, as the compiler's own wait counts assume)
+#ifdef OMK_EMU
+#define OMK_VMCNT(n) do { } while (0)
+#else
+#define OMK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+// workgroup barrier that does NOT drain vector memory (LDS-DMA requests stay in flight across it): the wave's own LDS traffic is
+// complete (lgkmcnt(0)), then s_barrier.  __syncthreads() would wait for vmcnt(0) whenever a DMA is pending.
+__device__ __forceinline__ void block_sync_lds() {
+#ifdef OMK_EMU
+  block_sync();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+
 // LDS layouts: unpadded rows, the 16-byte segment index XOR-ed with a function of the row (see ssd_mfma.hip, class A):
 //   128-column tiles (256 B rows): seg ^ swzK(row);  64-column tiles (128 B rows): seg ^ swzU(row), swzU = swzK & 7.
 __device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
