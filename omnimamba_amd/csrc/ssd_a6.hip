@@ -1,11 +1,9 @@
-// ssd_a6.hip -- class A scan (forward y and the dx scan of the backward): state in COLUMN SLICES, M tiles shared through LDS, tiles
-// staged by LDS-DMA.
+// ssd_a6.hip -- class A scan (forward y and the dx scan of the backward): state in COLUMN SLICES, M tiles shared through LDS.
 //
-// What the measurements of round 4 say about the scan kernels of this repo (profiles/r04_a5_experiments.txt): the pipes of a SIMD do not
-// hide behind each other to any useful degree at two waves per SIMD -- padding the chunk loop with VALU instructions costs their full
-// issue time, the LDS store pass of the staging costs its full time, a matrix instruction its 16 cycles -- so the time of a chunk is
-// close to the SUM of what it asks of the VALU, the matrix pipe, the LDS and the memory waits.  The row-strip kernel (ssd_mfma.hip)
-// spends ~820 instructions per wave and 64-token chunk (930 on the heaviest strip, which sets the pace).  This kernel needs ~550:
+// What the measurements of round 4 say about the scan kernels of this repo (profiles/r04_a5_experiments.txt): a SIMD retires about one
+// instruction every four cycles whatever the mix -- a wave's VALU, LDS and matrix instructions do not hide behind each other to any useful
+// degree at two waves per SIMD --, so the time of a chunk is its instruction count.  The row-strip kernel (ssd_mfma.hip) spends ~820
+// instructions per wave and 64-token chunk (930 on the heaviest strip, which sets the pace).  This kernel is built to need about half:
 //
 //   * wave w of a head owns the output COLUMNS u in [16 w, 16 w + 16) and the matching slice S[k = 0..127][u] of the running state (eight
 //     16 x 16 accumulator tiles).  The bf16 pack of that slice IS the A operand of S_in^T Q^T: the state never goes through LDS, is never
@@ -17,16 +15,13 @@
 //     head builds each tile (G = K Q^T, decay, causal mask, D on the diagonal, bf16 hi + lo) and leaves it in LDS as a ready B operand.
 //     Tiles are built one chunk AHEAD (K / Q / token scalars are staged two chunks ahead of their use, three LDS buffers), so the one
 //     barrier per chunk that the staging needs anyway also publishes them.
-//   * K / Q / U tiles and the dt' rows reach LDS by DMA (buffer_load ... lds, the XOR swizzle applied to the SOURCE address): no staging
-//     registers, no ds_write pass (48 KB per chunk at ~80 B / clk was 9 % of the kernel), and a whole chunk iteration between request
-//     and first use (with register staging the loads were waited for at the commit, 0.65 of an iteration later, and were late).
 //
 // One workgroup = 8 waves = the two heads of a head PAIR (the group's K / Q tiles are staged once for both), one workgroup per CU.
 // Contraction-slot bookkeeping (an MFMA sums over its 32 slots in any order as long as A and B agree):
 //   state tile t (0..7), accumulator register r on lane (n = lane & 15, g = lane >> 4)  <->  u = 16 w + n,
 //   k = 32 (t >> 1) + 8 g + 4 (t & 1) + r -- the registers of tiles 2i, 2i + 1 are k = 32 i + 8 g + 0..7, what a 16-byte row read of Q hands
-//   lane (l, g) for k-step i.  (The natural order k = 16 t + 4 g + r with the row fragments as two 8-byte reads measured 20 % slower:
-//   8-byte LDS reads need more waves per SIMD than this kernel has to reach their rate.)
+//   lane (l, g) for k-step i.  The K tile keeps the two 8-byte halves of a 16-byte segment swapped in rows with bit 2 set, so that the
+//   transposed reads of the state update (which fetch ONE half per lane) spread over all banks.
 #include <cstdlib>
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
@@ -39,17 +34,19 @@ namespace omk {
 
 constexpr int QA6 = 64;    // tokens staged per barrier
 struct SmemA6 {
-  uint16_t K[3][QA6 * 128];       // kx3 swizzle
+  uint16_t K[3][QA6 * 128];       // kx3 swizzle + half swap (kxh)
   uint16_t Q[3][QA6 * 128];       // kx3 swizzle
   uint16_t U[2][2][QA6 * 64];     // [buffer][head of the pair], ux3 swizzle
   u32x4 M[2][2][6][64];           // [buffer][head][record][lane]: per sub-chunk jj: 3 jj + 0 = {hi, lo} of tile (strip 0, block 0);
                                   // 3 jj + 1 = {hi of (1, 0), hi of (1, 1)}; 3 jj + 2 = {lo of (1, 0), lo of (1, 1)}
-  float rl[3][2][QA6], ws[3][2][QA6], dtl[3][2][QA6];   // [buffer][head][chunk row], read by the chunk's own iteration
-  float cs[2][2][QA6], lw[2][2][QA6];                   // read one iteration earlier (tile build): two buffers
+  f32x2 rv[3][2][QA6];            // [buffer][head][chunk row]: {cs, rl}
+  float lw[3][2][QA6], ws[3][2][QA6], dtl[3][2][QA6];
   float dec[3][2][2];             // decay over sub-chunk jj
-  float dtr[2][2][QA6];           // [head][dt' of the row's token, dt' of the token whose decay the row carries][row]: DMA target
 };
 static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
+
+// K tile element offset: kx3 with the 8-byte halves of a segment swapped in rows with bit 2 set
+__device__ __forceinline__ int kxh(int row, int col) { return kx3(row, col) ^ (((row >> 2) & 1) << 2); }
 
 template <int MODE, bool EXTRAS, bool DFOLD, bool DUMP, bool KHILO>
 __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
@@ -69,12 +66,11 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   const int c0 = seg * a.cps, c1 = (c0 + a.cps < nC) ? c0 + a.cps : nC;
   const bool rev = a.reverse != 0;
   auto chunk_lo = [&](int c) -> int { return (rev ? nC - 1 - c : c) * QA6; };
-  auto clipc = [&](int c) -> int { return c < c1 ? c : c1 - 1; };   // (chunks behind the end re-stage the last one: no branch around requests)
+  auto clipc = [&](int c) -> int { return c < c1 ? c : c1 - 1; };   // (chunks behind the end re-stage the last one: no branch around loads)
   auto rowtok = [&](int i) -> int { return rev ? QA6 - 1 - i : i; };
 
-  // ---- staging by DMA.  A request moves 64 x 16 bytes to 1 KB of LDS in lane order, so the lane picks the SOURCE segment that belongs
-  // at its slot: K / Q request n (0..15) fills rows 4 n .. 4 n + 3 (lane = 16 row + slot), wave `wave` issues n = 2 wave, 2 wave + 1;
-  // U request n (0..7) of a head fills rows 8 n .. 8 n + 7 (lane = 8 row + slot), wave (hh, w) issues n = 2 w, 2 w + 1.
+  // ---- staging: K, Q two 16-byte segments per thread (rows rowk + 32 r), U of the wave's own head two (rows rowu + 32 r)
+  const int rowk = tid >> 4, ck8 = (tid & 15) * 8, rowu = (tid & 255) >> 3, cu8 = (tid & 7) * 8;
   const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
   const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
   const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh;
@@ -82,39 +78,46 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   const int ksl = (int)a.K.sl, qsl = (int)a.Q.sl, usl = (int)a.U.sl, osl = (int)a.osl;
   const BufRes Kr = make_buf(Kb, (uint32_t)((int64_t)a.L * ksl * 2)), Qr = make_buf(Qb, (uint32_t)((int64_t)a.L * qsl * 2));
   const BufRes Ur = make_buf(Ub, (uint32_t)((int64_t)a.L * usl * 2)), Dr = make_buf(dtrow, (uint32_t)((int64_t)a.L * 4));
-  uint32_t kvo[2], qvo[2], uvo[2];
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-    const int rk = 8 * wave + 4 * m + (lane >> 4), sk = (lane & 15) ^ swzK(rk);
-    kvo[m] = 2u * (uint32_t)(rowtok(rk) * ksl + 8 * sk);
-    qvo[m] = 2u * (uint32_t)(rowtok(rk) * qsl + 8 * sk);
-    const int ru = 16 * w + 8 * m + (lane >> 3), sU = (lane & 7) ^ swzU(ru);
-    uvo[m] = 2u * (uint32_t)(rowtok(ru) * usl + 8 * sU);
-  }
+  const uint32_t kvo = 2u * (uint32_t)((rev ? 31 - rowk : rowk) * ksl + ck8), qvo = 2u * (uint32_t)((rev ? 31 - rowk : rowk) * qsl + ck8);
+  const uint32_t uvo = 2u * (uint32_t)((rev ? 31 - rowu : rowu) * usl + cu8);
   const uint32_t dvo = 4u * (uint32_t)rowtok(lane), dvo_a = 4u * (uint32_t)(rowtok(lane) + (rev ? 1 : 0));
-  auto dma_kq = [&](int kb, int tl) {
+  u32x4 rk[2], rq[2], ru[2];
+  float rdt = 0.f, rda = 0.f, rwv = 0.f;
+  int stlo = 0;   // first token of the K / Q / dt chunk in the staging registers
+  auto prefetch_kq = [&](int tl) {
+    stlo = tl;
     const uint32_t sk = 2u * (uint32_t)(tl * ksl), sq = 2u * (uint32_t)(tl * qsl);
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-      buf_ld16_lds(Kr, &sm.K[kb][(8 * wave + 4 * m) * 128], kvo[m], sk);
-      buf_ld16_lds(Qr, &sm.Q[kb][(8 * wave + 4 * m) * 128], qvo[m], sq);
+    for (int r = 0; r < 2; r++) {
+      const int ro = rev ? 32 * (1 - r) : 32 * r;
+      rk[r] = buf_ld16(Kr, kvo, sk + 2u * (uint32_t)(ro * ksl));
+      rq[r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)(ro * qsl));
+    }
+    rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
+    rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
+  };
+  auto prefetch_u = [&](int tl) {
+    const uint32_t su = 2u * (uint32_t)(tl * usl);
+#pragma unroll
+    for (int r = 0; r < 2; r++) ru[r] = buf_ld16(Ur, uvo, su + 2u * (uint32_t)((rev ? 32 * (1 - r) : 32 * r) * usl));
+  };
+  const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
+  const int hk = ((rowk >> 2) & 1) << 2;   // half swap of the thread's K rows (rowk and rowk + 32: the same bit 2)
+  auto commit_kq = [&](int kb) {   // rows past the end arrived as zeros
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk]) = u32x2{rk[r][0], rk[r][1]};
+      *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk ^ 4]) = u32x2{rk[r][2], rk[r][3]};
+      st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
     }
   };
-  auto dma_u = [&](int ub, int tl) {
-    const uint32_t su_ = 2u * (uint32_t)(tl * usl);
+  auto commit_u = [&](int ub) {
 #pragma unroll
-    for (int m = 0; m < 2; m++) buf_ld16_lds(Ur, &sm.U[ub][hh][(16 * w + 8 * m) * 64], uvo[m], su_);
-  };
-  int stlo = 0;   // first token of the chunk whose dt' rows are in (or on their way to) sm.dtr
-  auto dma_dt = [&](int tl) {   // waves with w == 0
-    stlo = tl;
-    buf_ld4_lds(Dr, &sm.dtr[hh][0][0], dvo, 4u * (uint32_t)tl);
-    if (rev) buf_ld4_lds(Dr, &sm.dtr[hh][1][0], dvo_a, 4u * (uint32_t)tl);
+    for (int r = 0; r < 2; r++) st16(&sm.U[ub][hh][o_cu + 32 * 64 * r], ru[r]);
   };
   const float Ah = a.A[h];
   const float Ah2 = Ah * LOG2E;
-  auto scalars = [&](int kb, int pb) {   // waves with w == 0; lanes = rows of the chunk whose dt' rows have landed in sm.dtr
-    float rdt = sm.dtr[hh][0][lane], rda = sm.dtr[hh][rev ? 1 : 0][lane], rwv;
+  auto scalars = [&](int kb) {   // waves with w == 0; lanes = rows of the staged K / Q / dt chunk of head hh
     {
       const int t = stlo + rowtok(lane);
       const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
@@ -126,26 +129,23 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const float e31 = wave_read_lane(cs, 31), e63 = wave_read_lane(cs, 63);
     const float csb = lane < 32 ? 0.f : e31;    // prefix in front of the lane's sub-chunk
     const float cse = lane < 32 ? e31 : e63;    // prefix at its end
-    sm.cs[pb][hh][lane] = cs;
-    sm.lw[pb][hh][lane] = log2_fast(rwv) - cs;
-    sm.rl[kb][hh][lane] = exp2_fast(cs - csb);
+    sm.rv[kb][hh][lane] = f32x2{cs, exp2_fast(cs - csb)};
+    sm.lw[kb][hh][lane] = log2_fast(rwv) - cs;
     sm.ws[kb][hh][lane] = rwv * exp2_fast(cse - cs);
     if (MODE == GS_DX) sm.dtl[kb][hh][lane] = rdt;
     if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = exp2_fast(cse - csb);
   };
 
   // ---- lane-constant LDS element offsets
-  int o_rd[4], o_kt[4];
+  int o_rd[4], o_kt[4], o_kr[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    o_rd[i] = kx3(t16, 32 * i + 8 * g16);                               // 16-byte row reads of Q / K: row t16, k = 32 i + 8 g16 .. + 7
-    o_kt[i] = kx3(4 * g16 + (t16 >> 2), 32 * i + 8 * (t16 & 3));        // K^T transpose reads: rows 4 g16 + 0..3, k = 32 i + 8 q (+ 4 for odd tiles)
+    o_rd[i] = kx3(t16, 32 * i + 8 * g16);                               // 16-byte row reads of Q: row t16, k = 32 i + 8 g16 ..
+    o_kt[i] = kxh(4 * g16 + (t16 >> 2), 32 * i + 8 * (t16 & 3));        // K^T transpose reads: rows 4 g16 + 0..3, k = 32 i + 8 q (+ 4 for odd tiles: ^ 4)
+    o_kr[i] = kxh(t16, 32 * i + 8 * g16);                               // 8-byte row reads of K (tile build): row t16, k = 32 i + 8 g16 .. + 3 (next four: ^ 4)
   }
   const int o_uf = ux3(4 * g16 + (t16 >> 2), 16 * w + 4 * (t16 & 3));   // U transpose read: rows 4 g16 + 0..3, columns 16 w + 0..15
   const int o_xu = ux3(t16, 16 * w + 4 * g16);                          // x of the lane's output row, columns 16 w + 4 g16 ..
-  auto rowfrag = [&](const uint16_t* tile, int row0, int i) -> u32x4 {  // tile[row0 + t16][32 i + 8 g16 .. + 7]
-    return ld16(&tile[o_rd[i] + 128 * row0]);
-  };
 
   // ---- running state: eight 16 x 16 tiles, see the header for the (tile, register) <-> k map
   f32x4 accS[8];
@@ -179,9 +179,14 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 4; r++) Du[r] = load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)(16 * w + 4 * g16 + r) * a.Dsp, a.D_dt);
   }
 
-  // ---- M tiles of one chunk (buffers kb: K / Q, pb: cs / lw, mb: tiles).  Wave roles: w = 0 none (it computes the token scalars),
-  // w = 3 the tiles (0, 0) of both sub-chunks, w = 1 / 2 the tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s,
-  // B = Q rows l; the lane holds s = 4 g16 + r of its own l = t16.
+  // ---- M tiles of one chunk (buffers kb: K / Q / scalars, mb: tiles).  Wave roles: w = 0 none (it computes the token scalars),
+  // w = 3 the tiles (0, 0) of both sub-chunks, w = 1 / 2 the tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds
+  // s = 4 g16 + r of its own l = t16.
+  auto krow = [&](int kb, int row0, int i) -> u32x4 {   // K[row0 + t16][32 i + 8 g16 .. + 7] out of the half-swapped tile
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(&sm.K[kb][o_kr[i] + 128 * row0]);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(&sm.K[kb][(o_kr[i] ^ 4) + 128 * row0]);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
   auto decay_tile = [&](const f32x4& gt, float cs_l, const f32x4& lw4, bool diag, uint32_t (&hi)[2], uint32_t (&lo)[2]) {
     float v[4];
 #pragma unroll
@@ -198,34 +203,34 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       lo[p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi[p2]), v[2 * p2 + 1] - bf_hi(hi[p2]));
     }
   };
-  auto build_tiles = [&](int kb, int pb, int mb) {
-    if (w == 0) return;
+  auto build_tiles = [&](int kb, int mb) {
+    if (w == 0) return;   // (the wave that computes the token scalars)
     if (w == 3) {
 #pragma unroll
-      for (int jj = 0; jj < 2; jj++) {
-        const int r0 = 32 * jj;
-        f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+     for (int jj = 0; jj < 2; jj++) {
+      const int r0 = 32 * jj;
+      f32x4 gt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(rowfrag(sm.K[kb], r0, i)), as_s16x8(rowfrag(sm.Q[kb], r0, i)), gt);
-        const float cs_l = sm.cs[pb][hh][r0 + t16];
-        const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[pb][hh][r0 + 4 * g16]);
-        uint32_t hi[2], lo[2];
-        decay_tile(gt, cs_l, lw4, true, hi, lo);
-        sm.M[mb][hh][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
-      }
+      for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(krow(kb, r0, i)), as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * r0])), gt);
+      const float cs_l = sm.rv[kb][hh][r0 + t16][0];
+      const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 4 * g16]);
+      uint32_t hi[2], lo[2];
+      decay_tile(gt, cs_l, lw4, true, hi, lo);
+      sm.M[mb][hh][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+     }
     } else {
       const int jj = w - 1;
       const int r0 = 32 * jj;
       f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const s16x8 qf = as_s16x8(rowfrag(sm.Q[kb], r0 + 16, i));
-        g0 = mfma16x16x32_bf16(as_s16x8(rowfrag(sm.K[kb], r0, i)), qf, g0);
-        g1 = mfma16x16x32_bf16(as_s16x8(rowfrag(sm.K[kb], r0 + 16, i)), qf, g1);
+        const s16x8 qf = as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * (r0 + 16)]));
+        g0 = mfma16x16x32_bf16(as_s16x8(krow(kb, r0, i)), qf, g0);
+        g1 = mfma16x16x32_bf16(as_s16x8(krow(kb, r0 + 16, i)), qf, g1);
       }
-      const float cs_l = sm.cs[pb][hh][r0 + 16 + t16];
-      const f32x4 lw0 = *reinterpret_cast<const f32x4*>(&sm.lw[pb][hh][r0 + 4 * g16]);
-      const f32x4 lw1 = *reinterpret_cast<const f32x4*>(&sm.lw[pb][hh][r0 + 16 + 4 * g16]);
+      const float cs_l = sm.rv[kb][hh][r0 + 16 + t16][0];
+      const f32x4 lw0 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 4 * g16]);
+      const f32x4 lw1 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 16 + 4 * g16]);
       uint32_t h0[2], l0[2], h1[2], l1[2];
       decay_tile(g0, cs_l, lw0, false, h0, l0);
       decay_tile(g1, cs_l, lw1, true, h1, l1);
@@ -234,33 +239,20 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     }
   };
 
-  // ---- prologue: the LDS tiles start from zeros (a short sequence leaves rows the DMA never touches), chunks c0 and c0 + 1 are
-  // staged with their scalars, the tiles of c0 built, and the requests of the first iteration are in flight
-  {
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    u32x4* base = reinterpret_cast<u32x4*>(smem_raw);
-    constexpr int nz = (int)((sizeof(sm.K) + sizeof(sm.Q) + sizeof(sm.U)) / 16);
-    for (int i = tid; i < nz; i += 512) base[i] = z4;
-  }
+  // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built
+  prefetch_kq(chunk_lo(c0));
+  prefetch_u(chunk_lo(c0));
+  commit_kq(0);
+  commit_u(0);
+  if (w == 0) scalars(0);
+  prefetch_kq(chunk_lo(clipc(c0 + 1)));
+  commit_kq(1);
+  if (w == 0) scalars(1);
   block_sync();
-  dma_kq(0, chunk_lo(c0));
-  dma_u(0, chunk_lo(c0));
-  if (w == 0) dma_dt(chunk_lo(c0));
-  OMK_VMCNT(0);
-  block_sync_lds();
-  if (w == 0) scalars(0, 0);
-  dma_kq(1, chunk_lo(clipc(c0 + 1)));
-  block_sync_lds();              // (the scalars wave has read sm.dtr)
-  if (w == 0) dma_dt(chunk_lo(clipc(c0 + 1)));
-  OMK_VMCNT(0);
-  block_sync_lds();
-  if (w == 0) scalars(1, 1);
-  build_tiles(0, 0, 0);
-  block_sync_lds();
-  // in flight when the loop starts: dt' of chunk c0 + 2 (first), K / Q of c0 + 2, U of c0 + 1
-  if (w == 0) dma_dt(chunk_lo(clipc(c0 + 2)));
-  dma_kq(2, chunk_lo(clipc(c0 + 2)));
-  dma_u(1, chunk_lo(clipc(c0 + 1)));
+  build_tiles(0, 0);
+  prefetch_kq(chunk_lo(clipc(c0 + 2)));
+  prefetch_u(chunk_lo(clipc(c0 + 1)));
+  block_sync();
   uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
   const BufRes Or = make_buf(ob, (uint32_t)((int64_t)a.L * osl * 2));
   uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
@@ -272,17 +264,17 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   // and the token scalars.  The operands of phase 2 are requested in front of phase 1 of the same sub-chunk, the row fragments of the
   // next sub-chunk in front of phase 2, so every LDS read has a phase of work between request and use.
   struct FragR { u32x4 q0[4], q1[4]; };
-  struct FragC { s16x4 u0, u1, kt[8][2]; f32x4 ws0, ws1; float rl0, rl1, dec, dts0, dts1; u32x4 m0, mh, ml; u32x2 x0, x1; };
+  struct FragC { s16x4 u0, u1, kt[8][2]; f32x2 rv0, rv1; f32x4 ws0, ws1; float dec, dts0, dts1; u32x4 m0, mh, ml; u32x2 x0, x1; };
   auto load_rows = [&](FragR& f, int kb, int jj) {
     if (OMK_A6_ABL & 1) { asm volatile("" : "+v"(f.q0[0]), "+v"(f.q0[1]), "+v"(f.q0[2]), "+v"(f.q0[3]), "+v"(f.q1[0]), "+v"(f.q1[1]), "+v"(f.q1[2]), "+v"(f.q1[3])); return; }
 #pragma unroll
-    for (int i = 0; i < 4; i++) f.q0[i] = rowfrag(sm.Q[kb], 32 * jj, i);
+    for (int i = 0; i < 4; i++) f.q0[i] = ld16(&sm.Q[kb][o_rd[i] + 128 * (32 * jj)]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) f.q1[i] = rowfrag(sm.Q[kb], 32 * jj + 16, i);
+    for (int i = 0; i < 4; i++) f.q1[i] = ld16(&sm.Q[kb][o_rd[i] + 128 * (32 * jj + 16)]);
   };
   auto load_cols = [&](FragC& f, int kb, int ub, int jj) {
     if (OMK_A6_ABL & 1) {
-      asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.rl0), "+v"(f.rl1), "+v"(f.ws0), "+v"(f.ws1), "+v"(f.dec), "+v"(f.m0), "+v"(f.mh), "+v"(f.ml));
+      asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.rv0), "+v"(f.rv1), "+v"(f.ws0), "+v"(f.ws1), "+v"(f.dec), "+v"(f.m0), "+v"(f.mh), "+v"(f.ml));
 #pragma unroll
       for (int t = 0; t < 8; t++) asm volatile("" : "+v"(f.kt[t][0]), "+v"(f.kt[t][1]));
       return;
@@ -295,14 +287,14 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     f.dec = sm.dec[kb][hh][jj];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * r0]);
-      f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * (r0 + 16)]);
+      f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * r0]);
+      f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * (r0 + 16)]);
     }
     f.m0 = sm.M[ub][hh][3 * jj][lane];
     f.mh = sm.M[ub][hh][3 * jj + 1][lane];
     f.ml = sm.M[ub][hh][3 * jj + 2][lane];
-    f.rl0 = sm.rl[kb][hh][r0 + t16];
-    f.rl1 = sm.rl[kb][hh][r0 + 16 + t16];
+    f.rv0 = sm.rv[kb][hh][r0 + t16];
+    f.rv1 = sm.rv[kb][hh][r0 + 16 + t16];
     if (!DFOLD) {
       f.x0 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * r0]);
       f.x1 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * (r0 + 16)]);
@@ -319,7 +311,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       sp[1] = pack_bf16x2(accS[2 * i][2], accS[2 * i][3]);
       sp[2] = pack_bf16x2(accS[2 * i + 1][0], accS[2 * i + 1][1]);
       sp[3] = pack_bf16x2(accS[2 * i + 1][2], accS[2 * i + 1][3]);
-      if (DUMP && dump_here) st16(dp + kx3(su, 32 * i + 8 * g16), sp);   // [u][k] image, kx3 swizzle: k = 32 i + 8 g16 .. + 7
+      if (DUMP && dump_here) st16(dp + su * 128 + (((4 * i + g16) ^ swzK(su)) << 3), sp);
       accA0 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0);
       accA1 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1);
     }
@@ -377,8 +369,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const f32x4 accB0 = mfma16x16x32_bf16(u00, as_s16x8(f.m0), f32x4{0.f, 0.f, 0.f, 0.f});
     f32x4 accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.mh), f32x4{0.f, 0.f, 0.f, 0.f});
     accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.ml), accB1);
-    out_rows(accA0 * f.rl0 + accB0, 32 * jj + t16, tlo, MODE == GS_DX ? f.dts0 : 1.f, f.x0);
-    out_rows(accA1 * f.rl1 + accB1, 32 * jj + 16 + t16, tlo, MODE == GS_DX ? f.dts1 : 1.f, f.x1);
+    out_rows(accA0 * f.rv0[1] + accB0, 32 * jj + t16, tlo, MODE == GS_DX ? f.dts0 : 1.f, f.x0);
+    out_rows(accA1 * f.rv1[1] + accB1, 32 * jj + 16 + t16, tlo, MODE == GS_DX ? f.dts1 : 1.f, f.x1);
   };
 
   FragR fr;
@@ -404,34 +396,29 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     phase2(fc, 0, tlo);
     OMK_SCHED_FENCE();
-    // ---- the tiles of the next chunk (waves 1 - 3) / the scalars of chunk c + 2 (wave 0; its dt' requests are the oldest of this
-    // wave's requests in flight: behind them at least the six tile requests and the two stores of sub-chunk 0)
-    if (c + 1 < c1) build_tiles(kb1, ub1, ub1);
-    if (w == 0) {
-      OMK_VMCNT(8);
-      scalars(kb2, ub0);
-    }
+    // ---- the tiles of the next chunk, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U)
+    if (c + 1 < c1) build_tiles(kb1, ub1);
+    if (!(OMK_A6_ABL & 2)) { commit_kq(kb2); commit_u(ub1); }
+    if (w == 0) scalars(kb2);
+#ifndef OMK_A6_LATEPF
+    if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }   // a whole iteration ahead of their commit
+#endif
     OMK_SCHED_FENCE();
     // ---- sub-chunk 1; the barrier of the chunk behind its last request for the current buffers
     load_cols(fc, kb0, ub0, 1);
     OMK_SCHED_FENCE();
     phase1(fr, false, dp);
     OMK_SCHED_FENCE();
-    // this wave's tile requests (issued behind the last barrier) have landed: at least the two stores of sub-chunk 0 are younger
-    OMK_VMCNT(2);
-    if (!(OMK_A6_ABL & 8)) block_sync_lds();
+    if (!(OMK_A6_ABL & 8)) block_sync();
     load_rows(fr, kb1, 0);
-    if (!(OMK_A6_ABL & 4)) {   // chunk c + 3 (K / Q / dt') and c + 2 (U) into the buffers this barrier has released
-      if (w == 0) dma_dt(chunk_lo(clipc(c + 3)));
-      dma_kq(kb0, chunk_lo(clipc(c + 3)));
-      dma_u(ub0, chunk_lo(clipc(c + 2)));
-    }
+#ifdef OMK_A6_LATEPF
+    if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }
+#endif
     OMK_SCHED_FENCE();
     phase2(fc, 1, tlo);
     OMK_SCHED_FENCE();
     { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
   }
-  OMK_VMCNT(0);   // (requests for chunks behind the end are still on their way to this workgroup's LDS)
   if (a.fin && seg == a.nseg - 1) {
     const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
 #pragma unroll
