@@ -598,6 +598,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   // (tried in round 2: the scan reading the raw (B, L, H) dt itself and applying bias / softplus / clamp in its scalar pass, to
   // save this 16 us launch -- 280 us against 236 + 16 us: the 2-byte loads at stride H are 64 requests per wave and chunk and the
   // softplus lands on wave 0's critical path between the publish and the barrier.  Not kept.)
+  launch_dt_prep(p->dt, p->dt_bias, d, dtp, nullptr, p->dt_softplus, p->dt_min, p->dt_max, stream);
   g.mode = GS_Y; g.U = make_src(p->x, false); g.K = make_src(p->Bm, true); g.Q = make_src(p->Cm, true);
   if (present(p->z)) g.Z = make_src(p->z, false);
   g.dtp = dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L; g.DU = d.P; g.DK = d.N; g.reverse = 0; g.w_is_dt = 1;
@@ -616,22 +617,6 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
 #endif
   if (ssd_seg_bytes(d.B * d.H, d.L) && !getenv("OMK_SSD_NO_SPLIT")) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
-  // round 4: the column-slice scan (ssd_a6.hip) prepares dt' in its own scalar pass (its scalar wave has no tile to build), which
-  // saves the preparation launch (12 - 28 us) and its 12 MB of traffic.  The other kernels read the prepared (B, H, L) array.
-  bool scan_prepares_dt = false;
-  if (!state_only && !p->force_generic && p->dt.dtype == OMK_BF16 && p->dt.stride[2] == 1 && present(p->out)) {
-    GScan gq = g;
-    gq.out = p->out.data; gq.osb = p->out.stride[0]; gq.osl = p->out.stride[1]; gq.osh = p->out.stride[2]; gq.out_dt = p->out.dtype;
-    gq.dtraw = (const uint16_t*)p->dt.data; gq.drsb = p->dt.stride[0]; gq.drsl = p->dt.stride[1];
-    if (ssd_mfma_launch(gq, nullptr, 1) == OMK_OK && !ssd_v6_applies(gq) && ssd_a6_prepares_dt(gq)) {
-      scan_prepares_dt = true;
-      g.dtraw = gq.dtraw; g.drsb = gq.drsb; g.drsl = gq.drsl;
-      g.dtbias = present(p->dt_bias) ? p->dt_bias.data : nullptr; g.dtbias_dt = p->dt_bias.dtype;
-      g.dt_softplus = p->dt_softplus; g.dt_lo = p->dt_min; g.dt_hi = p->dt_max;
-      g.dtp = nullptr;
-    }
-  }
-  if (!scan_prepares_dt) launch_dt_prep(p->dt, p->dt_bias, d, dtp, nullptr, p->dt_softplus, p->dt_min, p->dt_max, stream);
   if (state_only) {
     rc = (p->force_generic || p->x.dtype != OMK_BF16) ? OMK_EUNSUPPORTED : ssd_mfma_state_only(g, stream);
     if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the state-only pass exists for the MFMA shape only (bf16, headdim 64, d_state 128); run the scan and drop its output");

@@ -48,8 +48,7 @@ static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
 // K tile element offset: kx3 with the 8-byte halves of a segment swapped in rows with bit 2 set
 __device__ __forceinline__ int kxh(int row, int col) { return kx3(row, col) ^ (((row >> 2) & 1) << 2); }
 
-// FDT (forward): the scalar pass prepares dt' = clamp(softplus(dt + bias)) from the raw (B, L, H) dt itself -- no preparation launch
-template <int MODE, bool EXTRAS, bool DFOLD, bool DUMP, bool KHILO, bool FDT = false>
+template <int MODE, bool EXTRAS, bool DFOLD, bool DUMP, bool KHILO>
 __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA6& sm = *reinterpret_cast<SmemA6*>(smem_raw);
@@ -75,17 +74,13 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
   const uint16_t* Qb = (const uint16_t*)a.Q.p + (int64_t)b * a.Q.sb + (int64_t)g * a.Q.sh;
   const uint16_t* Ub = (const uint16_t*)a.U.p + (int64_t)b * a.U.sb + (int64_t)h * a.U.sh;
-  const float* dtrow = FDT ? nullptr : a.dtp + ((int64_t)b * a.H + h) * a.L;
-  const uint16_t* dtraw = FDT ? a.dtraw + (int64_t)b * a.drsb + h : nullptr;
-  const int drsl = (int)a.drsl;
+  const float* dtrow = a.dtp + ((int64_t)b * a.H + h) * a.L;
   const int ksl = (int)a.K.sl, qsl = (int)a.Q.sl, usl = (int)a.U.sl, osl = (int)a.osl;
   const BufRes Kr = make_buf(Kb, (uint32_t)((int64_t)a.L * ksl * 2)), Qr = make_buf(Qb, (uint32_t)((int64_t)a.L * qsl * 2));
-  const BufRes Ur = make_buf(Ub, (uint32_t)((int64_t)a.L * usl * 2));
-  const BufRes Dr = FDT ? make_buf(dtraw, (uint32_t)(((int64_t)a.L - 1) * drsl * 2 + 2)) : make_buf(dtrow, (uint32_t)((int64_t)a.L * 4));
+  const BufRes Ur = make_buf(Ub, (uint32_t)((int64_t)a.L * usl * 2)), Dr = make_buf(dtrow, (uint32_t)((int64_t)a.L * 4));
   const uint32_t kvo = 2u * (uint32_t)((rev ? 31 - rowk : rowk) * ksl + ck8), qvo = 2u * (uint32_t)((rev ? 31 - rowk : rowk) * qsl + ck8);
   const uint32_t uvo = 2u * (uint32_t)((rev ? 31 - rowu : rowu) * usl + cu8);
-  const uint32_t dvo = FDT ? 2u * (uint32_t)(rowtok(lane) * drsl) : 4u * (uint32_t)rowtok(lane), dvo_a = 4u * (uint32_t)(rowtok(lane) + (rev ? 1 : 0));
-  const float dt_bias_h = (FDT && a.dtbias) ? load_rt(a.dtbias, h, a.dtbias_dt) : 0.f;
+  const uint32_t dvo = 4u * (uint32_t)rowtok(lane), dvo_a = 4u * (uint32_t)(rowtok(lane) + (rev ? 1 : 0));
   u32x4 rk[2], rq[2], ru[2];
   float rdt = 0.f, rda = 0.f, rwv = 0.f;
   int stlo = 0;   // first token of the K / Q / dt chunk in the staging registers
@@ -98,11 +93,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       rk[r] = buf_ld16(Kr, kvo, sk + 2u * (uint32_t)(ro * ksl));
       rq[r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)(ro * qsl));
     }
-    if (FDT) rdt = __builtin_bit_cast(float, (uint32_t)buf_ld_u16(Dr, dvo, 2u * (uint32_t)(tl * drsl)) << 16);   // raw bf16 dt of the row's token
-    else {
-      rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
-      rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
-    }
+    rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
+    rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
   };
   auto prefetch_u = [&](int tl) {
     const uint32_t su = 2u * (uint32_t)(tl * usl);
@@ -126,16 +118,6 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   const float Ah = a.A[h];
   const float Ah2 = Ah * LOG2E;
   auto scalars = [&](int kb) {   // waves with w == 0; lanes = rows of the staged K / Q / dt chunk of head hh
-    if (FDT) {   // the arithmetic of ssd_dt_prep_vec_kernel (ssd.hip)
-      float v = rdt + dt_bias_h;
-      if (a.dt_softplus && v <= 20.f) {
-        const float ex = exp2_fast(v * LOG2E), u = 1.f + ex;
-        v = u == 1.f ? ex : log2_fast(u) * 0.6931471805599453f * ex * rcp_fast(u - 1.f);
-      }
-      v = v < a.dt_lo ? a.dt_lo : v;
-      v = v > a.dt_hi ? a.dt_hi : v;
-      rdt = v; rda = v;
-    }
     {
       const int t = stlo + rowtok(lane);
       const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
@@ -449,15 +431,6 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   }
 }
 
-bool ssd_a6_applies(const GScan& g);
-// would the forward scan prepare dt' itself (so that the caller can skip the preparation launch)?
-bool ssd_a6_prepares_dt(const GScan& g) {
-  if (!ssd_a6_applies(g) || g.mode != GS_Y || g.reverse || !g.dtraw) return false;
-  if (getenv("OMK_SSD_A6_FDT") && getenv("OMK_SSD_A6_FDT")[0] == '0') return false;
-  const SegPlan sp = g.seg ? ssd_segments(g.B * g.H, g.L) : SegPlan{1, 0};
-  return sp.nseg == 1;
-}
-
 bool ssd_a6_applies(const GScan& g) {
   if (const char* e = getenv("OMK_SSD_A6")) { if (e[0] == '0') return false; }
   else return false;   // opt-in until measured
@@ -485,14 +458,7 @@ int ssd_a6_launch(const GScan& g, omk_stream stream) {
 #define OMK_A6K(MODE_, EX_, DF_, DU_, KH_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), grid, block, smem, stream, a); } while (0)
-#define OMK_A6F(MODE_, EX_, DF_, DU_, KH_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_, true>), grid, block, smem, stream, a); } while (0)
-  const bool fdt = a.nseg == 1 && ssd_a6_prepares_dt(g) && !a.dtp;
-  if (!fdt && !a.dtp) return fail(OMK_EINVAL, "ssd_a6: no prepared dt'");
-#define OMK_A6(MODE_, EX_, DF_, DU_) do { \
-    if (MODE_ == GS_Y && fdt) { if (khilo) OMK_A6F(GS_Y, EX_, DF_, DU_, true); else OMK_A6F(GS_Y, EX_, DF_, DU_, false); } \
-    else if (khilo && MODE_ == GS_Y) OMK_A6K(MODE_, EX_, DF_, DU_, (MODE_ == GS_Y)); else OMK_A6K(MODE_, EX_, DF_, DU_, false); } while (0)
+#define OMK_A6(MODE_, EX_, DF_, DU_) do { if (khilo && MODE_ == GS_Y) OMK_A6K(MODE_, EX_, DF_, DU_, (MODE_ == GS_Y)); else OMK_A6K(MODE_, EX_, DF_, DU_, false); } while (0)
   const bool dfold = !a.D || a.Dsp == 0;   // one D per head (or none)
   if (a.mode == GS_Y) {
     const bool ex = a.Z.p || a.outx;
@@ -504,7 +470,6 @@ int ssd_a6_launch(const GScan& g, omk_stream stream) {
   }
 #undef OMK_A6
 #undef OMK_A6K
-#undef OMK_A6F
   return OMK_OK;
 }
 

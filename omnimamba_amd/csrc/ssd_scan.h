@@ -28,9 +28,6 @@ struct GScan {
   int mode;
   Src U, K, Q, X4, Z;   // X4: group vector of length DU for the token-scalar epilogue (C in dC, B in dB); Z: gate (Y)
   const float* dtp;     // (B, H, L) processed dt' (bias + softplus + clamp applied)
-  // forward only, optional: the raw dt (b, t, h) at dtraw[b*drsb + t*drsl + h] (bf16) with its bias / softplus / clamp, for a scan
-  // kernel that prepares dt' itself (ssd_a6.hip); dtp may then be null
-  const uint16_t* dtraw; int64_t drsb, drsl; const void* dtbias; int dtbias_dt; int dt_softplus; float dt_lo, dt_hi;
   const float* A;       // (H)
   int B, H, G, L, DU, DK;
   int reverse, w_is_dt;
@@ -113,7 +110,6 @@ int ssd_a5_launch(const GScan& g, omk_stream stream);
 // the same with 32-token sub-chunks and the intra tiles shared through LDS (ssd_a6.hip)
 bool ssd_a6_applies(const GScan& g);
 int ssd_a6_launch(const GScan& g, omk_stream stream);
-bool ssd_a6_prepares_dt(const GScan& g);   // g.dtraw set and the launch would take the dt'-preparing instantiation: g.dtp may be null
 // state-only pass over the whole sequence that leaves the window-boundary states in g.dump (class A descriptor, no output)
 int ssd_mfma_state_dump(const GScan& g, omk_stream stream);
 // state-only pass that leaves the state behind the sequence in g.fin (OMK_EUNSUPPORTED outside the MFMA shape)
