@@ -48,7 +48,9 @@ static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
 // K tile element offset: kx3 with the 8-byte halves of a segment swapped in rows with bit 2 set
 __device__ __forceinline__ int kxh(int row, int col) { return kx3(row, col) ^ (((row >> 2) & 1) << 2); }
 
-template <int MODE, bool EXTRAS, bool DFOLD, bool DUMP, bool KHILO>
+// STATE: the state-only pass (no output, no S_in^T Q^T, no intra block): window-boundary images (GScan::dump) and / or the state behind
+// the sequence, with exactly the arithmetic the scan proper carries its state with
+template <int MODE, bool EXTRAS, bool DFOLD, bool DUMP, bool KHILO, bool STATE = false>
 __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA6& sm = *reinterpret_cast<SmemA6*>(smem_raw);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 2; r++) {
       const int ro = rev ? 32 * (1 - r) : 32 * r;
       rk[r] = buf_ld16(Kr, kvo, sk + 2u * (uint32_t)(ro * ksl));
-      rq[r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)(ro * qsl));
+      if (!STATE) rq[r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)(ro * qsl));
     }
     rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
     rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 2; r++) {
       *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk]) = u32x2{rk[r][0], rk[r][1]};
       *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk ^ 4]) = u32x2{rk[r][2], rk[r][3]};
-      st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
+      if (!STATE) st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
     }
   };
   auto commit_u = [&](int ub) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     }
   };
   auto build_tiles = [&](int kb, int mb) {
-    if (w == 0) return;   // (the wave that computes the token scalars)
+    if (STATE || w == 0) return;   // (the wave that computes the token scalars)
     if (w == 3) {
 #pragma unroll
      for (int jj = 0; jj < 2; jj++) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   prefetch_u(chunk_lo(clipc(c0 + 1)));
   block_sync();
   uint16_t* ob = (uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)h * a.osh;
-  const BufRes Or = make_buf(ob, (uint32_t)((int64_t)a.L * osl * 2));
+  const BufRes Or = make_buf(STATE ? nullptr : ob, STATE ? 0u : (uint32_t)((int64_t)a.L * osl * 2));
   uint16_t* oxb = a.outx ? (uint16_t*)a.outx + (int64_t)b * a.osb + (int64_t)h * a.osh : nullptr;
   const uint16_t* zb = (MODE == GS_Y && a.Z.p) ? (const uint16_t*)a.Z.p + (int64_t)b * a.Z.sb + (int64_t)h * a.Z.sh : nullptr;
   const int zsl = (int)a.Z.sl;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   struct FragR { u32x4 q0[4], q1[4]; };
   struct FragC { s16x4 u0, u1, kt[8][2]; f32x2 rv0, rv1; f32x4 ws0, ws1; float dec, dts0, dts1; u32x4 m0, mh, ml; u32x2 x0, x1; };
   auto load_rows = [&](FragR& f, int kb, int jj) {
+    if (STATE) return;
     if (OMK_A6_ABL & 1) { asm volatile("" : "+v"(f.q0[0]), "+v"(f.q0[1]), "+v"(f.q0[2]), "+v"(f.q0[3]), "+v"(f.q1[0]), "+v"(f.q1[1]), "+v"(f.q1[2]), "+v"(f.q1[3])); return; }
 #pragma unroll
     for (int i = 0; i < 4; i++) f.q0[i] = ld16(&sm.Q[kb][o_rd[i] + 128 * (32 * jj)]);
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * r0]);
       f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * (r0 + 16)]);
     }
+    if (STATE) return;
     f.m0 = sm.M[ub][hh][3 * jj][lane];
     f.mh = sm.M[ub][hh][3 * jj + 1][lane];
     f.ml = sm.M[ub][hh][3 * jj + 2][lane];
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   };
   f32x4 accA0, accA1;
   auto phase1 = [&](const FragR& f, bool dump_here, uint16_t* dp) {
+    if (STATE && !(DUMP && dump_here)) return;
     accA0 = f32x4{0.f, 0.f, 0.f, 0.f}; accA1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -312,8 +317,10 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       sp[2] = pack_bf16x2(accS[2 * i + 1][0], accS[2 * i + 1][1]);
       sp[3] = pack_bf16x2(accS[2 * i + 1][2], accS[2 * i + 1][3]);
       if (DUMP && dump_here) st16(dp + su * 128 + (((4 * i + g16) ^ swzK(su)) << 3), sp);
-      accA0 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0);
-      accA1 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1);
+      if (!STATE) {
+        accA0 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0);
+        accA1 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1);
+      }
     }
   };
   auto out_rows = [&](f32x4 o, int row, int tlo, float dts, u32x2 xr) {   // the lane's row, columns 16 w + 4 g16 + r
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
         if (KHILO) accS[t] = mfma16x16x32_bf16(kk, as_s16x8(ul), accS[t]);
       }
     }
+    if (STATE) return;
     // ---- U^T M^T: strip 0 against tile (0, 0) (hi | lo in the two halves of the contraction, U twice); strip 1 against (1, 0) | (1, 1)
     s16x8 u00, u01;
     u00[0] = f.u0[0]; u00[1] = f.u0[1]; u00[2] = f.u0[2]; u00[3] = f.u0[3]; u00[4] = f.u0[0]; u00[5] = f.u0[1]; u00[6] = f.u0[2]; u00[7] = f.u0[3];
@@ -431,13 +439,48 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   }
 }
 
+// The column-slice kernel takes the class A scans of head PAIRS that share a group (OMK_SSD_A6=0: the row-strip kernel), split
+// sequences included (the zero-start state pass + fold of ssd_mfma_prepare_segments provides the segment start states).
 bool ssd_a6_applies(const GScan& g) {
-  if (const char* e = getenv("OMK_SSD_A6")) { if (e[0] == '0') return false; }
-  else return false;   // opt-in until measured
+  if (const char* e = getenv("OMK_SSD_A6")) if (e[0] == '0') return false;
   if (g.mode != GS_Y && g.mode != GS_DX) return false;
   if (g.H % 2 != 0 || (g.H / g.G) % 2 != 0) return false;
   if (g.state_only) return false;
   return true;
+}
+
+// state-only pass that leaves the state behind the sequence in g.fin (context-parallel shards): the scan proper with final states
+// carries exactly this state (hi + lo operand)
+int ssd_a6_state_only(const GScan& g, omk_stream stream) {
+  GScan q = g; q.state_only = 0;
+  if (!g.fin || g.mode != GS_Y || !ssd_a6_applies(q)) return OMK_EUNSUPPORTED;
+  GScan a = q;
+  a.out = nullptr; a.outx = nullptr; a.Z = Src{}; a.D = nullptr; a.dump = nullptr;
+  const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QA6 - 1) / QA6};
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  if (a.nseg > 1 && !a.seg_ready) {
+    int rc = ssd_mfma_prepare_segments(a, stream);
+    if (rc) return rc;
+  }
+  dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
+  const size_t smem = sizeof(SmemA6);
+  if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<GS_Y, false, true, false, true, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem);
+  OMK_LAUNCH((ssd_a6_kernel<GS_Y, false, true, false, true, true>), grid, block, smem, stream, a);
+  return OMK_OK;
+}
+
+// state-only pass over the whole sequence that leaves the window-boundary images in g.dump (no output): the recomputing backward
+int ssd_a6_state_dump(const GScan& g, omk_stream stream) {
+  if (!g.dump || !ssd_a6_applies(g) || g.mode != GS_Y) return OMK_EUNSUPPORTED;
+  GScan a = g;
+  a.out = nullptr; a.outx = nullptr; a.Z = Src{}; a.D = nullptr; a.fin = nullptr;
+  const SegPlan sp = (a.seg && a.seg_ready) ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QA6 - 1) / QA6};   // start states already folded
+  a.nseg = sp.nseg; a.cps = sp.cps;
+  dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
+  const size_t smem = sizeof(SmemA6);
+  if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<GS_Y, false, true, true, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem);
+  OMK_LAUNCH((ssd_a6_kernel<GS_Y, false, true, true, false, true>), grid, block, smem, stream, a);
+  return OMK_OK;
 }
 
 // called by ssd_mfma_launch after its shape / alignment checks (same preconditions as the row-strip kernel)

@@ -988,6 +988,10 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
 
 int ssd_mfma_state_dump(const GScan& g, omk_stream stream) {
   if (!g.dump || g.DU != 64 || g.DK != 128) return OMK_EUNSUPPORTED;
+  {   // the scan proper dumps with the same kernel: identical images
+    const int rc = ssd_a6_state_dump(g, stream);
+    if (rc != OMK_EUNSUPPORTED) return rc;
+  }
   GScan a = g;
   const SegPlan sp = (a.seg && a.seg_ready) ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};
   a.nseg = sp.nseg; a.cps = sp.cps;
@@ -1004,6 +1008,11 @@ int ssd_mfma_state_only(const GScan& g, omk_stream stream) {
   {
     const int64_t ms = g.K.sl > g.U.sl ? g.K.sl : g.U.sl;
     if ((int64_t)g.L * ms * 2 >= (int64_t)0xfffff000) return OMK_EUNSUPPORTED;
+  }
+  {   // the column-slice kernel's state pass: the state a scan with final states carries
+    GScan q = g; q.Q = q.K;
+    const int rc = ssd_a6_state_only(q, stream);
+    if (rc != OMK_EUNSUPPORTED) return rc;
   }
   GScan a = g;
   a.Q = a.K;   // never read by the state pass; keeps the buffer descriptors well formed

@@ -110,6 +110,8 @@ int ssd_a5_launch(const GScan& g, omk_stream stream);
 // the same with 32-token sub-chunks and the intra tiles shared through LDS (ssd_a6.hip)
 bool ssd_a6_applies(const GScan& g);
 int ssd_a6_launch(const GScan& g, omk_stream stream);
+int ssd_a6_state_only(const GScan& g, omk_stream stream);
+int ssd_a6_state_dump(const GScan& g, omk_stream stream);   // OMK_EUNSUPPORTED when the column-slice kernel does not take the shape
 // state-only pass over the whole sequence that leaves the window-boundary states in g.dump (class A descriptor, no output)
 int ssd_mfma_state_dump(const GScan& g, omk_stream stream);
 // state-only pass that leaves the state behind the sequence in g.fin (OMK_EUNSUPPORTED outside the MFMA shape)

@@ -309,4 +309,8 @@ def test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states(dev, monke
         e = rel(out.float(), o32)
         res[mode] = (max(e * e - q * q, 0.0) ** 0.5, rel(fin, f0))       # arithmetic part of the error of y, error of the final state
     assert res["1"][0] < 1e-3 and res["1"][1] < 1e-3, res
-    assert res["1"][1] < 0.6 * res["0"][1], res                           # and it is the precise path that does it
+    # round 4: the default kernel (ssd_a6.hip) carries its state in fp32 accumulators and enters the scaled operand of the state update
+    # as hi + lo whenever the final state is kept, so the default final state is already exact to 1e-5; what the precise path still
+    # buys is the bf16 rounding of the state copy that feeds y
+    assert res["0"][1] < 1e-3, res
+    assert res["1"][0] < 0.6 * res["0"][0], res
