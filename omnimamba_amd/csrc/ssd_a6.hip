@@ -40,7 +40,7 @@ struct SmemA6 {
   u32x4 M[2][2][6][64];           // [buffer][head][record][lane]: per sub-chunk jj: 3 jj + 0 = {hi, lo} of tile (strip 0, block 0);
                                   // 3 jj + 1 = {hi of (1, 0), hi of (1, 1)}; 3 jj + 2 = {lo of (1, 0), lo of (1, 1)}
   f32x2 rv[3][2][QA6];            // [buffer][head][chunk row]: {cs, rl}
-  float lw[3][2][QA6], ws[3][2][QA6], dtl[3][2][QA6];
+  float lw[3][2][QA6], ws[3][2][QA6];
   float dec[3][2][2];             // decay over sub-chunk jj
 };
 static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
@@ -131,10 +131,12 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const float e31 = wave_read_lane(cs, 31), e63 = wave_read_lane(cs, 63);
     const float csb = lane < 32 ? 0.f : e31;    // prefix in front of the lane's sub-chunk
     const float cse = lane < 32 ? e31 : e63;    // prefix at its end
-    sm.rv[kb][hh][lane] = f32x2{cs, exp2_fast(cs - csb)};
+    // dx scan: the output row is scaled by dt'_l -- folded into the row's two scalars (the factor of S_in^T Q^T and the exponent of the
+    // M build), so that D dy can ride on the diagonal of M unscaled like D x does in the forward
+    if (MODE == GS_DX) sm.rv[kb][hh][lane] = f32x2{cs + log2_fast(rdt), exp2_fast(cs - csb) * rdt};
+    else sm.rv[kb][hh][lane] = f32x2{cs, exp2_fast(cs - csb)};
     sm.lw[kb][hh][lane] = log2_fast(rwv) - cs;
     sm.ws[kb][hh][lane] = rwv * exp2_fast(cse - cs);
-    if (MODE == GS_DX) sm.dtl[kb][hh][lane] = rdt;
     if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = exp2_fast(cse - csb);
   };
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   // and the token scalars.  The operands of phase 2 are requested in front of phase 1 of the same sub-chunk, the row fragments of the
   // next sub-chunk in front of phase 2, so every LDS read has a phase of work between request and use.
   struct FragR { u32x4 q0[4], q1[4]; };
-  struct FragC { s16x4 u0, u1, kt[8][2]; f32x2 rv0, rv1; f32x4 ws0, ws1; float dec, dts0, dts1; u32x4 m0, mh, ml; u32x2 x0, x1; };
+  struct FragC { s16x4 u0, u1, kt[8][2]; f32x2 rv0, rv1; f32x4 ws0, ws1; float dec; u32x4 m0, mh, ml; u32x2 x0, x1; };
   auto load_rows = [&](FragR& f, int kb, int jj) {
     if (STATE) return;
     if (OMK_A6_ABL & 1) { asm volatile("" : "+v"(f.q0[0]), "+v"(f.q0[1]), "+v"(f.q0[2]), "+v"(f.q0[3]), "+v"(f.q1[0]), "+v"(f.q1[1]), "+v"(f.q1[2]), "+v"(f.q1[3])); return; }
@@ -303,7 +305,6 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       f.x0 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * r0]);
       f.x1 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * (r0 + 16)]);
     }
-    if (MODE == GS_DX) { f.dts0 = sm.dtl[kb][hh][r0 + t16]; f.dts1 = sm.dtl[kb][hh][r0 + 16 + t16]; }
   };
   f32x4 accA0, accA1;
   auto phase1 = [&](const FragR& f, bool dump_here, uint16_t* dp) {
@@ -323,9 +324,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       }
     }
   };
-  auto out_rows = [&](f32x4 o, int row, int tlo, float dts, u32x2 xr) {   // the lane's row, columns 16 w + 4 g16 + r
+  auto out_rows = [&](f32x4 o, int row, int tlo, u32x2 xr) {   // the lane's row, columns 16 w + 4 g16 + r
     const int erow = rowtok(row);
-    if (!DFOLD) o = o * dts + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
+    if (!DFOLD) o = o + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
     const uint32_t eoff = (uint32_t)(erow * osl + 16 * w + 4 * g16);
     if (MODE == GS_Y && EXTRAS && tlo + erow < a.L) {
       if (oxb) {
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const f32x4 accB0 = mfma16x16x32_bf16(u00, as_s16x8(f.m0), f32x4{0.f, 0.f, 0.f, 0.f});
     f32x4 accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.mh), f32x4{0.f, 0.f, 0.f, 0.f});
     accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.ml), accB1);
-    out_rows(accA0 * f.rv0[1] + accB0, 32 * jj + t16, tlo, MODE == GS_DX ? f.dts0 : 1.f, f.x0);
-    out_rows(accA1 * f.rv1[1] + accB1, 32 * jj + 16 + t16, tlo, MODE == GS_DX ? f.dts1 : 1.f, f.x1);
+    out_rows(accA0 * f.rv0[1] + accB0, 32 * jj + t16, tlo, f.x0);
+    out_rows(accA1 * f.rv1[1] + accB1, 32 * jj + 16 + t16, tlo, f.x1);
   };
 
   FragR fr;
@@ -508,6 +509,8 @@ int ssd_a6_launch(const GScan& g, omk_stream stream) {
     if (a.dump) { if (ex) return OMK_EUNSUPPORTED; if (dfold) OMK_A6(GS_Y, false, true, true); else OMK_A6(GS_Y, false, false, true); }
     else if (ex) { if (dfold) OMK_A6(GS_Y, true, true, false); else OMK_A6(GS_Y, true, false, false); }
     else { if (dfold) OMK_A6(GS_Y, false, true, false); else OMK_A6(GS_Y, false, false, false); }
+  } else if (dfold) {
+    if (a.dump) OMK_A6(GS_DX, false, true, true); else OMK_A6(GS_DX, false, true, false);
   } else {
     if (a.dump) OMK_A6(GS_DX, false, false, true); else OMK_A6(GS_DX, false, false, false);
   }
