@@ -575,6 +575,17 @@ static size_t fwd_window_states_bytes(const OmkSsdFwd* p) {
   if (const char* e = getenv("OMK_SSD_KHILO")) if (e[0] == '1') return 0;
   if (const char* e = getenv("OMK_SSD_PRECISE")) if (e[0] == '1') return 0;
   const int64_t B = p->x.shape[0], L = p->x.shape[1], H = p->x.shape[2];
+  // the same dry check the launch makes (strides, alignment, 32-bit row span): a forward the MFMA kernel cannot take must answer 0
+  // here, so that the caller allocates nothing and omk_ssd_scan_fwd takes its ordinary fall-back chain (advisor finding, round 3:
+  // a bf16 x at a 2-byte storage offset failed with 'window_states asked for on a shape outside the MFMA kernel')
+  if (p->x.ndim != 4 || p->Cm.ndim != 4 || p->out.ndim != 4 || p->out.dtype != OMK_BF16 || p->Bm.dtype != OMK_BF16 || p->Cm.dtype != OMK_BF16) return 0;
+  GScan g = {};
+  g.mode = GS_Y; g.U = make_src(p->x, false); g.K = make_src(p->Bm, true); g.Q = make_src(p->Cm, true);
+  g.B = (int)B; g.H = (int)H; g.G = (int)p->Bm.shape[2]; g.L = (int)L; g.DU = 64; g.DK = 128;
+  if (g.G < 1 || g.H % g.G != 0) return 0;
+  g.out = p->out.data; g.osb = p->out.stride[0]; g.osl = p->out.stride[1]; g.osh = p->out.stride[2]; g.out_dt = p->out.dtype;
+  if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
+  if (ssd_mfma_launch(g, nullptr, 1) != OMK_OK) return 0;
   return (size_t)B * ((L + 127) / 128) * H * 16384;
 }
 extern "C" size_t omk_ssd_scan_fwd_window_states_bytes(const OmkSsdFwd* p) { return fwd_window_states_bytes(p); }

@@ -91,7 +91,7 @@ class _FusedLinearCE(torch.autograd.Function):
 def fused_linear_cross_entropy(hidden2d, weight, labels1d):
     """mean over labels != -100 of CE(hidden2d @ weight^T, labels1d) without materialising the (tokens, vocab) logits.
     Edge behaviour that differs from torch.nn.CrossEntropyLoss: when EVERY label is -100 the result is 0 (torch: NaN); labels
-    outside [0, V) other than -100 contribute zero loss and gradient but are counted in the mean (torch raises) -- callers
+    outside [0, V) other than -100 contribute zero loss and gradient and are NOT counted in the mean (torch raises) -- callers
     validate their label range (the reference only ever produces ids < V and -100, omnimamba.py:190-218)."""
     return _FusedLinearCE.apply(hidden2d, weight, labels1d)
 

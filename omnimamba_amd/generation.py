@@ -40,20 +40,27 @@ def _top_p_filter_(logits, top_p):
     logits.masked_fill_(remove.scatter(1, sorted_idx, remove), float("-inf"))
 
 
+MAX_PREFILL_GRAPHS = 4
+
+
 def _prefill_graph_ok(seqlen):
     """Short prompts are launch bound: capture them.  Long ones (MMU prompts) run eager -- one graph per length would pin memory."""
     import os
     return os.environ.get("OMK_PREFILL_GRAPH", "1") != "0" and seqlen <= 512
 
 
-_draws = 0     # Philox offset of the next host-side call of the device sampler (one stream position per call)
+def _stream_base():
+    """Philox stream position of the next sampling call: 62 random bits from torch's default generator.  The reference draws with
+    torch.multinomial, which advances the global generator -- successive calls are independent, and `torch.manual_seed(s)` followed by
+    the same calls reproduces them.  Drawing the position from that generator gives the device sampler both properties (a fixed
+    position per call made every decode of the same prompt return the same ids; a module-level counter was not reset by re-seeding)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
 
 
 def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
     """(batch, vocab) -> (batch,) token ids.  top_k == 1 is greedy argmax (what the inference scripts use).  With 1 < top_k <= 64 on
     the MI355X the draw is one omk_sample launch (top-k select, temperature, top-p, Philox inverse-CDF draw: csrc/sample.hip) seeded
     from torch's generator -- same distribution as the reference's topk + softmax + multinomial chain, no host round trip."""
-    global _draws
     if top_k == 1:
         return logits.argmax(dim=-1)
     if top_p > 0.0:
@@ -61,8 +68,7 @@ def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
     kk = min(top_k, logits.size(-1)) if top_k > 0 else 0
     if logits.is_cuda and SMP.applies(logits, kk, min_p=min_p if top_k <= 0 else 0.0, top_p=top_p):
         # 1 < top_k <= 64, or the whole vocabulary without a top-p / min-p cut (t2i_generate's default arguments: top_k 0, top_p 1.0)
-        _draws += 1
-        return SMP.sample_device(logits, top_k=kk, top_p=top_p, temperature=temperature, seed=torch.initial_seed(), offset=_draws)
+        return SMP.sample_device(logits, top_k=kk, top_p=top_p, temperature=temperature, seed=torch.initial_seed(), offset=_stream_base())
     if top_k > 0:
         top_k = min(top_k, logits.size(-1))
         vals, idx = torch.topk(logits, top_k, dim=-1)
@@ -296,6 +302,11 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         inference_params.reset(max_length, batch_size)
         pkey = ("prefill", batch_size, seqlen_pr, task, input_embeddings.dtype)
         if _prefill_graph_ok(seqlen_pr) and pkey not in cache["graphs"]:
+            # at most MAX_PREFILL_GRAPHS captured prompt lengths per model (least recently captured goes first): text prompts of
+            # every length would otherwise pin a graph + static buffers each
+            pkeys = [k for k in cache["graphs"] if k[0] == "prefill"]
+            if len(pkeys) >= MAX_PREFILL_GRAPHS:
+                del cache["graphs"][pkeys[0]]
             cache["graphs"][pkey] = PrefillGraph(model, cache["ip"], batch_size, seqlen_pr, input_embeddings.shape[-1], task,
                                                  input_embeddings.dtype, mempool=cache["mempool"])
             inference_params.reset(max_length, batch_size)
@@ -394,11 +405,12 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
     else:
         out = model(None, input_embeddings, position_ids=None, task=task, inference_params=ip, num_last_tokens=1)
         lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
+    base = 0 if top_k == 1 else _stream_base()   # this call's stretch of the Philox stream: base, base + 1, ... (one position per token)
     first = (lg0.argmax(dim=-1, keepdim=True) if top_k == 1 else
-             SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=0).unsqueeze(1))
+             SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=base).unsqueeze(1))
     ip.seqlen_offset = seqlen_pr
     seqs = torch.cat([input_ids, first], dim=1)
     if n_steps > 0:
-        seqs = torch.cat([seqs, graph.run(first, seqlen_pr, n_steps)], dim=1)
+        seqs = torch.cat([seqs, graph.run(first, seqlen_pr, n_steps, draw0=base + 1)], dim=1)
         ip.seqlen_offset = seqlen_pr + n_steps
     return seqs

@@ -260,6 +260,7 @@ def test_device_loop_sampled_decode_is_reproducible_and_in_range(lm_1p3b):
     b = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)
     torch.manual_seed(12)
     c = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)
+    c2 = decode(ids, emb, model, Pn + new, top_k=20, top_p=0.9, temperature=0.8, task="t2i", cg=True, device_loop=True)   # no re-seed: a new stretch of the stream
     g = decode(ids, emb, model, Pn + new, top_k=1, task="t2i", cg=True, device_loop=True)
     # the default arguments of the reference's t2i_generate (top_k = 0, top_p = 1.0): full-vocabulary multinomial, also inside the graph
     torch.manual_seed(11)
@@ -269,5 +270,6 @@ def test_device_loop_sampled_decode_is_reproducible_and_in_range(lm_1p3b):
     model._decoding_cache = None
     assert a.shape == (1, Pn + new) and torch.equal(a, b)
     assert not torch.equal(a, c) and not torch.equal(a, g)
+    assert not torch.equal(c, c2)      # successive calls are independent draws, as with the reference's torch.multinomial
     assert int(a[:, Pn:].min()) >= 0 and int(a[:, Pn:].max()) < model.cfg.vqvae_vocab_size
     assert torch.equal(f1, f2) and not torch.equal(f1, g) and int(f1[:, Pn:].min()) >= 0 and int(f1[:, Pn:].max()) < model.cfg.vqvae_vocab_size

@@ -314,3 +314,25 @@ def test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states(dev, monke
     # buys is the bf16 rounding of the state copy that feeds y
     assert res["0"][1] < 1e-3, res
     assert res["1"][0] < 0.6 * res["0"][0], res
+
+
+def test_training_forward_on_a_layout_the_mfma_kernel_cannot_take_falls_back(dev):
+    """Advisor finding (round 3): bf16 (1, 130, 2, 64) x at a 2-byte storage offset with requires_grad.  The window-state query must
+    answer 0 for a forward the MFMA kernel cannot take (it makes the same dry check as the launch), so the call takes the generic
+    fall-back instead of failing with 'window_states asked for on a shape outside the MFMA kernel'."""
+    import omnimamba_amd.ssd_combined as S
+    L, H, P, N = 130, 2, 64, 128
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, 1, torch.bfloat16, seed=5)
+    buf = torch.zeros(x.numel() + 1, dtype=torch.bfloat16)
+    buf[1:] = x.reshape(-1)
+    xo = buf[1:].view(1, L, H, P).to(dev) if dev.type == "cpu" else None
+    if xo is None:   # keep the odd storage offset on the device
+        db = buf.to(dev)
+        xo = db[1:].view(1, L, H, P)
+    assert xo.storage_offset() == 1
+    xo = xo.detach().requires_grad_()
+    d = lambda t: None if t is None else t.to(dev)
+    y = S.mamba_chunk_scan_combined(xo, d(dt), d(A), d(Bm), d(Cm), 256, D=d(D), dt_bias=d(dtb), dt_softplus=True)
+    y.float().sum().backward()
+    y0 = S.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), 256, D=d(D), dt_bias=d(dtb), dt_softplus=True)
+    assert rel(y.float().cpu(), y0.float().cpu()) < 6e-3 and xo.grad is not None and torch.isfinite(xo.grad.float()).all()

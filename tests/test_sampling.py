@@ -143,3 +143,20 @@ def test_tiny_top_p_is_greedy_and_argument_checks(dev):
         sample_device(logits, top_k=65)
     with pytest.raises(RuntimeError):
         sample_device(logits, top_k=4, temperature=0.0)
+
+
+def test_host_sample_calls_advance_the_stream_and_reseeding_reproduces_them(dev):
+    """generation.sample() on the device sampler: two calls in a row are independent draws (the reference's torch.multinomial advances
+    the global generator), and torch.manual_seed(s) followed by the same calls gives the same ids (advisor finding, round 3: a fixed
+    stream position per call / a module counter that re-seeding did not reset)."""
+    from omnimamba_amd.generation import sample
+    torch.manual_seed(5)
+    logits = torch.randn(64, 4096).to(dev)
+    torch.manual_seed(77)
+    a1 = sample(logits, top_k=40, top_p=0.95, temperature=1.1).cpu()
+    a2 = sample(logits, top_k=40, top_p=0.95, temperature=1.1).cpu()
+    torch.manual_seed(77)
+    b1 = sample(logits, top_k=40, top_p=0.95, temperature=1.1).cpu()
+    b2 = sample(logits, top_k=40, top_p=0.95, temperature=1.1).cpu()
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert not torch.equal(a1, a2)
