@@ -439,6 +439,8 @@ def main():
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     tj = json.load(fh)
                     traffic[key] = (int(tj["traffic_bytes_per_launch"]), tj.get("source"))
+                    if key == "fwd" and "with_window_states" in tj:
+                        traffic["fwd_ws"] = int(tj["with_window_states"]["traffic_bytes_per_launch"])
             except (OSError, KeyError, ValueError):
                 traffic[key] = (None, None)
         from omnimamba_amd.ssd_combined import save_window_states_enabled
@@ -452,13 +454,13 @@ def main():
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
                        "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
-            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_mfma_a3_kernel<GS_Y> + ssd_dt_prep_kernel" + (
+            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_a6_kernel<GS_Y> + ssd_dt_prep_vec_kernel" + (
                              "; the forward also leaves its window states behind for the backward: +256 MiB of writes that are not algorithmic bytes; the plain forward of this shape is scan_target.B8_L4096)"
                              if save_ws else ")"),
                          "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
-                         # (the counters of the file are of the plain forward; the window states are one more write of 16 KB per head and 128 tokens)
-                         "traffic": None if traffic["fwd"][0] is None else traffic["fwd"][0] + (B_LOCAL * ((SEQ + 127) // 128) * H * 16384 if save_ws else 0),
-                         "traffic_source": None if traffic["fwd"][1] is None else traffic["fwd"][1] + ("; + the window states this launch writes, by size" if save_ws else ""),
+                         # (both instantiations -- with and without the window-state dumps -- are under the counters: round 4)
+                         "traffic": None if traffic["fwd"][0] is None else (traffic.get("fwd_ws", traffic["fwd"][0] + B_LOCAL * ((SEQ + 127) // 128) * H * 16384) if save_ws else traffic["fwd"][0]),
+                         "traffic_source": traffic["fwd"][1],
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
             "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + " + ("" if save_ws else "state-only forward pass + ") + "dx scan with window-state dumps + ssd_cp_kernel + folds + finish" + (
                                  "; forward window states saved by the training forward)" if save_ws else ")"),

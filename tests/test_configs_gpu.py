@@ -10,7 +10,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tolerances import ARITH_BUDGET, Q_BF16, arith_part, forward_budget   # the tolerance rule (tests/tolerances.py)
+from tolerances import ARITH_BUDGET, Q_BF16, arith_part, direct_bound, forward_budget   # the tolerance rule (tests/tolerances.py)
 
 
 def rel(a, b):
@@ -46,14 +46,18 @@ def test_cfg2_scan_forward_production_shape_vs_oracle():
     errs = []
     for b, h in ((0, 0), (0, 63), (3, 17), (7, 5), (7, 63), (4, 32), (1, 1), (6, 40)):
         sl = (x[b:b + 1, :, h:h + 1], dt[b:b + 1, :, h:h + 1], A[h:h + 1], Bm[b:b + 1], Cm[b:b + 1])
-        y64, f64, by, bf, (eu, efu) = forward_budget(*sl, D=D[h:h + 1], dt_bias=dtb[h:h + 1], dt_softplus=True)
+        y64, f64, by, bf, (eu, efu), (yu, fu) = forward_budget(*sl, D=D[h:h + 1], dt_bias=dtb[h:h + 1], dt_softplus=True, return_upstream=True)
         q = rel(y64[0, :, 0].bfloat16().float(), y64[0, :, 0])        # what one rounding of the exact result to bf16 costs on this slice
         e = rel(y[b, :, h], y64[0, :, 0])
         ef = rel(fin[b, h], f64[0, 0])
-        errs.append((b, h, round(float(A[h]), 2), "y", round(arith_part(e, q), 6), "upstream", round(eu, 6), "final", round(ef, 6), "upstream", round(efu, 6)))
+        dy_, df_ = rel(y[b, :, h], yu[0, :, 0]), rel(fin[b, h], fu[0, 0])     # DIRECT distances to the upstream-rounding oracle
+        errs.append((b, h, round(float(A[h]), 2), "y", round(arith_part(e, q), 6), "upstream", round(eu, 6), "direct", round(arith_part(dy_, q), 6),
+                     "final", round(ef, 6), "upstream", round(efu, 6), "direct", round(df_, 6)))
         assert arith_part(e, q) <= by, errs
-        assert ef <= bf, errs
-    print("(b, h, A_h, arithmetic error of y: ours / upstream-rounding oracle; final state: ours / upstream):", errs)
+        assert ef <= ARITH_BUDGET, errs                                # round 4: the kept final state meets the bare north-star 1e-3
+        assert dy_ <= direct_bound(by, eu, q), errs
+        assert df_ <= direct_bound(ARITH_BUDGET, efu), errs
+    print("(b, h, A_h, arithmetic error of y: ours / upstream-rounding oracle / direct distance between the two; final state: the same three):", errs)
 
 
 def test_cfg2_scan_backward_production_shape_vs_oracle():

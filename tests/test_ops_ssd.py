@@ -138,7 +138,8 @@ def test_ssd_mfma_fwd(dev, L, H, G, with_z, with_init):
     assert e < tol, (e, q, tol, up)
     # final state: the w_l K_l operand of the state update is rounded to bf16 once (as upstream's chunk-state kernel does) unless
     # OMK_SSD_KHILO / OMK_SSD_PRECISE ask for the hi + lo pair
-    assert rel(fin, f0) < bf, (rel(fin, f0), bf, up)
+    # round 4: a kept final state is carried with the hi + lo operand (ssd_a6.hip) -- the bare north-star 1e-3, not the upstream-rounding budget
+    assert rel(fin, f0) < 1e-3, (rel(fin, f0), bf, up)
     assert rel(outg.float(), o32) < tol and rel(fing, f0) < 1e-4
     if with_z:
         assert out_x is not None
@@ -168,6 +169,7 @@ def test_ssd_mfma_fwd_split_sequence(dev, monkeypatch, L, H, G, with_z, with_ini
     by, bf, up = _budgets(L, H, G, with_z, with_init)
     q = rel(o32.bfloat16().float(), o32)
     tol = (by ** 2 + q ** 2) ** 0.5
+    # (the segment start states come from the row-strip kernel's zero-start state pass: one bf16 operand rounding per chunk, the upstream budget)
     assert rel(out.float(), o32) < tol and rel(fin, f0) < bf, (rel(out.float(), o32), tol, rel(fin, f0), bf, up)
     assert rel(out.float(), out1.float().cpu()) < 2e-3 and rel(fin, fin1.cpu()) < 1e-5
 
