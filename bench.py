@@ -155,7 +155,7 @@ def selscan_cfg1(dev):
     return out
 
 
-def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage2=False):
+def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage2=False, dist_on=None):
     """BASELINE configs[3]: OmniMamba-1.3B stage-1 MMU pretrain step on synthetic image features + text ids, L = 2048:
     images_feat (B, 729, 2176) -> projector, text ids of length L - 733, labels = ids; stage 'align' with only the MMU
     task configured (projector + MMU LoRA adapters train); bf16 autocast, AdamW, clip 1.0.
@@ -164,37 +164,41 @@ def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage
     from omnimamba_amd.omni import OmniMambaPath
     from omnimamba_amd.stack import StackConfig
     from omnimamba_amd.train import Stage2Step, TrainConfig, synthetic_batch, wrap_ddp
+    dist_on = world > 1 if dist_on is None else dist_on
     torch.manual_seed(0)
     tasks = ("t2i", "mmu") if stage2 else ("mmu",)
     cfg = StackConfig.omnimamba_1_3b(t2i_task=stage2, mmu_task=True, mmu_positions=max(seqlen, 1500), t2i_positions=max(seqlen, 329))
     model = OmniMambaPath(cfg, stage="finetune" if stage2 else "align", device=dev, dtype=torch.float32)
     tc = TrainConfig()
-    net = wrap_ddp(model, tc, device_ids=[dev.index]) if world > 1 else None
+    net = wrap_ddp(model, tc, device_ids=[dev.index]) if dist_on else None
     step = Stage2Step(model, tc, ddp_model=net)
     data = synthetic_batch(cfg, batch, seqlen, dev, torch.bfloat16, rank=rank, tasks=tasks)
     for _ in range(warmup):
         step(data)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     # per-step HIP events on the current stream (rank 0's own steps; the headline figure is the barrier-bracketed wall time)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    step.time_backward = True
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(steps):
         step(data)
         evs[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    bwd = sorted(a.elapsed_time(b) for a, b in step.backward_ms)
+    bwd_ms = bwd[len(bwd) // 2] if bwd else float("nan")
     loss = sum(float(step.last[t]) for t in tasks)
     assert math.isfinite(loss)
     out = {"tokens_per_s": round(world * len(tasks) * batch * seqlen * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
@@ -206,8 +210,39 @@ def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage
                       "trainable_params": sum(p.numel() for p in model.parameters() if p.requires_grad),
                       "params": sum(p.numel() for p in model.parameters()), "dtype": "bf16 autocast, fp32 masters",
                       "parallelism": f"dp{world}" if world > 1 else "single"}}
+    out["comm_model"] = comm_model(out["config"]["trainable_params"], tc.bucket_cap_mb, dt / steps * 1e3, bwd_ms, world)
     del step, net, model
     torch.cuda.empty_cache()
+    return out
+
+
+XGMI_LINK_GBS = 153.0     # per direction and link; 7 links per GPU, point to point (MI355X_MICROARCH.md / task brief)
+
+
+def comm_model(trainable_params, bucket_cap_mb, step_ms, backward_ms, world):
+    """when the N devices are not there, the modelled gradient all-reduce next to the measured backward it has
+    to hide under.  fp32 gradients (4 B per trainable parameter; 2 B with TrainConfig.grad_compression = 'bf16'), DDP buckets of
+    bucket_cap_mb, reduce-scatter + all-gather volume 2 (N - 1) / N x bytes per GPU.  Two bounds for the time: ONE ring (every hop
+    on one 153 GB/s link) and ALL links (the N - 1 peers reached directly, each over its own link -- what a fully connected xGMI
+    node allows).  The all-reduce of a bucket starts when the backward has produced it, so all but the last bucket can run under
+    the backward: exposed = max(0, t_allreduce - backward x (buckets - 1) / buckets) (for one bucket: all of it).  Predicted
+    efficiency = step / (step + exposed); the measured numbers at N > 1 come from the driver's SCALE run of this file."""
+    out = {"measured_on_gpus": world, "step_ms": round(step_ms, 2), "backward_ms": round(backward_ms, 2), "trainable_params": trainable_params,
+           "xgmi_link_GBs": XGMI_LINK_GBS, "links_per_gpu": 7, "predicted": {}}
+    for comp, bpe in (("fp32", 4), ("bf16_compression", 2)):
+        nbytes = trainable_params * bpe
+        buckets = max(1, math.ceil(trainable_params * 4 / (bucket_cap_mb * 2 ** 20)))     # buckets are cut on the fp32 gradients
+        row = {"gradient_bytes": nbytes, "buckets": buckets}
+        for n in (2, 4, 8):
+            vol = 2.0 * (n - 1) / n * nbytes
+            t_ring = vol / (XGMI_LINK_GBS * 1e9) * 1e3
+            t_all = vol / (XGMI_LINK_GBS * 1e9 * (n - 1)) * 1e3
+            hide = backward_ms * (buckets - 1) / buckets
+            row[f"n{n}"] = {"allreduce_ms_one_ring": round(t_ring, 2), "allreduce_ms_all_links": round(t_all, 2),
+                            "exposed_ms_one_ring": round(max(0.0, t_ring - hide), 2), "exposed_ms_all_links": round(max(0.0, t_all - hide), 2),
+                            "efficiency_one_ring": round(step_ms / (step_ms + max(0.0, t_ring - hide)), 4),
+                            "efficiency_all_links": round(step_ms / (step_ms + max(0.0, t_all - hide)), 4)}
+        out["predicted"][comp] = row
     return out
 
 
@@ -325,9 +360,11 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the CPU launch test passes gloo)")
     ap.add_argument("--dry-launch", action="store_true", help="only initialise the process group and report ranks (CPU test of the launch path)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank path (launcher, process group, DDP, barriers, max over ranks) even with --gpus 1: "
+                                                              "runs the exact code of the N > 1 scaling runs on RCCL where only one GPU exists")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -352,10 +389,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend or "nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(args.backend or "nccl", device_id=dev, rank=rank, world_size=world)
 
     from omnimamba_amd import _prof
     from omnimamba_amd._lib import get_lib
@@ -367,7 +407,7 @@ def main():
     torch.manual_seed(0)                       # identical random-init weights on every rank
     block = Mamba2(D_MODEL, d_state=D_STATE, headdim=HEADDIM, layer_idx=0, device=dev)
     model = block
-    if world > 1:
+    if dist_on:
         from torch.nn.parallel import DistributedDataParallel as DDP
         # 32 MB buckets: out_proj.weight (33.5 MB, ready at the very start of backward) gets a bucket of its own and its
         # all-reduce overlaps the whole backward; with 64 MB it would wait for the small parameters whose gradients come
@@ -453,7 +493,7 @@ def main():
             "config": {"workload": "single Mamba-2 block fwd+bwd (BASELINE.json configs[1])", "batch_per_gpu": B_LOCAL,
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
-                       "parallelism": f"dp{world}" if world > 1 else "single", "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "process_group": (dist.get_backend() if dist_on else None), "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
             "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_a6_kernel<GS_Y> + ssd_dt_prep_vec_kernel" + (
                              "; the forward also leaves its window states behind for the backward: +256 MiB of writes that are not algorithmic bytes; the plain forward of this shape is scan_target.B8_L4096)"
                              if save_ws else ")"),
@@ -474,9 +514,9 @@ def main():
     extra_s = None if (args.no_selscan_cfg1 or world > 1 or rank != 0) else selscan_cfg1(dev)
     extra_tg = None if (args.no_scan_target or world > 1 or rank != 0) else scan_target(dev)
     extra_d = None if (args.no_decode or world > 1 or rank != 0) else decode_1p3b(dev)
-    extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world)      # every rank takes part (DDP)
+    extra_t = None if args.no_train_1p3b else train_1p3b(dev, rank, world, dist_on=dist_on)      # every rank takes part (DDP)
     torch.cuda.reset_peak_memory_stats()
-    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=5, warmup=2, batch=2, seqlen=8192, stage2=True)   # two warm-up steps: the caching allocator settles in the second
+    extra_t2 = None if args.no_train_1p3b else train_1p3b(dev, rank, world, steps=5, warmup=2, batch=2, seqlen=8192, stage2=True, dist_on=dist_on)   # two warm-up steps: the caching allocator settles in the second
     if rank == 0:
         out["train_1p3b"] = extra_t
         out["train_1p3b_stage2"] = extra_t2

@@ -27,6 +27,7 @@ class TrainConfig:
     clip: float = 1.0
     bucket_cap_mb: int = 128
     amp_dtype: torch.dtype = torch.bfloat16
+    grad_compression: str = "none"     # "bf16": the bucket all-reduce runs on bf16 copies of the fp32 gradient buckets (half the xGMI bytes)
 
 
 def cosine_with_min_lr(step, cfg: TrainConfig):
@@ -57,8 +58,17 @@ def wrap_ddp(model, cfg: TrainConfig, device_ids=None):
     # two forwards share one backward and each activates only one task's adapters -> parameters are used by exactly one
     # of the two graphs; static_graph is not needed, but every trainable parameter must receive a gradient in the step,
     # which Stage2 (both tasks per step) guarantees.
-    return DDP(model, device_ids=device_ids, gradient_as_bucket_view=True, bucket_cap_mb=cfg.bucket_cap_mb,
-               broadcast_buffers=False)
+    net = DDP(model, device_ids=device_ids, gradient_as_bucket_view=True, bucket_cap_mb=cfg.bucket_cap_mb,
+              broadcast_buffers=False)
+    if cfg.grad_compression == "bf16":
+        # SURVEY.md section 2.3 C1 "optional bf16 compression hook": stage 2 all-reduces 5.9 GB of fp32 gradients per step
+        # (/root/reference/train_stage2.py:37-38 trains every parameter); the hook casts each bucket to bf16, all-reduces, and casts
+        # back into the fp32 bucket view -- half the bytes on every xGMI link, one bf16 rounding per gradient element and rank sum
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        net.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
+    elif cfg.grad_compression != "none":
+        raise ValueError(f"grad_compression: 'none' or 'bf16', not {cfg.grad_compression!r}")
+    return net
 
 
 class Stage2Step:
@@ -77,6 +87,8 @@ class Stage2Step:
         self.opt = torch.optim.AdamW(params, lr=cfg.lr, betas=cfg.betas, weight_decay=cfg.weight_decay, fused=fused)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: cosine_with_min_lr(s, cfg))
         self.last = {}
+        self.time_backward = False   # bench.py: HIP events around the backward (the window the gradient all-reduce has to hide in)
+        self.backward_ms = []
 
     def __call__(self, batch):
         dev_type = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
@@ -89,7 +101,14 @@ class Stage2Step:
                 loss = self.net(batch, task)
                 self.last[task] = loss.detach()      # logged from the device scalar: no per-step .item() (trainer.py:122-125)
                 total = total + loss
-        total.backward()
+        if self.time_backward and dev_type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            total.backward()
+            e1.record()
+            self.backward_ms.append((e0, e1))
+        else:
+            total.backward()
         if self.cfg.clip:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None], self.cfg.clip)
         self.opt.step()

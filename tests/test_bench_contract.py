@@ -70,3 +70,18 @@ def test_bench_under_an_external_launcher_does_not_relaunch():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_the_multi_rank_code_on_rccl_with_one_gpu():
+    """The SCALE driver runs `python bench.py --gpus N`: launcher, nccl process group, DDP, barriers and the max over ranks.  With one
+    GPU that code never ran (world size 1 skips it).  --force-dist takes exactly that path at N = 1: bench.py re-executes itself under
+    torch.distributed.run, initialises RCCL, wraps the block in DDP (32 MB buckets, all-reduce of every gradient) and times K steps."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--min-seconds", "0",
+                        "--no-cpu-baseline", "--no-selscan-cfg1", "--no-scan-target", "--no-decode", "--no-train-1p3b"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["config"]["process_group"] == "nccl" and j["value"] > 0

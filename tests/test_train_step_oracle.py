@@ -205,3 +205,78 @@ def test_wide_two_layer_stack_step_matches_oracle_composition(stage, L, tasks):
         checked += 1
     print(f"stage {stage} L {L}: loss {total.item():.5f} vs oracle {ref.item():.5f}; {checked} gradients checked, worst {worst}")
     assert checked >= (3 if stage == "align" else 10)
+
+
+def _nccl_group_of_one(dev):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    return dist, created
+
+
+@pytest.mark.gpu
+def test_bf16_gradient_compression_hook_on_nccl_world_size_one():
+    """SURVEY.md section 2.3 C1 (optional bf16 compression hook; 5.9 GB of fp32 gradients per stage-2 step,
+    /root/reference/train_stage2.py:37-38): TrainConfig(grad_compression='bf16') registers the bf16 bucket hook on the DDP wrapper.  On
+    RCCL at world size 1: the step runs, and every gradient equals the uncompressed one to ONE bf16 rounding (the bucket travels as
+    bf16 and comes back into the fp32 bucket view)."""
+    from omnimamba_amd.train import Stage2Step, TrainConfig, wrap_ddp
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist, created = _nccl_group_of_one(dev)
+    try:
+        model = _model(dev)
+        plain = copy.deepcopy(model)
+        batch = _batch(model.cfg, dev)
+        tc = TrainConfig(lr=0.0, clip=0.0, amp_dtype=torch.bfloat16, bucket_cap_mb=1, grad_compression="bf16")
+        net = wrap_ddp(model, tc, device_ids=[0])
+        a = Stage2Step(model, tc, ddp_model=net)(batch)
+        b = Stage2Step(plain, TrainConfig(lr=0.0, clip=0.0, amp_dtype=torch.bfloat16))(batch)
+        torch.cuda.synchronize()
+        assert abs(a.item() - b.item()) < 1e-6 * abs(b.item()) + 1e-7
+        n_checked = 0
+        for (n, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):
+            assert (p.grad is None) == (q.grad is None), n
+            if p.grad is None:
+                continue
+            assert p.grad.dtype == torch.float32
+            assert torch.equal(p.grad, q.grad.bfloat16().float()), n       # exactly one rounding to bf16
+            n_checked += 1
+        assert n_checked > 40
+        with pytest.raises(ValueError):
+            wrap_ddp(copy.deepcopy(plain), TrainConfig(grad_compression="fp8"), device_ids=[0])
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_context_parallel_block_on_an_nccl_group_of_one():
+    """Mamba2.forward(cp_group=) with the group living on RCCL (world size 1: the all-gathers of the conv halo and of the boundary
+    states, and their backward all-reduces, execute on the nccl backend): output and parameter gradients equal the plain forward."""
+    from omnimamba_amd.mamba2 import Mamba2
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist, created = _nccl_group_of_one(dev)
+    try:
+        torch.manual_seed(0)
+        blk = Mamba2(256, d_state=128, headdim=64, layer_idx=0, device=dev)
+        ref = copy.deepcopy(blk)
+        u = torch.randn(2, 320, 256, device=dev)
+        dy = torch.randn_like(u)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(u, cp_group=dist.group.WORLD)
+            y0 = ref(u)
+        y.backward(dy.to(y.dtype))
+        y0.backward(dy.to(y0.dtype))
+        torch.cuda.synchronize()
+        assert rel(y.float(), y0.float()) < 6e-3
+        for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+            assert p.grad is not None and rel(p.grad, q.grad) < 3e-2, (n, rel(p.grad, q.grad))
+    finally:
+        if created:
+            dist.destroy_process_group()
