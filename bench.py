@@ -310,6 +310,33 @@ def decode_1p3b(dev):
            "time_to_first_token_ms": round(ttft * 1e3, 3), "ms_per_token": round(ms_tok, 4), "tokens_per_s": round(1e3 / ms_tok, 1),
            "total_ms": round(best * 1e3, 2), "weights_GBs": round(n_param * 4 / (ms_tok * 1e-3) / 1e9, 1),
            "frac_of_hbm_peak": round(n_param * 4 / (ms_tok * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "params": n_param, "dtype": "f32"}
+    # BASELINE.md cfg 3 also lists batch 8 / 32 and bf16 weights (scripts/inference_t2i.py:29-46 batches prompts): ms per decode STEP,
+    # tokens/s of the whole batch, bytes per step = weights + the recurrent state read and written (48 layers x (conv + ssm state))
+    def more(model_, bsz, wbytes, new_=64):
+        ids_ = torch.zeros(bsz, P, dtype=torch.long, device=dev)
+        emb_ = (torch.randn(bsz, P, cfg.d_model, device=dev) * 0.02 + model_.backbone.pos_embed[:, :P].float()).to(next(model_.parameters()).dtype)
+        model_._decoding_cache = None
+        decode(ids_, emb_, model_, P + new_, top_k=1, task="t2i", cg=True)
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        decode(ids_, emb_, model_, P + 1, top_k=1, task="t2i", cg=True)
+        torch.cuda.synchronize()
+        tf_ = time.perf_counter() - t0_
+        b_ = float("inf")
+        for _ in range(2):
+            t0_ = time.perf_counter()
+            decode(ids_, emb_, model_, P + new_, top_k=1, task="t2i", cg=True)
+            torch.cuda.synchronize()
+            b_ = min(b_, time.perf_counter() - t0_)
+        ms_ = (b_ - tf_) / (new_ - 1) * 1e3
+        sbytes = 2 * bsz * cfg.n_layer * (64 * 64 * 128 + (2 * cfg.d_model + 2 * 128) * 4) * wbytes
+        model_._decoding_cache = None
+        return {"ms_per_step": round(ms_, 4), "tokens_per_s": round(bsz * 1e3 / ms_, 1),
+                "GBs_weights_plus_state": round((n_param * wbytes + sbytes) / (ms_ * 1e-3) / 1e9, 1)}
+    out["batches"] = {"f32_B8": more(model, 8, 4), "f32_B32": more(model, 32, 4)}
+    model = model.to(torch.bfloat16)
+    out["batches"]["bf16_B1"] = more(model, 1, 2, new_=128)
+    out["batches"]["bf16_B8"] = more(model, 8, 2)
     # the VQ decode tail behind the 256 ids (mamba_vlm.py:104-108; VQ-16 geometry, random weights): ids -> 3 x 256 x 256 pixels
     from omnimamba_amd.vq_tail import VQDecodeTail
     tail = VQDecodeTail().to(dev).eval()
@@ -348,6 +375,7 @@ def self_launch(args):
 
 
 def main():
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # the VQ tail's library convolutions: no exhaustive find (5 s of naive kernels per run)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
