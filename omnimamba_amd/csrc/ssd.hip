@@ -85,16 +85,24 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
   const bool hok = h < a.H;   // H is even: both heads of the pair are in or out
   float bias[2] = {0.f, 0.f};
   if (a.bias && hok) { bias[0] = load_rt(a.bias, h, a.bias_dt); bias[1] = load_rt(a.bias, h + 1, a.bias_dt); }
-  const T* src = (const T*)a.dt + (int64_t)b * a.sb + h;
+  const T* src = (const T*)a.dt + (int64_t)b * a.sb + (hok ? h : 0);
+  // all eight loads of the thread first, without control flow (rows behind the end read the last row and are masked below): with
+  // the load under `if (t < L)` the eight round trips to memory ran one after the other (13.5 us per launch; round 4)
+  float raw[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int t = lb * 64 + 8 * j + tr;
+    load_vec<T, 2>(src + (int64_t)(t < a.L ? t : a.L - 1) * a.sl, raw[j]);
+  }
+  const bool want_d = a.dsoft != nullptr;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int tl = 8 * j + tr, t = lb * 64 + tl;
     float v2[2] = {0.f, 0.f}, d2[2] = {1.f, 1.f};
     if (t < a.L && hok) {
-      load_vec<T, 2>(src + (int64_t)t * a.sl, v2);
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        float v = v2[e] + bias[e], d = 1.f;
+        float v = raw[j][e] + bias[e], d = 1.f;
         if (a.softplus && v <= 20.f) {
           const float ex = exp2_fast(v * LOG2E), u = 1.f + ex;
           d = ex * rcp_fast(u);
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
       }
     }
     sv[2 * hp][tl] = v2[0]; sv[2 * hp + 1][tl] = v2[1];
-    sd[2 * hp][tl] = d2[0]; sd[2 * hp + 1][tl] = d2[1];
+    if (want_d) { sd[2 * hp][tl] = d2[0]; sd[2 * hp + 1][tl] = d2[1]; }
   }
   block_sync();
   const int hh = tid >> 2, q = tid & 3, hg = hb * 64 + hh;
