@@ -225,7 +225,8 @@ def comm_model(trainable_params, bucket_cap_mb, step_ms, backward_ms, world):
     bucket_cap_mb, reduce-scatter + all-gather volume 2 (N - 1) / N x bytes per GPU.  Two bounds for the time: ONE ring (every hop
     on one 153 GB/s link) and ALL links (the N - 1 peers reached directly, each over its own link -- what a fully connected xGMI
     node allows).  The all-reduce of a bucket starts when the backward has produced it, so all but the last bucket can run under
-    the backward: exposed = max(0, t_allreduce - backward x (buckets - 1) / buckets) (for one bucket: all of it).  Predicted
+    the backward; the last one (the first layers' gradients) has nothing left to hide behind:
+    exposed = max(t_allreduce / buckets, t_allreduce - backward x (buckets - 1) / buckets).  Predicted
     efficiency = step / (step + exposed); the measured numbers at N > 1 come from the driver's SCALE run of this file."""
     out = {"measured_on_gpus": world, "step_ms": round(step_ms, 2), "backward_ms": round(backward_ms, 2), "trainable_params": trainable_params,
            "xgmi_link_GBs": XGMI_LINK_GBS, "links_per_gpu": 7, "predicted": {}}
@@ -238,10 +239,11 @@ def comm_model(trainable_params, bucket_cap_mb, step_ms, backward_ms, world):
             t_ring = vol / (XGMI_LINK_GBS * 1e9) * 1e3
             t_all = vol / (XGMI_LINK_GBS * 1e9 * (n - 1)) * 1e3
             hide = backward_ms * (buckets - 1) / buckets
+            ex_ring, ex_all = max(t_ring / buckets, t_ring - hide), max(t_all / buckets, t_all - hide)
             row[f"n{n}"] = {"allreduce_ms_one_ring": round(t_ring, 2), "allreduce_ms_all_links": round(t_all, 2),
-                            "exposed_ms_one_ring": round(max(0.0, t_ring - hide), 2), "exposed_ms_all_links": round(max(0.0, t_all - hide), 2),
-                            "efficiency_one_ring": round(step_ms / (step_ms + max(0.0, t_ring - hide)), 4),
-                            "efficiency_all_links": round(step_ms / (step_ms + max(0.0, t_all - hide)), 4)}
+                            "exposed_ms_one_ring": round(ex_ring, 2), "exposed_ms_all_links": round(ex_all, 2),
+                            "efficiency_one_ring": round(step_ms / (step_ms + ex_ring), 4),
+                            "efficiency_all_links": round(step_ms / (step_ms + ex_all), 4)}
         out["predicted"][comp] = row
     return out
 
