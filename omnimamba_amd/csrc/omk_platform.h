@@ -122,17 +122,6 @@ __device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
   for (int r = 0; r < 4; r++) d[r] = w.d32[l][r];
   return d;
 }
-// v_mfma_f32_16x16x16_bf16: A[i = l & 15][k = 4 (l >> 4) + e], B[k = 4 (l >> 4) + e][j = l & 15], e = 0..3
-__device__ __forceinline__ f32x4 mfma16x16x16_bf16(s16x4 a, s16x4 b, f32x4 c) {
-  emu::Wave& w = emu::cur_wave();
-  int l = emu::lane_id();
-  for (int e = 0; e < 4; e++) { w.a16[l][e] = (uint16_t)a[e]; w.b16[l][e] = (uint16_t)b[e]; }
-  for (int r = 0; r < 4; r++) w.c32[l][r] = c[r];
-  emu::wave_collective(emu::op_mfma16k16);
-  f32x4 d;
-  for (int r = 0; r < 4; r++) d[r] = w.d32[l][r];
-  return d;
-}
 __device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
   emu::Wave& w = emu::cur_wave();
   int l = emu::lane_id();
@@ -170,11 +159,6 @@ __device__ __forceinline__ f32x16 mfma32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) 
 }
 __device__ __forceinline__ f32x4 mfma16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-// v_mfma_f32_16x16x16_bf16 (the contraction over 16: one ds_read_b64_tr_b16 fragment per operand, lane (i, g) holds k = 4 g + 0..3)
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16x16x16_bf16(s16x4 a, s16x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 // v_mfma_f32_16x16x4_f32: fp32 operands (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]), 32 cycles per SIMD: the
 // fp32 matrix rate of this chip equals its fp32 VALU rate -- what the instruction buys is 1024 MACs per issue slot instead of 64

@@ -1,9 +1,10 @@
 // ssd_a6.hip -- class A scan (forward y and the dx scan of the backward): state in COLUMN SLICES, M tiles shared through LDS.
 //
-// What the measurements of round 4 say about the scan kernels of this repo (profiles/r04_a5_experiments.txt): a SIMD retires about one
-// instruction every four cycles whatever the mix -- a wave's VALU, LDS and matrix instructions do not hide behind each other to any useful
-// degree at two waves per SIMD --, so the time of a chunk is its instruction count.  The row-strip kernel (ssd_mfma.hip) spends ~820
-// instructions per wave and 64-token chunk (930 on the heaviest strip, which sets the pace).  This kernel is built to need about half:
+// What the measurements of round 4 say about the scan kernels of this repo (profiles/r04_a5_a6_experiments.txt): at two waves per SIMD the
+// pipes of a SIMD hardly hide behind each other -- 400 padding VALU instructions per chunk cost their full 4.4 cycles each, the LDS store
+// pass of the staging its full time, a matrix instruction its 16 cycles -- so a chunk costs about the SUM of what it asks of the VALU,
+// the matrix pipe and the LDS, and a workgroup moves at the pace of its heaviest wave.  The row-strip kernel (ssd_mfma.hip) is paced by
+// its fourth strip (930 instructions per 64-token chunk against 650 on the first).  This kernel gives every wave the same ~530:
 //
 //   * wave w of a head owns the output COLUMNS u in [16 w, 16 w + 16) and the matching slice S[k = 0..127][u] of the running state (eight
 //     16 x 16 accumulator tiles).  The bf16 pack of that slice IS the A operand of S_in^T Q^T: the state never goes through LDS, is never

@@ -1048,7 +1048,6 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   if (dry) return OMK_OK;
   if (ssd_v6_applies(g)) return ssd_v6_launch(g, stream);
   if (ssd_a6_applies(g)) return ssd_a6_launch(g, stream);
-  if (ssd_a5_applies(g)) return ssd_a5_launch(g, stream);
   // one head (x one segment of the sequence) per workgroup, two workgroups per CU
   GScan a = g;
   const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QC - 1) / QC};

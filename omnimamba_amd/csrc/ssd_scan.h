@@ -104,10 +104,8 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = 
 // the hi + lo ("precise") forward scan (ssd_v6.hip): OMK_SSD_PRECISE=1
 bool ssd_v6_applies(const GScan& g);
 int ssd_v6_launch(const GScan& g, omk_stream stream);
-// the column-slice class A kernel (ssd_a5.hip): state slices in registers, 16-token sub-chunks, one workgroup per head pair
-bool ssd_a5_applies(const GScan& g);
-int ssd_a5_launch(const GScan& g, omk_stream stream);
-// the same with 32-token sub-chunks and the intra tiles shared through LDS (ssd_a6.hip)
+// the column-slice class A kernel (ssd_a6.hip): state slices in registers, 32-token sub-chunks, intra tiles shared through LDS, one
+// workgroup per head pair (its 16-token predecessor ssd_a5.hip and their experiments: git history, profiles/r04_a5_a6_experiments.txt)
 bool ssd_a6_applies(const GScan& g);
 int ssd_a6_launch(const GScan& g, omk_stream stream);
 int ssd_a6_state_only(const GScan& g, omk_stream stream);

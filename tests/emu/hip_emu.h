@@ -253,25 +253,6 @@ inline void op_mfma16(Wave& w) {
   for (int l = 0; l < WAVE; l++)
     for (int r = 0; r < 4; r++) w.d32[l][r] = C[(l >> 4) * 4 + r][l & 15];
 }
-// v_mfma_f32_16x16x16_bf16: A[i=l&15][k=4*(l>>4)+e], B[k=4*(l>>4)+e][j=l&15], e = 0..3, C/D as above
-inline void op_mfma16k16(Wave& w) {
-  static float A[16][16], B[16][16], C[16][16];
-  for (int l = 0; l < WAVE; l++)
-    for (int e = 0; e < 4; e++) {
-      A[l & 15][4 * (l >> 4) + e] = bf2f(w.a16[l][e]);
-      B[4 * (l >> 4) + e][l & 15] = bf2f(w.b16[l][e]);
-    }
-  for (int l = 0; l < WAVE; l++)
-    for (int r = 0; r < 4; r++) C[(l >> 4) * 4 + r][l & 15] = w.c32[l][r];
-  for (int i = 0; i < 16; i++)
-    for (int j = 0; j < 16; j++) {
-      float acc = C[i][j];
-      for (int k = 0; k < 16; k++) acc = fmaf(A[i][k], B[k][j], acc);
-      C[i][j] = acc;
-    }
-  for (int l = 0; l < WAVE; l++)
-    for (int r = 0; r < 4; r++) w.d32[l][r] = C[(l >> 4) * 4 + r][l & 15];
-}
 // v_mfma_f32_16x16x4_f32 (fp32 operands, one block): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D[row=(l>>4)*4+r][col=l&15];
 // the operands arrive in c32[l][4] (A) and c32[l][5] (B)
 inline void op_mfma16_f32(Wave& w) {
