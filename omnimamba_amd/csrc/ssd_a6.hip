@@ -21,8 +21,8 @@
 // Contraction-slot bookkeeping (an MFMA sums over its 32 slots in any order as long as A and B agree):
 //   state tile t (0..7), accumulator register r on lane (n = lane & 15, g = lane >> 4)  <->  u = 16 w + n,
 //   k = 32 (t >> 1) + 8 g + 4 (t & 1) + r -- the registers of tiles 2i, 2i + 1 are k = 32 i + 8 g + 0..7, what a 16-byte row read of Q hands
-//   lane (l, g) for k-step i.  The K tile keeps the two 8-byte halves of a 16-byte segment swapped in rows with bit 2 set, so that the
-//   transposed reads of the state update (which fetch ONE half per lane) spread over all banks.
+//   lane (l, g) for k-step i.  (The transposed reads of the state update fetch ONE 8-byte half of a segment per lane: 2-way bank
+//   conflicts.  Swapping the halves in rows with bit 2 set removes them and costs 8-byte K stores / row reads: measured neutral.)
 #include <cstdlib>
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
@@ -35,7 +35,7 @@ namespace omk {
 
 constexpr int QA6 = 64;    // tokens staged per barrier
 struct SmemA6 {
-  uint16_t K[3][QA6 * 128];       // kx3 swizzle + half swap (kxh)
+  uint16_t K[3][QA6 * 128];       // kx3 swizzle
   uint16_t Q[3][QA6 * 128];       // kx3 swizzle
   uint16_t U[2][2][QA6 * 64];     // [buffer][head of the pair], ux3 swizzle
   u32x4 M[2][2][6][64];           // [buffer][head][record][lane]: per sub-chunk jj: 3 jj + 0 = {hi, lo} of tile (strip 0, block 0);
@@ -46,8 +46,6 @@ struct SmemA6 {
 };
 static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
 
-// K tile element offset: kx3 with the 8-byte halves of a segment swapped in rows with bit 2 set
-__device__ __forceinline__ int kxh(int row, int col) { return kx3(row, col) ^ (((row >> 2) & 1) << 2); }
 
 // STATE: the state-only pass (no output, no S_in^T Q^T, no intra block): window-boundary images (GScan::dump) and / or the state behind
 // the sequence, with exactly the arithmetic the scan proper carries its state with
@@ -105,12 +103,10 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 2; r++) ru[r] = buf_ld16(Ur, uvo, su + 2u * (uint32_t)((rev ? 32 * (1 - r) : 32 * r) * usl));
   };
   const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
-  const int hk = ((rowk >> 2) & 1) << 2;   // half swap of the thread's K rows (rowk and rowk + 32: the same bit 2)
   auto commit_kq = [&](int kb) {   // rows past the end arrived as zeros
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk]) = u32x2{rk[r][0], rk[r][1]};
-      *reinterpret_cast<u32x2*>(&sm.K[kb][(o_ck + 32 * 128 * r) ^ hk ^ 4]) = u32x2{rk[r][2], rk[r][3]};
+      st16(&sm.K[kb][o_ck + 32 * 128 * r], rk[r]);
       if (!STATE) st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
     }
   };
@@ -142,12 +138,11 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   };
 
   // ---- lane-constant LDS element offsets
-  int o_rd[4], o_kt[4], o_kr[4];
+  int o_rd[4], o_kt[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    o_rd[i] = kx3(t16, 32 * i + 8 * g16);                               // 16-byte row reads of Q: row t16, k = 32 i + 8 g16 ..
-    o_kt[i] = kxh(4 * g16 + (t16 >> 2), 32 * i + 8 * (t16 & 3));        // K^T transpose reads: rows 4 g16 + 0..3, k = 32 i + 8 q (+ 4 for odd tiles: ^ 4)
-    o_kr[i] = kxh(t16, 32 * i + 8 * g16);                               // 8-byte row reads of K (tile build): row t16, k = 32 i + 8 g16 .. + 3 (next four: ^ 4)
+    o_rd[i] = kx3(t16, 32 * i + 8 * g16);                               // 16-byte row reads of Q / K: row t16, k = 32 i + 8 g16 ..
+    o_kt[i] = kx3(4 * g16 + (t16 >> 2), 32 * i + 8 * (t16 & 3));        // K^T transpose reads: rows 4 g16 + 0..3, k = 32 i + 8 q (+ 4 for odd tiles)
   }
   const int o_uf = ux3(4 * g16 + (t16 >> 2), 16 * w + 4 * (t16 & 3));   // U transpose read: rows 4 g16 + 0..3, columns 16 w + 0..15
   const int o_xu = ux3(t16, 16 * w + 4 * g16);                          // x of the lane's output row, columns 16 w + 4 g16 ..
@@ -187,10 +182,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   // ---- M tiles of one chunk (buffers kb: K / Q / scalars, mb: tiles).  Wave roles: w = 0 none (it computes the token scalars),
   // w = 3 the tiles (0, 0) of both sub-chunks, w = 1 / 2 the tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds
   // s = 4 g16 + r of its own l = t16.
-  auto krow = [&](int kb, int row0, int i) -> u32x4 {   // K[row0 + t16][32 i + 8 g16 .. + 7] out of the half-swapped tile
-    const u32x2 lo = *reinterpret_cast<const u32x2*>(&sm.K[kb][o_kr[i] + 128 * row0]);
-    const u32x2 hi = *reinterpret_cast<const u32x2*>(&sm.K[kb][(o_kr[i] ^ 4) + 128 * row0]);
-    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  auto krow = [&](int kb, int row0, int i) -> u32x4 {   // K[row0 + t16][32 i + 8 g16 .. + 7]
+    return ld16(&sm.K[kb][o_rd[i] + 128 * row0]);
   };
   auto decay_tile = [&](const f32x4& gt, float cs_l, const f32x4& lw4, bool diag, uint32_t (&hi)[2], uint32_t (&lo)[2]) {
     float v[4];
@@ -293,8 +286,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     f.dec = sm.dec[kb][hh][jj];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * r0]);
-      f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][(o_kt[t >> 1] ^ (4 * (t & 1))) + 128 * (r0 + 16)]);
+      f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * r0]);
+      f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * (r0 + 16)]);
     }
     if (STATE) return;
     f.m0 = sm.M[ub][hh][3 * jj][lane];
