@@ -338,3 +338,30 @@ def test_training_forward_on_a_layout_the_mfma_kernel_cannot_take_falls_back(dev
     y.float().sum().backward()
     y0 = S.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), 256, D=d(D), dt_bias=d(dtb), dt_softplus=True)
     assert rel(y.float().cpu(), y0.float().cpu()) < 6e-3 and xo.grad is not None and torch.isfinite(xo.grad.float()).all()
+
+
+@pytest.mark.parametrize("L", [1, 5, 31, 33, 63, 65, 127, 129, 191])
+def test_ssd_column_slice_kernel_short_and_ragged_sequences(dev, L):
+    """ssd_a6.hip stages two chunks ahead and builds its intra tiles a chunk ahead: sequences shorter than one chunk, ragged last
+    chunks and lengths around the 32-token sub-chunk and 128-token window boundaries (rows behind the end arrive as zeros, their
+    weights are zero, their stores are dropped).  Forward with final state and backward (dx scan, window-state dumps) vs the oracle."""
+    import omnimamba_amd.ssd_combined as S
+    H, P, N, G = 4, 64, 128, 2
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, torch.bfloat16, seed=100 + L)
+    A = -(torch.rand(H, generator=torch.Generator().manual_seed(L)) * 15 + 1)
+    d = lambda t: None if t is None else t.to(dev)
+    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb, init)]
+    y, fin = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6],
+                                         initial_states=leaves[7], dt_softplus=True, return_final_states=True)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).bfloat16()
+    y.backward(gy.to(dev))
+    ref = [t.clone().float().requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb, init)]
+    y0, f0 = O.ssd_ref_chunked(ref[0], ref[1], ref[2], ref[3], ref[4], 64, D=ref[5], dt_bias=ref[6], initial_states=ref[7], dt_softplus=True,
+                               return_final_states=True)
+    y0.backward(gy.float())
+    assert rel(y.float().cpu(), y0) < 6e-3 and rel(fin.cpu(), f0) < 1e-3
+    assert rel(leaves[0].grad.float().cpu(), ref[0].grad) < 8e-3                      # dx
+    assert rel(leaves[3].grad.float().cpu(), ref[3].grad) < 8e-3 and rel(leaves[4].grad.float().cpu(), ref[4].grad) < 8e-3   # dB, dC
+    assert rel(leaves[7].grad.float().cpu(), ref[7].grad) < 8e-3                      # d(initial_states)
+    for t in leaves:
+        assert torch.isfinite(t.grad.float()).all()
