@@ -12,10 +12,11 @@
 //   * the chunk is walked in SUB-CHUNKS of 32 tokens.  Per sub-chunk: one pack of the state (16 cvt), 8 MFMAs for S_in^T Q^T (two strips of
 //     16 rows), 8 MFMAs for the state update with all 32 contraction slots carrying tokens (A = two transposed K fragments, B = the
 //     ws-scaled U fragments of the two strips), 3 MFMAs for the intra block.
-//   * the intra block M (3 tiles of 16 x 16 per sub-chunk: two diagonal, one full) does not depend on the column slice, so ONE wave of the
-//     head builds each tile (G = K Q^T, decay, causal mask, D on the diagonal, bf16 hi + lo) and leaves it in LDS as a ready B operand.
-//     Tiles are built one chunk AHEAD (K / Q / token scalars are staged two chunks ahead of their use, three LDS buffers), so the one
-//     barrier per chunk that the staging needs anyway also publishes them.
+//   * the intra block M (3 tiles of 16 x 16 per sub-chunk: two diagonal, one full) does not depend on the column slice, and its G = K Q^T
+//     not even on the head of the pair: ONE wave of the workgroup builds each of the six tiles of a chunk for both heads (4 MFMAs, then
+//     per head: decay as row factor x column factor prepared by the scalar wave, causal mask, D on the diagonal, bf16 hi + lo) and
+//     leaves them in LDS as ready B operands.  Tiles are built one chunk AHEAD (K / Q / token scalars are staged two chunks ahead of
+//     their use, three LDS buffers), so the one barrier per chunk that the staging needs anyway also publishes them.
 //
 // One workgroup = 8 waves = the two heads of a head PAIR (the group's K / Q tiles are staged once for both), one workgroup per CU.
 // Contraction-slot bookkeeping (an MFMA sums over its 32 slots in any order as long as A and B agree):
@@ -40,9 +41,16 @@ struct SmemA6 {
   uint16_t U[2][2][QA6 * 64];     // [buffer][head of the pair], ux3 swizzle
   u32x4 M[2][2][6][64];           // [buffer][head][record][lane]: per sub-chunk jj: 3 jj + 0 = {hi, lo} of tile (strip 0, block 0);
                                   // 3 jj + 1 = {hi of (1, 0), hi of (1, 1)}; 3 jj + 2 = {lo of (1, 0), lo of (1, 1)}
-  f32x2 rv[3][2][QA6];            // [buffer][head][chunk row]: {cs, rl}
-  float lw[3][2][QA6], ws[3][2][QA6];
+  float rl[3][2][QA6], ws[3][2][QA6];   // [buffer][head][chunk row]: the row's factor of S_in^T Q^T, the weight of its state-update term
   float dec[3][2][2];             // decay over sub-chunk jj
+  // the tile builders' scalars, [tile buffer][head][chunk row]: the decay exp2(cs_l - cs_s) w_s of an M entry as a PRODUCT of a row
+  // and a column factor around a reference inside the tile (diagonal tiles: the middle of the 16-token block, rfd / cfd; the full
+  // tile: the block boundary, fo = the column factor in block 0 and the row factor in block 1 of a sub-chunk) -- three exponentials
+  // per token in the scalar wave instead of four per lane and tile in the builders.  wide[][] != 0: a block of the chunk decays by
+  // more than 2^-90 and the factors could leave the fp32 range; the arrays then hold the exponents (cs_l, log2 w_s - cs_s) and the
+  // builders take the exponential of their sum per entry, as they did before round 4
+  float rfd[2][2][QA6], cfd[2][2][QA6], fo[2][2][QA6];
+  int wide[2][2];
 };
 static_assert(sizeof(SmemA6) <= 160 * 1024, "one workgroup per CU");
 
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   };
   const float Ah = a.A[h];
   const float Ah2 = Ah * LOG2E;
-  auto scalars = [&](int kb) {   // waves with w == 0; lanes = rows of the staged K / Q / dt chunk of head hh
+  auto scalars = [&](int kb, int mb) {   // waves with w == 0; lanes = rows of the staged K / Q / dt chunk of head hh
     {
       const int t = stlo + rowtok(lane);
       const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
@@ -128,13 +136,28 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const float e31 = wave_read_lane(cs, 31), e63 = wave_read_lane(cs, 63);
     const float csb = lane < 32 ? 0.f : e31;    // prefix in front of the lane's sub-chunk
     const float cse = lane < 32 ? e31 : e63;    // prefix at its end
-    // dx scan: the output row is scaled by dt'_l -- folded into the row's two scalars (the factor of S_in^T Q^T and the exponent of the
-    // M build), so that D dy can ride on the diagonal of M unscaled like D x does in the forward
-    if (MODE == GS_DX) sm.rv[kb][hh][lane] = f32x2{cs + log2_fast(rdt), exp2_fast(cs - csb) * rdt};
-    else sm.rv[kb][hh][lane] = f32x2{cs, exp2_fast(cs - csb)};
-    sm.lw[kb][hh][lane] = log2_fast(rwv) - cs;
+    // dx scan: the output row is scaled by dt'_l -- folded into the row's two factors (of S_in^T Q^T and of the M build), so that
+    // D dy can ride on the diagonal of M unscaled like D x does in the forward
+    const float rsc = MODE == GS_DX ? rdt : 1.f;
+    sm.rl[kb][hh][lane] = exp2_fast(cs - csb) * rsc;
     sm.ws[kb][hh][lane] = rwv * exp2_fast(cse - cs);
     if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = exp2_fast(cse - csb);
+    if (STATE) return;
+    const int b16 = lane & ~15;
+    const bool blk1 = (lane & 16) != 0;
+    const float cmid = shfl(cs, b16 + 7), cbnd = shfl(cs, blk1 ? b16 - 1 : b16 + 15);
+    const bool wide = ballot_any(fabsf(cs - cmid) > 90.f);
+    if (!wide) {
+      sm.rfd[mb][hh][lane] = exp2_fast(cs - cmid) * rsc;
+      sm.cfd[mb][hh][lane] = rwv * exp2_fast(cmid - cs);
+      sm.fo[mb][hh][lane] = blk1 ? exp2_fast(cs - cbnd) * rsc : rwv * exp2_fast(cbnd - cs);
+    } else {
+      const float csr = MODE == GS_DX ? cs + log2_fast(rdt) : cs, lw = log2_fast(rwv) - cs;
+      sm.rfd[mb][hh][lane] = csr;
+      sm.cfd[mb][hh][lane] = lw;
+      sm.fo[mb][hh][lane] = blk1 ? csr : lw;
+    }
+    if (lane == 0) sm.wide[mb][hh] = wide ? 1 : 0;
   };
 
   // ---- lane-constant LDS element offsets
@@ -172,68 +195,80 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
         accS[t][r] = load_rt(a.init, (int64_t)b * a.isb + (int64_t)h * a.ish + (int64_t)su * a.isu + (int64_t)k * a.isk, a.init_dt);
       }
   }
-  const float Dh = (DFOLD && a.D) ? load_rt(a.D, (int64_t)h * a.Dsh, a.D_dt) : 0.f;
   f32x4 Du = {0.f, 0.f, 0.f, 0.f};   // D of the lane's four output columns (epilogue form)
   if (!DFOLD && a.D) {
 #pragma unroll
     for (int r = 0; r < 4; r++) Du[r] = load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)(16 * w + 4 * g16 + r) * a.Dsp, a.D_dt);
   }
 
-  // ---- M tiles of one chunk (buffers kb: K / Q / scalars, mb: tiles).  Wave roles: w = 0 none (it computes the token scalars),
-  // w = 3 the tiles (0, 0) of both sub-chunks, w = 1 / 2 the tiles (1, 0) and (1, 1) of sub-chunk 0 / 1.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds
-  // s = 4 g16 + r of its own l = t16.
+#ifdef OMK_PHASE_PROF   // developer build (tools/phase_prof_a6.py): s_memtime deltas per phase, workgroup 0
+  uint64_t pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0;
+#define PT6(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
+#define PTW(i, v) do { if (prof) { asm volatile("v_readfirstlane_b32 s0, %0" :: "v"(v) : "s0"); PT6(i); } } while (0)
+  uint64_t tprev = prof ? clock64_() : 0;
+  const uint64_t t_core0 = tprev, t_ref0 = prof ? __builtin_readsteadycounter() : 0;
+#else
+#define PT6(i) do { } while (0)
+#define PTW(i, v) do { } while (0)
+#endif
+  // ---- M tiles of one chunk (buffers kb: K / Q, mb: tiles and their scalars).  G = K Q^T is the same for the two heads of the pair:
+  // each of the six tiles (sub-chunk jj: (0, 0), (1, 0), (1, 1)) is one wave's -- wave (hh, w) builds tile w - 1 of sub-chunk jj = hh
+  // for BOTH heads (4 MFMAs, then per head the decay, the causal mask, D on the diagonal, bf16 hi + lo); the waves w = 0 compute
+  // the token scalars.  G^T[s][l]: A = K rows s, B = Q rows l; the lane holds s = 4 g16 + r of its own l = t16.
   auto krow = [&](int kb, int row0, int i) -> u32x4 {   // K[row0 + t16][32 i + 8 g16 .. + 7]
     return ld16(&sm.K[kb][o_rd[i] + 128 * row0]);
   };
-  auto decay_tile = [&](const f32x4& gt, float cs_l, const f32x4& lw4, bool diag, uint32_t (&hi)[2], uint32_t (&lo)[2]) {
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      v[r] = gt[r] * exp2_fast(cs_l + lw4[r]);
-      if (diag) {
-        if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh : 0.f);
-        else v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int p2 = 0; p2 < 2; p2++) {
-      hi[p2] = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
-      lo[p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi[p2]), v[2 * p2 + 1] - bf_hi(hi[p2]));
-    }
-  };
+  float Dh2[2] = {0.f, 0.f};
+  if (DFOLD && a.D) {
+    Dh2[0] = load_rt(a.D, (int64_t)(2 * hp) * a.Dsh, a.D_dt);
+    Dh2[1] = load_rt(a.D, (int64_t)(2 * hp + 1) * a.Dsh, a.D_dt);
+  }
   auto build_tiles = [&](int kb, int mb) {
-    if (STATE || w == 0) return;   // (the wave that computes the token scalars)
-    if (w == 3) {
+    if (STATE || w == 0) return;   // (the waves that compute the token scalars)
+    const int jj = hh, tt = w - 1;
+    const int rb = 32 * jj + (tt >= 1 ? 16 : 0), cb = 32 * jj + (tt == 2 ? 16 : 0);   // first row (l) / column (s) of the tile
+    const bool diag = tt != 1;
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-     for (int jj = 0; jj < 2; jj++) {
-      const int r0 = 32 * jj;
-      f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(krow(kb, cb, i)), as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * rb])), gt);
+    PTW(7, gt[0]);
 #pragma unroll
-      for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(krow(kb, r0, i)), as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * r0])), gt);
-      const float cs_l = sm.rv[kb][hh][r0 + t16][0];
-      const f32x4 lw4 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 4 * g16]);
-      uint32_t hi[2], lo[2];
-      decay_tile(gt, cs_l, lw4, true, hi, lo);
-      sm.M[mb][hh][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
-     }
-    } else {
-      const int jj = w - 1;
-      const int r0 = 32 * jj;
-      f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    for (int h2 = 0; h2 < 2; h2++) {
+      const float* rfa = diag ? sm.rfd[mb][h2] : sm.fo[mb][h2];
+      const float* cfa = diag ? sm.cfd[mb][h2] : sm.fo[mb][h2];
+      const float rf = rfa[rb + t16];
+      const f32x4 cf = *reinterpret_cast<const f32x4*>(&cfa[cb + 4 * g16]);
+      const bool wide = uniform_i(sm.wide[mb][h2]) != 0;
+      float v[4];
+      if (wide) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const s16x8 qf = as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * (r0 + 16)]));
-        g0 = mfma16x16x32_bf16(as_s16x8(krow(kb, r0, i)), qf, g0);
-        g1 = mfma16x16x32_bf16(as_s16x8(krow(kb, r0 + 16, i)), qf, g1);
+        for (int r = 0; r < 4; r++) v[r] = gt[r] * exp2_fast(rf + cf[r]);
+      } else {
+        const f32x4 gc = gt * cf * rf;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = gc[r];
       }
-      const float cs_l = sm.rv[kb][hh][r0 + 16 + t16][0];
-      const f32x4 lw0 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 4 * g16]);
-      const f32x4 lw1 = *reinterpret_cast<const f32x4*>(&sm.lw[kb][hh][r0 + 16 + 4 * g16]);
-      uint32_t h0[2], l0[2], h1[2], l1[2];
-      decay_tile(g0, cs_l, lw0, false, h0, l0);
-      decay_tile(g1, cs_l, lw1, true, h1, l1);
-      sm.M[mb][hh][3 * jj + 1][lane] = u32x4{h0[0], h0[1], h1[0], h1[1]};
-      sm.M[mb][hh][3 * jj + 2][lane] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      if (diag) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh2[h2] : 0.f);
+          else v[r] = (4 * g16 + r <= t16) ? v[r] : 0.f;
+        }
+      }
+      uint32_t hi[2], lo[2];
+#pragma unroll
+      for (int p2 = 0; p2 < 2; p2++) {
+        hi[p2] = pack_bf16x2(v[2 * p2], v[2 * p2 + 1]);
+        lo[p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi[p2]), v[2 * p2 + 1] - bf_hi(hi[p2]));
+      }
+      PTW(8 + h2, lo[1]);
+      if (tt == 0) sm.M[mb][h2][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+      else {
+        uint32_t* mh = reinterpret_cast<uint32_t*>(&sm.M[mb][h2][3 * jj + 1][lane]) + 2 * (tt - 1);
+        *reinterpret_cast<u32x2*>(mh) = u32x2{hi[0], hi[1]};
+        *reinterpret_cast<u32x2*>(mh + 4 * 64) = u32x2{lo[0], lo[1]};
+      }
     }
   };
 
@@ -242,10 +277,10 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   prefetch_u(chunk_lo(c0));
   commit_kq(0);
   commit_u(0);
-  if (w == 0) scalars(0);
+  if (w == 0) scalars(0, 0);
   prefetch_kq(chunk_lo(clipc(c0 + 1)));
   commit_kq(1);
-  if (w == 0) scalars(1);
+  if (w == 0) scalars(1, 1);
   block_sync();
   build_tiles(0, 0);
   prefetch_kq(chunk_lo(clipc(c0 + 2)));
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   // and the token scalars.  The operands of phase 2 are requested in front of phase 1 of the same sub-chunk, the row fragments of the
   // next sub-chunk in front of phase 2, so every LDS read has a phase of work between request and use.
   struct FragR { u32x4 q0[4], q1[4]; };
-  struct FragC { s16x4 u0, u1, kt[8][2]; f32x2 rv0, rv1; f32x4 ws0, ws1; float dec; u32x4 m0, mh, ml; u32x2 x0, x1; };
+  struct FragC { s16x4 u0, u1, kt[8][2]; float rl0, rl1; f32x4 ws0, ws1; float dec; u32x4 m0, mh, ml; u32x2 x0, x1; };
   auto load_rows = [&](FragR& f, int kb, int jj) {
     if (STATE) return;
     if (OMK_A6_ABL & 1) { asm volatile("" : "+v"(f.q0[0]), "+v"(f.q0[1]), "+v"(f.q0[2]), "+v"(f.q0[3]), "+v"(f.q1[0]), "+v"(f.q1[1]), "+v"(f.q1[2]), "+v"(f.q1[3])); return; }
@@ -273,7 +308,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   };
   auto load_cols = [&](FragC& f, int kb, int ub, int jj) {
     if (OMK_A6_ABL & 1) {
-      asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.rv0), "+v"(f.rv1), "+v"(f.ws0), "+v"(f.ws1), "+v"(f.dec), "+v"(f.m0), "+v"(f.mh), "+v"(f.ml));
+      asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.rl0), "+v"(f.rl1), "+v"(f.ws0), "+v"(f.ws1), "+v"(f.dec), "+v"(f.m0), "+v"(f.mh), "+v"(f.ml));
 #pragma unroll
       for (int t = 0; t < 8; t++) asm volatile("" : "+v"(f.kt[t][0]), "+v"(f.kt[t][1]));
       return;
@@ -293,8 +328,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     f.m0 = sm.M[ub][hh][3 * jj][lane];
     f.mh = sm.M[ub][hh][3 * jj + 1][lane];
     f.ml = sm.M[ub][hh][3 * jj + 2][lane];
-    f.rv0 = sm.rv[kb][hh][r0 + t16];
-    f.rv1 = sm.rv[kb][hh][r0 + 16 + t16];
+    f.rl0 = sm.rl[kb][hh][r0 + t16];
+    f.rl1 = sm.rl[kb][hh][r0 + 16 + t16];
     if (!DFOLD) {
       f.x0 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * r0]);
       f.x1 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * (r0 + 16)]);
@@ -372,10 +407,13 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const f32x4 accB0 = mfma16x16x32_bf16(u00, as_s16x8(f.m0), f32x4{0.f, 0.f, 0.f, 0.f});
     f32x4 accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.mh), f32x4{0.f, 0.f, 0.f, 0.f});
     accB1 = mfma16x16x32_bf16(u01, as_s16x8(f.ml), accB1);
-    out_rows(accA0 * f.rv0[1] + accB0, 32 * jj + t16, tlo, f.x0);
-    out_rows(accA1 * f.rv1[1] + accB1, 32 * jj + 16 + t16, tlo, f.x1);
+    out_rows(accA0 * f.rl0 + accB0, 32 * jj + t16, tlo, f.x0);
+    out_rows(accA1 * f.rl1 + accB1, 32 * jj + 16 + t16, tlo, f.x1);
   };
 
+#ifdef OMK_PHASE_PROF
+  tprev = prof ? clock64_() : 0;
+#endif
   FragR fr;
   FragC fc;
   load_rows(fr, 0, 0);
@@ -399,10 +437,14 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     phase2(fc, 0, tlo);
     OMK_SCHED_FENCE();
+    PT6(0);
     // ---- the tiles of the next chunk, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U)
     if (c + 1 < c1) build_tiles(kb1, ub1);
+    PT6(1);
     if (!(OMK_A6_ABL & 2)) { commit_kq(kb2); commit_u(ub1); }
-    if (w == 0) scalars(kb2);
+    PT6(2);
+    if (w == 0) scalars(kb2, ub0);
+    PT6(3);
 #ifndef OMK_A6_LATEPF
     if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }   // a whole iteration ahead of their commit
 #endif
@@ -412,7 +454,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     phase1(fr, false, dp);
     OMK_SCHED_FENCE();
+    PT6(4);
     if (!(OMK_A6_ABL & 8)) block_sync();
+    PT6(5);
     load_rows(fr, kb1, 0);
 #ifdef OMK_A6_LATEPF
     if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }
@@ -420,8 +464,17 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     phase2(fc, 1, tlo);
     OMK_SCHED_FENCE();
+    PT6(6);
     { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
   }
+#ifdef OMK_PHASE_PROF
+  if (prof) {
+    pt[10] = clock64_() - t_core0;
+    pt[11] = (__builtin_readsteadycounter() - t_ref0) | ((uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 40);   // HW_ID above bit 40
+  }
+  if (prof && lane == 0)
+    for (int i = 0; i < 12; i++) a.prof[wave * 12 + i] = pt[i];
+#endif
   if (a.fin && seg == a.nseg - 1) {
     const float extra = a.fin_extra_decay ? expf(dtrow[0] * Ah) : 1.f;
 #pragma unroll

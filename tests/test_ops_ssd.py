@@ -365,3 +365,32 @@ def test_ssd_column_slice_kernel_short_and_ragged_sequences(dev, L):
     assert rel(leaves[7].grad.float().cpu(), ref[7].grad) < 8e-3                      # d(initial_states)
     for t in leaves:
         assert torch.isfinite(t.grad.float()).all()
+
+
+def test_ssd_column_slice_kernel_extreme_decays_take_the_exponent_path(dev):
+    """ssd_a6.hip builds the decay of an intra tile as (row factor) x (column factor) around a reference inside the tile; a head whose
+    16-token blocks decay by more than 2^-90 would leave the fp32 range with that, so its scalar wave hands the builders exponents
+    instead (SmemA6::wide) -- per head and chunk.  Heads here: moderate, extreme (dt |A| ~ 16 per token), around the threshold, and
+    one that switches inside the sequence; the forward, the final state and dx against the fp64 oracle."""
+    import omnimamba_amd.ssd_combined as S
+    Bsz, L, H, P, N, G = 1, 200, 4, 64, 128, 1
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(Bsz, L, H, P, N, G, torch.bfloat16, seed=77)
+    A = torch.tensor([-2.0, -16.0, -7.8, -12.0])
+    dt = torch.ones(Bsz, L, H) + 0.02 * torch.randn(Bsz, L, H, generator=torch.Generator().manual_seed(3))
+    dt[:, :, 0] *= 0.05
+    dt[:, 100:, 3] *= 0.01            # head 3: extreme for the first 100 tokens, slow behind
+    dt = dt.bfloat16()
+    leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, init)]
+    y, fin = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], initial_states=leaves[6],
+                                         return_final_states=True)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).bfloat16()
+    y.backward(gy.to(dev))
+    ref = [t.clone().double().requires_grad_() for t in (x, dt, A, Bm, Cm, D, init)]
+    y0, f0 = O.ssd_ref_chunked(ref[0], ref[1], ref[2], ref[3], ref[4], 64, D=ref[5], initial_states=ref[6], return_final_states=True,
+                               compute_dtype=torch.float64)
+    y0.backward(gy.double())
+    assert torch.isfinite(y.float()).all() and torch.isfinite(fin).all()
+    for h in range(H):
+        assert rel(y[:, :, h].float().cpu(), y0[:, :, h]) < 6e-3, h
+        assert rel(fin[:, h].cpu(), f0[:, h]) < 1e-3, h
+        assert rel(leaves[0].grad[:, :, h].float().cpu(), ref[0].grad[:, :, h]) < 8e-3, h
