@@ -224,24 +224,41 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     Dh2[0] = load_rt(a.D, (int64_t)(2 * hp) * a.Dsh, a.D_dt);
     Dh2[1] = load_rt(a.D, (int64_t)(2 * hp + 1) * a.Dsh, a.D_dt);
   }
-  auto build_tiles = [&](int kb, int mb) {
+  // The builder's LDS reads (operands of G, the factors of both heads) are requested a phase before its arithmetic
+  // (build_loads in front of phase 2 of sub-chunk 0, build_tiles behind it): on their own they were a chain of three exposed LDS
+  // round trips, 1300 of the 5600 cycles of a chunk (tools/phase_prof_a6.py).
+  struct FragB { u32x4 k[4], q[4]; };
+  const int bjj = hh, btt = w - 1;                                                          // the wave's tile: sub-chunk, (0, 0) / (1, 0) / (1, 1)
+  const int brb = 32 * bjj + (btt >= 1 ? 16 : 0), bcb = 32 * bjj + (btt == 2 ? 16 : 0);    // its first row (l) / column (s)
+  const bool bdiag = btt != 1;
+  auto build_loads = [&](FragB& f, int kb, int mb) {
     if (STATE || w == 0) return;   // (the waves that compute the token scalars)
-    const int jj = hh, tt = w - 1;
-    const int rb = 32 * jj + (tt >= 1 ? 16 : 0), cb = 32 * jj + (tt == 2 ? 16 : 0);   // first row (l) / column (s) of the tile
-    const bool diag = tt != 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { f.k[i] = krow(kb, bcb, i); f.q[i] = ld16(&sm.Q[kb][o_rd[i] + 128 * brb]); }
+  };
+  auto build_tiles = [&](const FragB& f, int mb) {
+    if (STATE || w == 0) return;
+    float rf2[2];
+    f32x4 cf2[2];
+    int wide2[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {   // (requested in front of the MFMAs)
+      const float* rfa = bdiag ? sm.rfd[mb][h2] : sm.fo[mb][h2];
+      const float* cfa = bdiag ? sm.cfd[mb][h2] : sm.fo[mb][h2];
+      rf2[h2] = rfa[brb + t16];
+      cf2[h2] = *reinterpret_cast<const f32x4*>(&cfa[bcb + 4 * g16]);
+      wide2[h2] = sm.wide[mb][h2];
+    }
     f32x4 gt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(krow(kb, cb, i)), as_s16x8(ld16(&sm.Q[kb][o_rd[i] + 128 * rb])), gt);
+    for (int i = 0; i < 4; i++) gt = mfma16x16x32_bf16(as_s16x8(f.k[i]), as_s16x8(f.q[i]), gt);
     PTW(7, gt[0]);
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++) {
-      const float* rfa = diag ? sm.rfd[mb][h2] : sm.fo[mb][h2];
-      const float* cfa = diag ? sm.cfd[mb][h2] : sm.fo[mb][h2];
-      const float rf = rfa[rb + t16];
-      const f32x4 cf = *reinterpret_cast<const f32x4*>(&cfa[cb + 4 * g16]);
-      const bool wide = uniform_i(sm.wide[mb][h2]) != 0;
+      const float rf = rf2[h2];
+      const f32x4 cf = cf2[h2];
       float v[4];
-      if (wide) {
+      if (uniform_i(wide2[h2]) != 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = gt[r] * exp2_fast(rf + cf[r]);
       } else {
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = gc[r];
       }
-      if (diag) {
+      if (bdiag) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (DFOLD) v[r] = (4 * g16 + r < t16) ? v[r] : (4 * g16 + r == t16 ? v[r] + Dh2[h2] : 0.f);
@@ -263,14 +280,15 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
         lo[p2] = pack_bf16x2(v[2 * p2] - bf_lo(hi[p2]), v[2 * p2 + 1] - bf_hi(hi[p2]));
       }
       PTW(8 + h2, lo[1]);
-      if (tt == 0) sm.M[mb][h2][3 * jj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+      if (btt == 0) sm.M[mb][h2][3 * bjj][lane] = u32x4{hi[0], hi[1], lo[0], lo[1]};
       else {
-        uint32_t* mh = reinterpret_cast<uint32_t*>(&sm.M[mb][h2][3 * jj + 1][lane]) + 2 * (tt - 1);
+        uint32_t* mh = reinterpret_cast<uint32_t*>(&sm.M[mb][h2][3 * bjj + 1][lane]) + 2 * (btt - 1);
         *reinterpret_cast<u32x2*>(mh) = u32x2{hi[0], hi[1]};
         *reinterpret_cast<u32x2*>(mh + 4 * 64) = u32x2{lo[0], lo[1]};
       }
     }
   };
+  FragB fb;
 
   // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built
   prefetch_kq(chunk_lo(c0));
@@ -282,7 +300,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   commit_kq(1);
   if (w == 0) scalars(1, 1);
   block_sync();
-  build_tiles(0, 0);
+  build_loads(fb, 0, 0);
+  build_tiles(fb, 0);
   prefetch_kq(chunk_lo(clipc(c0 + 2)));
   prefetch_u(chunk_lo(clipc(c0 + 1)));
   block_sync();
@@ -306,7 +325,11 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) f.q1[i] = ld16(&sm.Q[kb][o_rd[i] + 128 * (32 * jj + 16)]);
   };
-  auto load_cols = [&](FragC& f, int kb, int ub, int jj) {
+  // The 30 LDS reads of a sub-chunk's phase-2 operands are requested in five GROUPS, the first in front of phase 1 and one behind each of
+  // its four k-steps: a wave can have 15 LDS instructions in flight (lgkmcnt), a burst of 30 stops it from issuing anything else for
+  // two LDS latencies -- and its partner on the SIMD is doing the same thing at the same time.
+  auto load_cols = [&](FragC& f, int kb, int ub, int jj, int grp) {
+    if ((OMK_A6_ABL & 1) && grp != 0) return;
     if (OMK_A6_ABL & 1) {
       asm volatile("" : "+v"(f.u0), "+v"(f.u1), "+v"(f.rl0), "+v"(f.rl1), "+v"(f.ws0), "+v"(f.ws1), "+v"(f.dec), "+v"(f.m0), "+v"(f.mh), "+v"(f.ml));
 #pragma unroll
@@ -314,29 +337,38 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       return;
     }
     const int r0 = 32 * jj;
-    f.ws0 = *reinterpret_cast<const f32x4*>(&sm.ws[kb][hh][r0 + 4 * g16]);
-    f.ws1 = *reinterpret_cast<const f32x4*>(&sm.ws[kb][hh][r0 + 16 + 4 * g16]);
-    f.u0 = lds_read_tr16_b64(&sm.U[ub][hh][o_uf + 64 * r0]);          // U[r0 + 4 g16 + e][16 w + t16]
-    f.u1 = lds_read_tr16_b64(&sm.U[ub][hh][o_uf + 64 * (r0 + 16)]);
-    f.dec = sm.dec[kb][hh][jj];
+    if (grp == 0) {
+      f.ws0 = *reinterpret_cast<const f32x4*>(&sm.ws[kb][hh][r0 + 4 * g16]);
+      f.ws1 = *reinterpret_cast<const f32x4*>(&sm.ws[kb][hh][r0 + 16 + 4 * g16]);
+      f.u0 = lds_read_tr16_b64(&sm.U[ub][hh][o_uf + 64 * r0]);          // U[r0 + 4 g16 + e][16 w + t16]
+      f.u1 = lds_read_tr16_b64(&sm.U[ub][hh][o_uf + 64 * (r0 + 16)]);
+      f.dec = sm.dec[kb][hh][jj];
+    }
+    if (STATE ? grp == 0 : true) {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * r0]);
-      f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * (r0 + 16)]);
+      for (int t = 0; t < 8; t++) {
+        if (!STATE && (t >> 1) != (grp == 0 ? 0 : grp == 1 ? -1 : grp - 1)) continue;   // k-steps 0 | 1 | 2 | 3 in groups 0 | 2 | 3 | 4 (STATE: all in group 0)
+        f.kt[t][0] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * r0]);
+        f.kt[t][1] = lds_read_tr16_b64(&sm.K[kb][o_kt[t >> 1] + 4 * (t & 1) + 128 * (r0 + 16)]);
+      }
     }
     if (STATE) return;
-    f.m0 = sm.M[ub][hh][3 * jj][lane];
-    f.mh = sm.M[ub][hh][3 * jj + 1][lane];
-    f.ml = sm.M[ub][hh][3 * jj + 2][lane];
-    f.rl0 = sm.rl[kb][hh][r0 + t16];
-    f.rl1 = sm.rl[kb][hh][r0 + 16 + t16];
-    if (!DFOLD) {
-      f.x0 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * r0]);
-      f.x1 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * (r0 + 16)]);
+    if (grp == 1) {
+      f.m0 = sm.M[ub][hh][3 * jj][lane];
+      f.mh = sm.M[ub][hh][3 * jj + 1][lane];
+      f.ml = sm.M[ub][hh][3 * jj + 2][lane];
+    }
+    if (grp == 4) {
+      f.rl0 = sm.rl[kb][hh][r0 + t16];
+      f.rl1 = sm.rl[kb][hh][r0 + 16 + t16];
+      if (!DFOLD) {
+        f.x0 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * r0]);
+        f.x1 = *reinterpret_cast<const u32x2*>(&sm.U[ub][hh][o_xu + 64 * (r0 + 16)]);
+      }
     }
   };
   f32x4 accA0, accA1;
-  auto phase1 = [&](const FragR& f, bool dump_here, uint16_t* dp) {
+  auto phase1 = [&](const FragR& f, bool dump_here, uint16_t* dp, FragC& nf, int nkb, int nub, int njj) {   // n*: the operand groups to request
     if (STATE && !(DUMP && dump_here)) return;
     accA0 = f32x4{0.f, 0.f, 0.f, 0.f}; accA1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -350,6 +382,9 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       if (!STATE) {
         accA0 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0);
         accA1 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1);
+        OMK_SCHED_FENCE();
+        load_cols(nf, nkb, nub, njj, i + 1);
+        OMK_SCHED_FENCE();
       }
     }
   };
@@ -429,17 +464,24 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       dp = a.dump + ((((int64_t)b * a.dump_nw + (cid >> 1)) * a.H + h) << 13);
     }
     // ---- sub-chunk 0
-    load_cols(fc, kb0, ub0, 0);
+    const bool skipc = (OMK_A6_ABL & 32) && hh == 1;   // (ablation: the second head's waves only stage)
+    const bool skipb = skipc || (OMK_A6_ABL & 64);     // (ablation: no tile build)
+    if (!skipc) {
+    load_cols(fc, kb0, ub0, 0, 0);
     OMK_SCHED_FENCE();
-    phase1(fr, dump_here, dp);
+    phase1(fr, dump_here, dp, fc, kb0, ub0, 0);
     OMK_SCHED_FENCE();
-    load_rows(fr, kb0, 1);
+    }
+    if (c + 1 < c1 && !skipb) build_loads(fb, kb1, ub1);
     OMK_SCHED_FENCE();
+    if (!skipc) {
     phase2(fc, 0, tlo);
     OMK_SCHED_FENCE();
+    load_rows(fr, kb0, 1);
+    }
     PT6(0);
     // ---- the tiles of the next chunk, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U)
-    if (c + 1 < c1) build_tiles(kb1, ub1);
+    if (c + 1 < c1 && !skipb) build_tiles(fb, ub1);
     PT6(1);
     if (!(OMK_A6_ABL & 2)) { commit_kq(kb2); commit_u(ub1); }
     PT6(2);
@@ -450,19 +492,21 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
 #endif
     OMK_SCHED_FENCE();
     // ---- sub-chunk 1; the barrier of the chunk behind its last request for the current buffers
-    load_cols(fc, kb0, ub0, 1);
+    if (!skipc) {
+    load_cols(fc, kb0, ub0, 1, 0);
     OMK_SCHED_FENCE();
-    phase1(fr, false, dp);
+    phase1(fr, false, dp, fc, kb0, ub0, 1);
     OMK_SCHED_FENCE();
+    }
     PT6(4);
     if (!(OMK_A6_ABL & 8)) block_sync();
     PT6(5);
-    load_rows(fr, kb1, 0);
+    if (!skipc) load_rows(fr, kb1, 0);
 #ifdef OMK_A6_LATEPF
     if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }
 #endif
     OMK_SCHED_FENCE();
-    phase2(fc, 1, tlo);
+    if (!skipc) phase2(fc, 1, tlo);
     OMK_SCHED_FENCE();
     PT6(6);
     { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
