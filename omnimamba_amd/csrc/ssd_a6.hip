@@ -368,7 +368,14 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     }
   };
   f32x4 accA0, accA1;
-  auto phase1 = [&](const FragR& f, bool dump_here, uint16_t* dp, FragC& nf, int nkb, int nub, int njj) {   // n*: the operand groups to request
+  // Window-state images (GScan::dump) leave through a buffer resource in the segment order of ssd_tiles.h (img_off): 1 KB of consecutive
+  // bytes per store instruction.  (Measured, training forward B 8 L 4096: images as 16 rows x 64 bytes per instruction 252 us, consecutive
+  // 229 - 239 us, consecutive and issued in every chunk with the unwanted ones sent behind the end of the resource 233 - 244 us; without
+  // images 202 us.  The cost is the store path of the CU, not HBM: images aimed at one L2-resident spot cost the same.)
+  const uint32_t dump_nb = (DUMP && a.dump) ? (uint32_t)((((int64_t)a.dump_nw - 1) * a.H + 1) << 14) : 0u;
+  const BufRes Pr = make_buf((DUMP && a.dump) ? a.dump + ((((int64_t)b * a.dump_nw) * a.H + h) << 13) : nullptr, dump_nb);
+  const uint32_t pvo = 16u * (uint32_t)(256 * w + lane);   // segment (4 w + i) 64 + lane of the image (img_off in ssd_tiles.h): + 1 KB per k-step i
+  auto phase1 = [&](const FragR& f, bool dump_slot, bool dump_here, uint32_t dso, FragC& nf, int nkb, int nub, int njj) {   // n*: the operand groups to request
     if (STATE && !(DUMP && dump_here)) return;
     accA0 = f32x4{0.f, 0.f, 0.f, 0.f}; accA1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
       sp[1] = pack_bf16x2(accS[2 * i][2], accS[2 * i][3]);
       sp[2] = pack_bf16x2(accS[2 * i + 1][0], accS[2 * i + 1][1]);
       sp[3] = pack_bf16x2(accS[2 * i + 1][2], accS[2 * i + 1][3]);
-      if (DUMP && dump_here) st16(dp + su * 128 + (((4 * i + g16) ^ swzK(su)) << 3), sp);
+      if (DUMP && dump_slot && dump_here) buf_st16(Pr, sp, pvo + 1024u * (uint32_t)i, dso);
       if (!STATE) {
         accA0 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0);
         accA1 = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1);
@@ -457,11 +464,13 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     const int ub0 = (c - c0) & 1, ub1 = ub0 ^ 1;
     const int tlo = chunk_lo(c);
     bool dump_here = false;
-    uint16_t* dp = nullptr;
+    uint32_t dso = dump_nb;
     if (DUMP && a.dump) {   // window-boundary image of the state in front of this chunk, the [u][k] kx3 image ssd_cp.hip reads
       const int cid = rev ? nC - 1 - c : c;
       dump_here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
-      dp = a.dump + ((((int64_t)b * a.dump_nw + (cid >> 1)) * a.H + h) << 13);
+      if (OMK_A6_ABL & 256) dump_here = false;                                              // (ablation: no image leaves)
+      if (dump_here) dso = (uint32_t)(((int64_t)(cid >> 1) * a.H) << 14);
+      if (OMK_A6_ABL & 128) dso = dump_here ? 0u : dump_nb;                                 // (ablation: every image of a head lands on its first)
     }
     // ---- sub-chunk 0
     const bool skipc = (OMK_A6_ABL & 32) && hh == 1;   // (ablation: the second head's waves only stage)
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     if (!skipc) {
     load_cols(fc, kb0, ub0, 0, 0);
     OMK_SCHED_FENCE();
-    phase1(fr, dump_here, dp, fc, kb0, ub0, 0);
+    phase1(fr, true, dump_here, dso, fc, kb0, ub0, 0);
     OMK_SCHED_FENCE();
     }
     if (c + 1 < c1 && !skipb) build_loads(fb, kb1, ub1);
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     if (!skipc) {
     load_cols(fc, kb0, ub0, 1, 0);
     OMK_SCHED_FENCE();
-    phase1(fr, false, dp, fc, kb0, ub0, 1);
+    phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
     OMK_SCHED_FENCE();
     }
     PT6(4);

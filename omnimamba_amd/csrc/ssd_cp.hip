@@ -127,8 +127,8 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       const int q = tq + 512 * i, row = q >> 3, seg = q & 7;
       st16(&sm.X[ux3(row, seg * 8)], rx[i]);
       st16(&sm.DY[ux3(row, seg * 8)], ry[i]);
-      st16(&sm.S[q * 8], rs[i]);
-      st16(&sm.Gt[q * 8], rg[i]);
+      st16(&sm.S[img_off(q)], rs[i]);    // (segment order of the images in memory: ssd_tiles.h)
+      st16(&sm.Gt[img_off(q)], rg[i]);
     }
   };
   // dD and < Graw, S_in > of the staged head fall out of the staging registers: per-wave partial sums into plain slots, ahead of

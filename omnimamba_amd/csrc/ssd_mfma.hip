@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void ssd_mfma_a3_kernel(GScan a) {
       if (here) {
         uint16_t* dp = a.dump + ((((int64_t)b * a.dump_nw + (cid >> 1)) * a.H + h) << 13);   // [b][window][h]: a window's heads are contiguous
 #pragma unroll
-        for (int i = 0; i < 4; i++) st16(dp + (tid + 256 * i) * 8, ld16(&sm.S[(tid + 256 * i) * 8]));
+        for (int i = 0; i < 4; i++) st16(dp + (tid + 256 * i) * 8, ld16(&sm.S[img_off(tid + 256 * i)]));   // (segment order of the images: ssd_tiles.h)
         if (STATE) block_sync();   // (the scan proper has barrier X between these reads and the next publish)
       }
     }

@@ -107,6 +107,14 @@ __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff,
   __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
 #endif
 }
+__device__ __forceinline__ void buf_st16(const BufRes& b, u32x4 v, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint64_t o = (uint64_t)voff + soff;
+  if (o < b.nbytes) *reinterpret_cast<u32x4*>(const_cast<char*>(b.base) + o) = v;
+#else
+  __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
+#endif
+}
 
 // ---- LDS-DMA (buffer_load ... lds): the 64 lanes of a wave fetch 16 (4) bytes each from the resource and the memory pipeline writes
 // them to LDS at lds_base + 16 (4) * lane -- no staging registers, no ds_write pass.  lds_base must be wave-uniform; the request
@@ -155,6 +163,14 @@ __device__ __forceinline__ void block_sync_lds() {
 __device__ __forceinline__ int swzK(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
 __device__ __forceinline__ int swzU(int r) { return swzK(r) & 7; }
 __device__ __forceinline__ int kx3(int row, int col) { return row * 128 + ((((col >> 3) ^ swzK(row)) << 3) | (col & 7)); }
+// Window-state images in memory (GScan::dump, 16 KB per head and window): the 16-byte segments of the [u][k] kx3 image in the ORDER THE
+// COLUMN-SLICE SCAN HOLDS THEM -- segment q = (4 w + i) 64 + lane is k-segment 4 i + (lane >> 4) of row u = 16 w + (lane & 15) -- so
+// that every store instruction of the scan writes 1 KB of consecutive bytes (as 16 rows x 64 bytes the images cost the training
+// forward 35 us of 237: tools/ubench/store_cost.hip).  img_off: element offset of segment q inside the kx3 image in LDS.
+__device__ __forceinline__ int img_off(int q) {
+  const int su = 16 * (q >> 8) + (q & 15);
+  return su * 128 + (((4 * ((q >> 6) & 3) + ((q >> 4) & 3)) ^ swzK(su)) << 3);
+}
 __device__ __forceinline__ int ux3(int row, int col) { return row * 64 + ((((col >> 3) ^ swzU(row)) << 3) | (col & 7)); }
 
 // 32x32x16 operand fragment out of a swizzled row-major [contraction][col] tile (K: 128 columns, U: 64 columns):
