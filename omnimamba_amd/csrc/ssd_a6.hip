@@ -139,9 +139,15 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     // dx scan: the output row is scaled by dt'_l -- folded into the row's two factors (of S_in^T Q^T and of the M build), so that
     // D dy can ride on the diagonal of M unscaled like D x does in the forward
     const float rsc = MODE == GS_DX ? rdt : 1.f;
-    sm.rl[kb][hh][lane] = exp2_fast(cs - csb) * rsc;
-    sm.ws[kb][hh][lane] = rwv * exp2_fast(cse - cs);
-    if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = exp2_fast(cse - csb);
+    // LAZY decay: unless the first sub-chunk decays by more than 2^-60, the state is carried through it UNDECAYED (T = S / d0: the
+    // update terms of its tokens weighted 2^(-cs_s) instead of 2^(cs_31 - cs_s), its dec == 1.f tells phase 2 to skip the multiply),
+    // the rows of the second sub-chunk take d0 into their factor of S_in^T Q^T, and its update applies d0 d1 at once: one pass of
+    // multiplies over the state slice per chunk instead of two.  The state is exact again at every chunk boundary (images, final state).
+    const bool lazy = e31 > -60.f;
+    const float csb_r = lazy ? 0.f : csb, cse_w = lane < 32 ? (lazy ? 0.f : e31) : e63;
+    sm.rl[kb][hh][lane] = exp2_fast(cs - csb_r) * rsc;
+    sm.ws[kb][hh][lane] = rwv * exp2_fast(cse_w - cs);
+    if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = lane < 32 ? (lazy ? 1.f : exp2_fast(e31)) : exp2_fast(lazy ? e63 : e63 - e31);
     if (STATE) return;
     const int b16 = lane & ~15;
     const bool blk1 = (lane & 16) != 0;
@@ -432,12 +438,16 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
           if (KHILO) ul[2 * s2 + p2] = pack_bf16x2(us[2 * p2] - bf_lo(hi), us[2 * p2 + 1] - bf_hi(hi));
         }
       }
+      if (uniform_i((int)__builtin_bit_cast(uint32_t, f.dec)) != 0x3f800000) {   // (1.f: the scalar wave's mark of a lazily carried sub-chunk)
+#pragma unroll
+        for (int t = 0; t < 8; t++) accS[t] = accS[t] * f.dec;
+      }
 #pragma unroll
       for (int t = 0; t < 8; t++) {
         s16x8 kk;
         kk[0] = f.kt[t][0][0]; kk[1] = f.kt[t][0][1]; kk[2] = f.kt[t][0][2]; kk[3] = f.kt[t][0][3];
         kk[4] = f.kt[t][1][0]; kk[5] = f.kt[t][1][1]; kk[6] = f.kt[t][1][2]; kk[7] = f.kt[t][1][3];
-        accS[t] = mfma16x16x32_bf16(kk, as_s16x8(uh), accS[t] * f.dec);
+        accS[t] = mfma16x16x32_bf16(kk, as_s16x8(uh), accS[t]);
         if (KHILO) accS[t] = mfma16x16x32_bf16(kk, as_s16x8(ul), accS[t]);
       }
     }
