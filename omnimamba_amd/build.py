@@ -31,8 +31,13 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+# per-file flags: ssd_a7.hip (one wave per SIMD, > 256 registers per lane) wants its MFMA accumulators in VGPRs -- by default the
+# compiler parks them in AGPRs above 256 registers and pays 330 v_accvgpr copies per chunk for the VALU work on the state
+FILE_FLAGS = {"ssd_a7.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _compile(src, obj, verbose):
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
