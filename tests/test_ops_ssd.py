@@ -394,3 +394,25 @@ def test_ssd_column_slice_kernel_extreme_decays_take_the_exponent_path(dev):
         assert rel(y[:, :, h].float().cpu(), y0[:, :, h]) < 6e-3, h
         assert rel(fin[:, h].cpu(), f0[:, h]) < 1e-3, h
         assert rel(leaves[0].grad[:, :, h].float().cpu(), ref[0].grad[:, :, h]) < 8e-3, h
+
+
+def test_ssd_one_wave_per_simd_experiment_matches_the_product_kernel_bitwise(dev, monkeypatch):
+    """ssd_a7.hip (OMK_SSD_A7=1: 4 waves x 32 state columns per workgroup) is the column-slice scan with another work split and the same
+    arithmetic: output, final state and the gradients of a backward that runs its dx scan through it must equal the product kernel's
+    bit for bit (the experiment stays in the tree only as long as it stays in sync)."""
+    import omnimamba_amd.ssd_combined as S
+    H, P, N, G, L = 4, 64, 128, 2, 200
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(2, L, H, P, N, G, torch.bfloat16, seed=11)
+
+    def run():
+        leaves = [t.clone().to(dev).requires_grad_() for t in (x, dt, A, Bm, Cm, D, dtb, init)]
+        y, fin = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6],
+                                             initial_states=leaves[7], dt_softplus=True, return_final_states=True)
+        y.backward(torch.ones_like(y))
+        return [y.detach().float().cpu(), fin.detach().cpu()] + [t.grad.float().cpu() for t in leaves]
+
+    ref = run()
+    monkeypatch.setenv("OMK_SSD_A7", "1")
+    got = run()
+    for r, g_ in zip(ref, got):
+        assert torch.equal(r, g_)
