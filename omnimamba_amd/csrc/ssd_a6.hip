@@ -404,7 +404,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
   auto out_rows = [&](f32x4 o, int row, int tlo, u32x2 xr) {   // the lane's row, columns 16 w + 4 g16 + r
     const int erow = rowtok(row);
     if (!DFOLD) o = o + Du * f32x4{bf_lo(xr[0]), bf_hi(xr[0]), bf_lo(xr[1]), bf_hi(xr[1])};
-    const uint32_t eoff = (uint32_t)(erow * osl + 16 * w + 4 * g16);
+    uint32_t eoff = (uint32_t)(erow * osl + 16 * w + 4 * g16);
+    if (OMK_A6_ABL & 512) eoff = (uint32_t)(rowtok((row & ~15) + 4 * w + g16) * osl + 4 * t16);   // (ablation: four full 128-byte rows per store, wrong data)
     if (MODE == GS_Y && EXTRAS && tlo + erow < a.L) {
       if (oxb) {
         u32x2 ox = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
