@@ -111,13 +111,17 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     for (int r = 0; r < 2; r++) ru[r] = buf_ld16(Ur, uvo, su + 2u * (uint32_t)((rev ? 32 * (1 - r) : 32 * r) * usl));
   };
   const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
-  auto commit_kq = [&](int kb) {   // rows past the end arrived as zeros
+  // (the commit of an iteration goes in three pieces -- K in front of phase 2 of sub-chunk 0, Q behind it, U in front of the barrier: as one
+  // burst of 48 ds_write_b128 per CU it kept the LDS pipe from the fragment reads for ~770 cycles per chunk; in pieces 1 % faster)
+  auto commit_k = [&](int kb) {   // rows past the end arrived as zeros
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      st16(&sm.K[kb][o_ck + 32 * 128 * r], rk[r]);
-      if (!STATE) st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
-    }
+    for (int r = 0; r < 2; r++) st16(&sm.K[kb][o_ck + 32 * 128 * r], rk[r]);
   };
+  auto commit_q = [&](int kb) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) if (!STATE) st16(&sm.Q[kb][o_ck + 32 * 128 * r], rq[r]);
+  };
+  auto commit_kq = [&](int kb) { commit_k(kb); commit_q(kb); };
   auto commit_u = [&](int ub) {
 #pragma unroll
     for (int r = 0; r < 2; r++) st16(&sm.U[ub][hh][o_cu + 32 * 64 * r], ru[r]);
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     OMK_SCHED_FENCE();
     }
     if (c + 1 < c1 && !skipb) build_loads(fb, kb1, ub1);
+    if (!(OMK_A6_ABL & 2)) commit_k(kb2);
     OMK_SCHED_FENCE();
     if (!skipc) {
     phase2(fc, 0, tlo);
@@ -503,12 +508,12 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     // ---- the tiles of the next chunk, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U)
     if (c + 1 < c1 && !skipb) build_tiles(fb, ub1);
     PT6(1);
-    if (!(OMK_A6_ABL & 2)) { commit_kq(kb2); commit_u(ub1); }
+    if (!(OMK_A6_ABL & 2)) commit_q(kb2);
     PT6(2);
     if (w == 0) scalars(kb2, ub0);
     PT6(3);
 #ifndef OMK_A6_LATEPF
-    if (!(OMK_A6_ABL & 4)) { prefetch_kq(chunk_lo(clipc(c + 3))); prefetch_u(chunk_lo(clipc(c + 2))); }   // a whole iteration ahead of their commit
+    if (!(OMK_A6_ABL & 4)) prefetch_kq(chunk_lo(clipc(c + 3)));   // a whole iteration ahead of their commit
 #endif
     OMK_SCHED_FENCE();
     // ---- sub-chunk 1; the barrier of the chunk behind its last request for the current buffers
@@ -518,6 +523,8 @@ __global__ __launch_bounds__(512) void ssd_a6_kernel(GScan a) {
     phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
     OMK_SCHED_FENCE();
     }
+    if (!(OMK_A6_ABL & 2)) commit_u(ub1);
+    if (!(OMK_A6_ABL & 4)) prefetch_u(chunk_lo(clipc(c + 2)));
     PT6(4);
     if (!(OMK_A6_ABL & 8)) block_sync();
     PT6(5);
