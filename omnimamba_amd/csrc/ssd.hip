@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_kernel(DtPrepArgs a) {
 
 // The same for 16-bit dt with unit head stride (the block's zxbcdt view): 64 tokens x 64 heads per block, two adjacent heads per
 // 4-byte load, the (B, H, L) rows stored as 16-byte vectors of four tokens.
-template <class T>
+template <class T, int TOK>   // TOK tokens x 64 heads per block
 __global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
-  __shared__ float sv[64][65], sd[64][65];
+  __shared__ float sv[64][TOK + 1], sd[64][TOK + 1];
   const int tid = threadIdx.x;
-  const int nth = (a.H + 63) / 64, ntl = (a.L + 63) / 64;
+  const int nth = (a.H + 63) / 64, ntl = (a.L + TOK - 1) / TOK;
   const int hb = blockIdx.x % nth, lb = (blockIdx.x / nth) % ntl, b = blockIdx.x / (nth * ntl);
   if (blockIdx.x == 0) {
 #pragma unroll
@@ -88,16 +88,16 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
   const T* src = (const T*)a.dt + (int64_t)b * a.sb + (hok ? h : 0);
   // all eight loads of the thread first, without control flow (rows behind the end read the last row and are masked below): with
   // the load under `if (t < L)` the eight round trips to memory ran one after the other (13.5 us per launch; round 4)
-  float raw[8][2];
+  float raw[TOK / 8][2];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int t = lb * 64 + 8 * j + tr;
+  for (int j = 0; j < TOK / 8; j++) {
+    const int t = lb * TOK + 8 * j + tr;
     load_vec<T, 2>(src + (int64_t)(t < a.L ? t : a.L - 1) * a.sl, raw[j]);
   }
   const bool want_d = a.dsoft != nullptr;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int tl = 8 * j + tr, t = lb * 64 + tl;
+  for (int j = 0; j < TOK / 8; j++) {
+    const int tl = 8 * j + tr, t = lb * TOK + tl;
     float v2[2] = {0.f, 0.f}, d2[2] = {1.f, 1.f};
     if (t < a.L && hok) {
 #pragma unroll
@@ -119,11 +119,11 @@ __global__ __launch_bounds__(256) void ssd_dt_prep_vec_kernel(DtPrepArgs a) {
   block_sync();
   const int hh = tid >> 2, q = tid & 3, hg = hb * 64 + hh;
   if (hg < a.H) {
-    const int64_t o = ((int64_t)b * a.H + hg) * a.L + lb * 64 + 16 * q;
+    const int64_t o = ((int64_t)b * a.H + hg) * a.L + lb * TOK + (TOK / 4) * q;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int tl = 16 * q + 4 * i;
-      if (lb * 64 + tl < a.L) {   // L % 4 == 0: a vector is in or out as a whole
+    for (int i = 0; i < TOK / 16; i++) {
+      const int tl = (TOK / 4) * q + 4 * i;
+      if (lb * TOK + tl < a.L) {   // L % 4 == 0: a vector is in or out as a whole
         *reinterpret_cast<f32x4*>(a.dtp + o + 4 * i) = f32x4{sv[hh][tl], sv[hh][tl + 1], sv[hh][tl + 2], sv[hh][tl + 3]};
         if (a.dsoft) *reinterpret_cast<f32x4*>(a.dsoft + o + 4 * i) = f32x4{sd[hh][tl], sd[hh][tl + 1], sd[hh][tl + 2], sd[hh][tl + 3]};
       }
@@ -541,9 +541,17 @@ static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdD
   const bool vec = (dt.dtype == OMK_BF16 || dt.dtype == OMK_F16) && a.sh == 1 && (a.sl % 2) == 0 && (a.sb % 2) == 0 && ((uintptr_t)dt.data & 3) == 0 &&
                    (d.H % 2) == 0 && (d.L % 4) == 0 && ((uintptr_t)dtp & 15) == 0 && (!dsoft || ((uintptr_t)dsoft & 15) == 0);
   if (vec) {
-    dim3 grid((unsigned)((int64_t)d.B * ((d.L + 63) / 64) * ((d.H + 63) / 64)));
-    if (dt.dtype == OMK_BF16) OMK_LAUNCH((ssd_dt_prep_vec_kernel<bf16_t>), grid, block, 0, stream, a);
-    else OMK_LAUNCH((ssd_dt_prep_vec_kernel<f16_t>), grid, block, 0, stream, a);
+    // 32-token tiles: 7.6 us per launch against 9.7 us with 64 (twice the blocks in flight; the (B, H, L) rows still leave as full 128-byte lines)
+    static const int tok = getenv("OMK_DT_PREP_TOK") ? atoi(getenv("OMK_DT_PREP_TOK")) : 32;
+    if (tok == 32) {
+      dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 63) / 64)));
+      if (dt.dtype == OMK_BF16) OMK_LAUNCH((ssd_dt_prep_vec_kernel<bf16_t, 32>), grid, block, 0, stream, a);
+      else OMK_LAUNCH((ssd_dt_prep_vec_kernel<f16_t, 32>), grid, block, 0, stream, a);
+    } else {
+      dim3 grid((unsigned)((int64_t)d.B * ((d.L + 63) / 64) * ((d.H + 63) / 64)));
+      if (dt.dtype == OMK_BF16) OMK_LAUNCH((ssd_dt_prep_vec_kernel<bf16_t, 64>), grid, block, 0, stream, a);
+      else OMK_LAUNCH((ssd_dt_prep_vec_kernel<f16_t, 64>), grid, block, 0, stream, a);
+    }
     return;
   }
   dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 31) / 32)));
