@@ -206,6 +206,15 @@ __device__ __forceinline__ float wave_incl_scan_add(float v) {
   return v;
 }
 __device__ __forceinline__ float wave_read_lane(float v, int l) { return shfl(v, l); }
+// lane N of the lane's own row of 16 / lane 15 of the row of 16 in front of an odd row, lane 15 of its own row for an even row
+template <int N> __device__ __forceinline__ float wave_row_bcast(float v) { return shfl(v, (lane_id() & ~15) + N); }
+__device__ __forceinline__ float wave_pair_boundary(float v) { const int l = lane_id(); return shfl(v, (l & 16) ? (l & ~15) - 1 : (l & ~15) + 15); }
+// v_permlane16_swap: the odd rows of 16 lanes of x change places with the even rows of y (x: lanes 16..31 <-> y: lanes 0..15, x: 48..63 <-> y: 32..47)
+__device__ __forceinline__ void wave_swap16(uint32_t& x, uint32_t& y) {
+  const int l = lane_id();
+  const uint32_t xo = shfl(x, l ^ 16), yo = shfl(y, l ^ 16);
+  if (l & 16) x = yo; else y = xo;
+}
 #else
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 = log2
@@ -227,6 +236,19 @@ __device__ __forceinline__ float wave_incl_scan_add(float v) {
 __device__ __forceinline__ float wave_read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// lane N of the lane's own row of 16 (DPP row_newbcast: no LDS round trip, unlike ds_bpermute behind __shfl)
+template <int N> __device__ __forceinline__ float wave_row_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, false));
+}
+// odd rows of 16: lane 15 of the row in front (row_bcast:15); even rows: lane 15 of their own row (row_newbcast:15)
+__device__ __forceinline__ void wave_swap16(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0]; y = r[1];
+}
+__device__ __forceinline__ float wave_pair_boundary(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15f, 0x5, 0xf, false);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+}
 #endif
 // Phase markers for tools/isa_phases.py (developer builds with -DOMK_ISA_MARKS only): a comment line in the ISA
 #if defined(OMK_ISA_MARKS) && !defined(OMK_EMU)
@@ -245,6 +267,12 @@ __device__ __forceinline__ float wave_read_lane(float v, int l) {
 #define OMK_WAVES_PER_EU(n)
 #else
 #define OMK_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+// Keep a value alive without using it (ablation builds)
+#ifdef OMK_EMU
+#define OMK_KEEP(x) do { } while (0)
+#else
+#define OMK_KEEP(x) asm volatile("" :: "v"(x))
 #endif
 // Make a lane value opaque to the optimiser at this point: address arithmetic derived from it afterwards stays inside
 // the loop instead of being hoisted into (many) loop-invariant registers.
