@@ -89,6 +89,10 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     // =====================================================================================================================
     // helper wave: staging, token scalars, M tiles (ssd_a7.hip's code for these, on the 256 threads of waves 4..7)
     // =====================================================================================================================
+    // (the role of a helper -- w: scalars + one tile, or two tiles -- is a compile-time constant of its loop: as a run-time value it cut the loop
+    // into ~60 basic blocks with a branch each)
+    auto helper_body = [&](auto wtag) {
+    constexpr int w = decltype(wtag)::value;
     const int ht = tid & 255;
     const int rowk = ht >> 4, ck8 = (ht & 15) * 8, rowu = (ht & 127) >> 3, cu8 = (ht & 7) * 8;
     const uint16_t* Kb = (const uint16_t*)a.K.p + (int64_t)b * a.K.sb + (int64_t)g * a.K.sh;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
 #endif
     for (int c = c0; c < c1; c++) {
       const int ub0 = (c - c0) & 1, ub1 = ub0 ^ 1;
-      const bool more = c + 1 < c1;
+      constexpr bool more = true;   // (behind the last chunk the builders redo its tiles from the re-staged buffers: nobody reads them, no branch)
 #if OMK_A8_DMA
       // the tiles of chunk c + 1, the requests for chunk c + 2 (K / Q) and c + 1 (U), the scalars of chunk c + 2.  (OMK_A8_VAR ablations,
       // wrong results: 16 no tile build, 32 no scalars, 128 no requests.)  The steps are fenced: left alone the compiler moved the builder's
@@ -375,6 +379,8 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
     }
     PT8_END();
+    };
+    if (w == 0) helper_body(std::integral_constant<int, 0>{}); else helper_body(std::integral_constant<int, 1>{});
     return;
   }
 
@@ -573,8 +579,9 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     for (int cg = 0; cg < 2; cg++) {
       accB0[cg] = mfma16x16x32_bf16(f.u00[cg], as_s16x8(f.m0), f32x4{0.f, 0.f, 0.f, 0.f});
       accB1[cg] = mfma16x16x32_bf16(f.u01[cg], as_s16x8(f.mh), f32x4{0.f, 0.f, 0.f, 0.f});
-      accB1[cg] = mfma16x16x32_bf16(f.u01[cg], as_s16x8(f.ml), accB1[cg]);
     }
+#pragma unroll
+    for (int cg = 0; cg < 2; cg++) accB1[cg] = mfma16x16x32_bf16(f.u01[cg], as_s16x8(f.ml), accB1[cg]);   // (not right behind the MFMA it accumulates on)
     if (MUL) {
 #pragma unroll
       for (int cg = 0; cg < 2; cg++) accS[cg][0] = accS[cg][0] * f.dec;
@@ -592,7 +599,14 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       kk[0] = f.kt[t][0][0]; kk[1] = f.kt[t][0][1]; kk[2] = f.kt[t][0][2]; kk[3] = f.kt[t][0][3];
       kk[4] = f.kt[t][1][0]; kk[5] = f.kt[t][1][1]; kk[6] = f.kt[t][1][2]; kk[7] = f.kt[t][1][3];
       accS[cg][t] = mfma16x16x32_bf16(kk, as_s16x8(uh[cg]), accS[cg][t]);
-      if (KHILO) accS[cg][t] = mfma16x16x32_bf16(kk, as_s16x8(ul[cg]), accS[cg][t]);
+      if (KHILO && n > 0) {   // the lo half of the tile before: one MFMA behind the hi half it accumulates on, not right behind it
+        const int t1 = (n - 1) >> 1, c1_ = (n - 1) & 1;
+        s16x8 k1;
+        k1[0] = f.kt[t1][0][0]; k1[1] = f.kt[t1][0][1]; k1[2] = f.kt[t1][0][2]; k1[3] = f.kt[t1][0][3];
+        k1[4] = f.kt[t1][1][0]; k1[5] = f.kt[t1][1][1]; k1[6] = f.kt[t1][1][2]; k1[7] = f.kt[t1][1][3];
+        accS[c1_][t1] = mfma16x16x32_bf16(k1, as_s16x8(ul[c1_]), accS[c1_][t1]);
+      }
+      if (KHILO && n == 15) accS[1][7] = mfma16x16x32_bf16(kk, as_s16x8(ul[1]), accS[1][7]);
       if (MUL && n + 2 < 16) accS[(n + 2) & 1][(n + 2) >> 1] = accS[(n + 2) & 1][(n + 2) >> 1] * f.dec;
       if (n == 4) out_rows(accA0[0] * f.rl0 + accB0[0], accA0[1] * f.rl0 + accB0[1], jj, 0, so);
       if (n == 8) out_rows(accA1[0] * f.rl1 + accB1[0], accA1[1] * f.rl1 + accB1[1], jj, 1, so);
@@ -618,17 +632,19 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       dump_here = rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
       if (dump_here) dso = (uint32_t)(((int64_t)(cid >> 1) * a.H) << 14);
     }
+    if (!(OMK_A8_VAR & 1024)) {   // (ablation 1024: the compute waves only stage and meet the barrier)
     phase1(fr, true, dump_here, dso, fc, kb0, ub0, 0);
     PT8(0);
     phase2(std::false_type{}, fc, 0, so, fr, kb0, 1);
     PT8(1);
     phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
+    }
     if (OMK_A8_CU && !(OMK_A8_VAR & 64)) commit_u(ub0 ^ 1);                                   // U of chunk c + 1
     if (OMK_A8_CU && !(OMK_A8_VAR & 128)) prefetch_u(chunk_lo(clipc(c + 2)));
     PT8(2);
     block_sync();   // behind the last request for the buffers of chunk c
     PT8(3);
-    phase2(std::true_type{}, fc, 1, so, fr, kb1, 0);
+    if (!(OMK_A8_VAR & 1024)) phase2(std::true_type{}, fc, 1, so, fr, kb1, 0);
     PT8(4);
     { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
   }

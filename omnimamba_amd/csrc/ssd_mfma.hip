@@ -978,9 +978,18 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
   if (!a.seg || a.nseg < 2) return OMK_OK;
   dim3 block(256), sgrid((unsigned)(a.B * a.H * (a.nseg - 1)));
   const size_t smem = sizeof(SmemA3);
-  // the state pass does not depend on the mode (no output); it reads U, K, dt' and the scan direction only
-  if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
-  OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), sgrid, block, smem, stream, a);
+  // the state pass does not depend on the mode (no output); it reads U, K, dt' and the scan direction only.  When the caller keeps the
+  // final state (prefill -> decode hand-off, context-parallel shards) the segment states carry the hi + lo operand like the scan proper
+  // does then: a kept final state of a SPLIT sequence (B = 1 prefill) is exact to fp32 accumulation too, not 1e-3 off.
+  const char* khe = getenv("OMK_SSD_KHILO");
+  const bool khilo = g.mode == GS_Y && (khe ? khe[0] == '1' : (g.fin != nullptr));
+  if (khilo) {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false, true>), sgrid, block, smem, stream, a);
+  } else {
+    if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
+    OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), sgrid, block, smem, stream, a);
+  }
   dim3 fgrid((unsigned)((int64_t)a.B * a.H * (SEG_STATE / 256)));
   OMK_LAUNCH(ssd_seg_fold_kernel, fgrid, block, 0, stream, a);
   return OMK_OK;

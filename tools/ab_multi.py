@@ -16,7 +16,7 @@ from tools.bench_scan import timeit
 dev = torch.device("cuda:0")
 H, P, N, G = 64, 64, 128, 1
 out = []
-for (B, L) in [(8, 4096), (8, 8192)]:
+for (B, L) in [tuple(int(v) for v in t.split('x')) for t in os.environ.get('AB_SHAPES', '8x4096,8x8192').split(',')]:
     torch.manual_seed(0)
     xBC = torch.randn(B, L, H * P + 2 * G * N, device=dev).bfloat16()
     x = xBC[..., :H * P].view(B, L, H, P); Bm = xBC[..., H * P:H * P + G * N].view(B, L, G, N); Cm = xBC[..., H * P + G * N:].view(B, L, G, N)
