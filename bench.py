@@ -197,7 +197,8 @@ def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
-    bwd = sorted(a.elapsed_time(b) for a, b in step.backward_ms)
+    bwd = sorted(step.take_backward_ms())
+    step.time_backward = False
     bwd_ms = bwd[len(bwd) // 2] if bwd else float("nan")
     loss = sum(float(step.last[t]) for t in tasks)
     assert math.isfinite(loss)
@@ -378,6 +379,7 @@ def self_launch(args):
 
 def main():
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # the VQ tail's library convolutions: no exhaustive find (5 s of naive kernels per run)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # read by HSA at initialisation: before the first torch.cuda call of this process
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -424,7 +426,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend or "nccl", device_id=dev, rank=rank, world_size=world)
 
     from omnimamba_amd import _prof

@@ -31,9 +31,8 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-# per-file flags: ssd_a7.hip (one wave per SIMD, > 256 registers per lane) wants its MFMA accumulators in VGPRs -- by default the
-# compiler parks them in AGPRs above 256 registers and pays 330 v_accvgpr copies per chunk for the VALU work on the state
-FILE_FLAGS = {"ssd_a7.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# per-file flags (none at present; the one-wave-per-SIMD experiment that needed one left the tree in round 5)
+FILE_FLAGS = {}
 
 
 def _compile(src, obj, verbose):

@@ -604,7 +604,6 @@ int ssd_a6_state_dump(const GScan& g, omk_stream stream) {
 
 // called by ssd_mfma_launch after its shape / alignment checks (same preconditions as the row-strip kernel)
 int ssd_a6_launch(const GScan& g, omk_stream stream) {
-  if (ssd_a7_applies(g)) return ssd_a7_launch(g, stream);
   if (ssd_a8_applies(g)) return ssd_a8_launch(g, stream);
   GScan a = g;
   const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QA6 - 1) / QA6};

@@ -3,15 +3,15 @@
 //
 // Where it comes from.  ssd_a6.hip runs eight identical waves of 16 state columns: every wave reads all of Q and all of K^T of a sub-chunk
 // from LDS for its 16 columns (LDS busy 53 % of a chunk) and the two instruction streams of a SIMD run in lockstep, so the pipes of a
-// SIMD add up instead of overlapping.  ssd_a7.hip (one wave per SIMD, 32 columns, 363 registers) halved the fragment
-// reads but left three serial latency chains -- tile build, commit of the staged chunk, token scalars -- fully exposed in its single
-// stream (218 us against 197).  Here those chains live in a SECOND wave per SIMD:
+// SIMD add up instead of overlapping.  The round-4 experiment with ONE wave of 32 columns per SIMD (ssd_a7.hip, 363 registers,
+// git history) halved the fragment reads but left three serial latency chains -- tile build, commit of the staged chunk, token scalars --
+// fully exposed in its single stream (218 us against 197).  Here those chains live in a SECOND wave per SIMD:
 //   * compute wave (hh, w), waves 0..3: the state columns [32 w, 32 w + 32) of head hh as two groups of eight 16 x 16 accumulator tiles,
 //     and nothing but the two phases of a sub-chunk (ssd_a6.hip header): pack + S_in^T Q^T, then state update + U^T M^T + output rows.
 //     Its stream is written in issue order: every MFMA is followed by the few VALU / LDS instructions that fit in its shadow
 //     (pack of the next tile pair, the scaled U operand, decay of the next tile, output rows), pinned by scheduling fences;
 //   * helper wave, waves 4..7: global loads of chunk c + 3 (K, Q, dt') and c + 2 (U), their commit to LDS, the token scalars of chunk
-//     c + 2 and the shared M tiles of chunk c + 1 (G = K Q^T once for both heads) -- a7's roles (hh, w) unchanged.  Its waits (vmcnt,
+//     c + 2 and the shared M tiles of chunk c + 1 (G = K Q^T once for both heads).  Its waits (vmcnt,
 //     LDS round trips, the DPP scan chain) cost the compute wave nothing; the hardware interleaves the two streams.
 // Both kinds take 256 registers (two waves per SIMD).  Same LDS layout, staging distances, barrier (one per chunk) and ARITHMETIC as
 // ssd_a6.hip: results are equal bit for bit (tests/test_ops_ssd.py).  Variants here: one D per head (or none), no gate / pre-gate copy;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
 
   if (helper) {
     // =====================================================================================================================
-    // helper wave: staging, token scalars, M tiles (ssd_a7.hip's code for these, on the 256 threads of waves 4..7)
+    // helper wave: staging, token scalars, M tiles (the 256 threads of waves 4..7)
     // =====================================================================================================================
     // (the role of a helper -- w: scalars + one tile, or two tiles -- is a compile-time constant of its loop: as a run-time value it cut the loop
     // into ~60 basic blocks with a branch each)

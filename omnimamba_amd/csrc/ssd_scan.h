@@ -109,8 +109,6 @@ int ssd_v6_launch(const GScan& g, omk_stream stream);
 bool ssd_a6_applies(const GScan& g);
 int ssd_a6_launch(const GScan& g, omk_stream stream);
 int ssd_a6_state_only(const GScan& g, omk_stream stream);
-bool ssd_a7_applies(const GScan& g);   // OMK_SSD_A7=1: the one-wave-per-SIMD experiment (ssd_a7.hip)
-int ssd_a7_launch(const GScan& g, omk_stream stream);
 // the specialised-wave class A kernel (ssd_a8.hip): four compute waves of 32 state columns + four helper waves per head pair
 bool ssd_a8_applies(const GScan& g);   // OMK_SSD_A8=0: ssd_a6.hip takes its shapes
 int ssd_a8_launch(const GScan& g, omk_stream stream);

@@ -302,8 +302,8 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         inference_params.reset(max_length, batch_size)
         pkey = ("prefill", batch_size, seqlen_pr, task, input_embeddings.dtype)
         if _prefill_graph_ok(seqlen_pr) and pkey not in cache["graphs"]:
-            # at most MAX_PREFILL_GRAPHS captured prompt lengths per model (least recently captured goes first): text prompts of
-            # every length would otherwise pin a graph + static buffers each
+            # at most MAX_PREFILL_GRAPHS captured prompt lengths per model (the least recently USED goes first: a hit below moves its
+            # key to the end): text prompts of every length would otherwise pin a graph + static buffers each
             pkeys = [k for k in cache["graphs"] if k[0] == "prefill"]
             if len(pkeys) >= MAX_PREFILL_GRAPHS:
                 del cache["graphs"][pkeys[0]]
@@ -311,6 +311,8 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
                                                  input_embeddings.dtype, mempool=cache["mempool"])
             inference_params.reset(max_length, batch_size)
         prefill_graph = cache["graphs"].get(pkey)
+        if prefill_graph is not None:
+            cache["graphs"][pkey] = cache["graphs"].pop(pkey)     # most recently used last
     else:
         inference_params = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size)
         prefill_graph = None

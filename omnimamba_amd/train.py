@@ -9,6 +9,7 @@ messages to spread over all links; bucket all-reduce overlaps the (bandwidth-bou
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 from dataclasses import dataclass
@@ -88,7 +89,13 @@ class Stage2Step:
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: cosine_with_min_lr(s, cfg))
         self.last = {}
         self.time_backward = False   # bench.py: HIP events around the backward (the window the gradient all-reduce has to hide in)
-        self.backward_ms = []
+        self.backward_events = collections.deque(maxlen=256)   # (start, end) HIP event pairs of the last backwards
+
+    def take_backward_ms(self):
+        """Durations (ms) of the backwards timed since the last call (time_backward = True); the event pairs are dropped."""
+        out = [a.elapsed_time(b) for a, b in self.backward_events]
+        self.backward_events.clear()
+        return out
 
     def __call__(self, batch):
         dev_type = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
@@ -106,7 +113,7 @@ class Stage2Step:
             e0.record()
             total.backward()
             e1.record()
-            self.backward_ms.append((e0, e1))
+            self.backward_events.append((e0, e1))
         else:
             total.backward()
         if self.cfg.clip:
