@@ -212,6 +212,40 @@ def train_1p3b(dev, rank, world, steps=10, warmup=2, batch=8, seqlen=2048, stage
                       "params": sum(p.numel() for p in model.parameters()), "dtype": "bf16 autocast, fp32 masters",
                       "parallelism": f"dp{world}" if world > 1 else "single"}}
     out["comm_model"] = comm_model(out["config"]["trainable_params"], tc.bucket_cap_mb, dt / steps * 1e3, bwd_ms, world)
+    if not dist_on and world == 1 and dev.type == "cuda":
+        # what the DDP wrapper itself costs (bucket copies, hooks, the RCCL all-reduce of one rank): the SAME model and optimizer behind
+        # DistributedDataParallel on an nccl group of one, step time minus the plain step time above (next #6)
+        import torch.distributed as dist
+        own_pg = not dist.is_initialized()
+        try:
+            if own_pg:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            net = wrap_ddp(model, tc, device_ids=[dev.index])
+            step.net = net
+            for _ in range(2):
+                step(data)
+            torch.cuda.synchronize()
+            n2 = max(3, steps // 2)
+            ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n2 + 1)]
+            ev2[0].record()
+            for i in range(n2):
+                step(data)
+                ev2[i + 1].record()
+            torch.cuda.synchronize()
+            per2 = sorted(ev2[i].elapsed_time(ev2[i + 1]) for i in range(n2))
+            out["ddp_world1"] = {"ms_per_step_median": round(per2[len(per2) // 2], 2), "steps": n2, "backend": "nccl (RCCL), world size 1",
+                                 "grad_compression": tc.grad_compression}
+            out["ddp_overhead_ms"] = round(per2[len(per2) // 2] - per[len(per) // 2], 2)
+        except Exception as e:   # noqa: BLE001 -- a reported extra, never a reason to lose the bench line
+            out["ddp_overhead_ms"] = None
+            out["ddp_world1"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        finally:
+            if own_pg and dist.is_initialized():
+                dist.destroy_process_group()
     del step, net, model
     torch.cuda.empty_cache()
     return out
@@ -510,8 +544,10 @@ def main():
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     tj = json.load(fh)
                     traffic[key] = (int(tj["traffic_bytes_per_launch"]), tj.get("source"))
+                    traffic[key + "_mfma"] = tj.get("mfma_busy")
                     if key == "fwd" and "with_window_states" in tj:
                         traffic["fwd_ws"] = int(tj["with_window_states"]["traffic_bytes_per_launch"])
+                        traffic["fwd_ws_mfma"] = tj["with_window_states"].get("mfma_busy")
             except (OSError, KeyError, ValueError):
                 traffic[key] = (None, None)
         from omnimamba_amd.ssd_combined import save_window_states_enabled
@@ -525,18 +561,21 @@ def main():
                        "global_batch": B_LOCAL * world, "seq_len": SEQ, "d_model": D_MODEL, "d_state": D_STATE,
                        "headdim": HEADDIM, "nheads": H, "params": "fp32 master, bf16 autocast",
                        "parallelism": f"dp{world}" if world > 1 else "single", "process_group": (dist.get_backend() if dist_on else None), "library_gemm_solutions": "recorded (TunableOp file)" if tuned else "default"},
-            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_a6_kernel<GS_Y> + ssd_dt_prep_vec_kernel" + (
+            "roofline": {"bound": "hbm", "kernel": "omk_ssd_scan_fwd as the training step launches it (ssd_a8_kernel<GS_Y, DUMP> + ssd_dt_prep_vec_kernel" + (
                              "; the forward also leaves its window states behind for the backward: +256 MiB of writes that are not algorithmic bytes; the plain forward of this shape is scan_target.B8_L4096)"
                              if save_ws else ")"),
                          "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
-                         # (both instantiations -- with and without the window-state dumps -- are under the counters: round 4)
+                         # (both instantiations -- with and without the window-state dumps -- are under the counters)
                          "traffic": None if traffic["fwd"][0] is None else (traffic.get("fwd_ws", traffic["fwd"][0] + B_LOCAL * ((SEQ + 127) // 128) * H * 16384) if save_ws else traffic["fwd"][0]),
                          "traffic_source": traffic["fwd"][1],
+                         # share of the SIMD-cycles of the launch the matrix pipe is busy (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),
+                         # from the same PMC passes as `traffic`: = the share of the dense bf16 MFMA peak at the clock the kernel runs at)
+                         "mfma_busy": (traffic.get("fwd_ws_mfma") if save_ws else traffic.get("fwd_mfma")),
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
             "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + " + ("" if save_ws else "state-only forward pass + ") + "dx scan with window-state dumps + ssd_cp_kernel + folds + finish" + (
                                  "; forward window states saved by the training forward)" if save_ws else ")"),
                              "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
-                             "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1],
+                             "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1], "mfma_busy": traffic.get("bwd_mfma"),
                              "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": round(ms_b, 4), "launches_timed": n_b},
             "tokens_per_s": round(world * tok / (elapsed / nsteps), 1),
         }

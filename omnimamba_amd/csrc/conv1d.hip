@@ -408,6 +408,10 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
       else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 2, TG_>), grid, block, 0, stream, a); } while (0)
     const char* tle = getenv("OMK_CONV_FWD_TL");   // developer A/B of the tokens per thread (bf16)
     const int tl = (tle && *tle) ? atoi(tle) : (a.L >= 1024 ? 64 : 32);   // 64: -4 % on the 1.3B slice (halo rows), 128: worse again
+    const char* vce = getenv("OMK_CONV_FWD_VEC");   // developer A/B: "8" = 16 bytes per lane, 4 tokens in flight
+    if (p->x.dtype == OMK_BF16 && vce && vce[0] == '8' && a.C % 8 == 0) {
+      if (vce[1] == '8') CONV_FWD_V(bf16_t, 8, 64, 8); else if (vce[1] == '2') CONV_FWD_V(bf16_t, 8, 32, 4); else CONV_FWD_V(bf16_t, 8, 64, 4);
+    } else
     if (p->x.dtype == OMK_BF16) {
       if (tl == 128) CONV_FWD_V(bf16_t, 4, 128, 8); else if (tl == 64) CONV_FWD_V(bf16_t, 4, 64, 8); else if (tl == 16) CONV_FWD_V(bf16_t, 4, 16, 8);
       else CONV_FWD_V(bf16_t, 4, 32, 8);

@@ -7,6 +7,7 @@
 // spills.  Every byte is touched once with 16-byte loads/stores; weight-gradient partials go to a [nparts][cols]
 // workspace (nparts <= 1024) that a second tiny kernel folds.
 // Algorithmic bytes per row of `cols`: add+norm fwd = cols * (sx + sres_in + sx + sres_out); gated fwd = 3 * cols * sx.
+#include <cstdlib>
 #include "omk_common.h"
 
 namespace omk {
@@ -336,6 +337,76 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
   }
 }
 
+// The reference's mode only (OmniMamba / Mamba-2: gate z present, norm_before_gate = 0, no bias, one segment per block row): the rows of a
+// block are software pipelined -- the 16-byte loads of the NEXT row are in flight while this row is reduced and stored (a persistent
+// block otherwise has one row of loads outstanding per wave: the general kernel runs at 4.5 TB/s where a plain element-wise kernel with
+// the same three streams reaches 6.1) -- and nothing the mode does not need stays in registers (bias, the gate after its use).
+template <class TX, int VEC, int NCHUNK, int WPR>
+__global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_lean_kernel(NormArgs a) {
+  NORM_ROWMAP();
+  const TX* x = (const TX*)a.x;
+  const TX* z = (const TX*)a.z;
+  TX* y = (TX*)a.y;
+  const int gs = a.cols / a.ngroups;
+  const float inv_n = 1.f / (float)gs;
+  const int grp = blockIdx.x % a.ngroups;
+  const int g0 = grp * gs;
+  const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
+  float wreg[NCHUNK][VEC];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) wreg[c][i] = load_rt(a.w, g0 + NORM_COL(c) + i, a.wdt);
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  vec_t<TX, VEC> rx[NCHUNK], rz[NCHUNK];
+  auto issue = [&](int64_t it) {
+    const int64_t rraw = it * RPB + wrow;
+    const int64_t row = rraw < a.rows ? rraw : a.rows - 1;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      if (a.rms & 32) {
+        const u32x4 vx = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + row * a.xs + g0 + NORM_COL(c)));
+        const u32x4 vz = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(z + row * a.zs + g0 + NORM_COL(c)));
+        rx[c] = __builtin_bit_cast(vec_t<TX, VEC>, vx); rz[c] = __builtin_bit_cast(vec_t<TX, VEC>, vz);
+      } else {
+      rx[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(x + row * a.xs + g0 + NORM_COL(c));
+      rz[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(z + row * a.zs + g0 + NORM_COL(c));
+      }
+    }
+  };
+  if (bi < niter) issue(bi);
+  for (int64_t it = bi; it < niter; it += nbg) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    float v[NCHUNK][VEC];
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        v[c][i] = (a.rms & 4) ? to_f32(rx[c].e[i]) * to_f32(rz[c].e[i]) : to_f32(rx[c].e[i]) * silu_fast(to_f32(rz[c].e[i]));
+        s2 += v[c][i] * v[c][i];
+      }
+    if (it + nbg < niter) issue(it + nbg);   // (the staging registers are free: the next row's loads fly during the reduction)
+    const float rstd = (a.rms & 2) ? s2 : rsqrtf(row_sum<WPR>(s2, red, wave, rpar) * inv_n + a.eps);   // (a.rms bits 1, 2: developer ablations, OMK_NORM_ABL)
+    if (lane == 0 && wsub == 0 && a.rstd && rlive && !(a.rms & 8)) a.rstd[rraw * a.ngroups + grp] = rstd;
+    if (rlive) {
+#pragma unroll
+      for (int c = 0; c < NCHUNK; c++) {
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = v[c][i] * rstd * wreg[c][i];
+        if (!(a.rms & 16)) {   // (streamed once: non-temporal, - 3 %)
+          vec_t<TX, VEC> ov;
+#pragma unroll
+          for (int i = 0; i < VEC; i++) ov.e[i] = from_f32<TX>(o[i]);
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(y + rraw * a.ys + g0 + NORM_COL(c)));
+        } else st<TX, VEC>(y + rraw * a.ys + g0 + NORM_COL(c), o);
+      }
+    }
+  }
+}
+
 template <class TX, int VEC, int NCHUNK, int WPR>
 __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArgs a) {
   NORM_ROWMAP();
@@ -445,6 +516,96 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
   }
 }
 
+// The reference's mode of the backward (gate present, norm_before_gate = 0): the general kernel above evaluates the sigmoid of the gate
+// twice and keeps six fp32 arrays per lane alive across the row reduction (157 registers: three waves per SIMD, and 40 VALU + 4
+// transcendental operations per element -- more SIMD time than the five streams take at the memory roof).  Here: one sigmoid, the
+// inputs stay in their 16-byte staging registers until their last use, three fp32 arrays cross the reduction.
+template <class TX, int VEC, int NCHUNK, int WPR>
+__global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_lean_kernel(NormBwdArgs a) {
+  NORM_ROWMAP();
+  const TX* x = (const TX*)a.x;
+  const TX* z = (const TX*)a.z;
+  const TX* dy = (const TX*)a.dy;
+  TX* dx = (TX*)a.dx;
+  TX* dz = (TX*)a.dz;
+  const int gs = a.cols / a.ngroups;
+  const float inv_n = 1.f / (float)gs;
+  const int grp = blockIdx.x % a.ngroups;
+  const int g0 = grp * gs;
+  const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
+  // (the weight row lives in LDS, read per row: sixteen registers that decide between three and four waves per SIMD)
+  __shared__ __attribute__((aligned(16))) float wsh[WPR * NCHUNK * 64 * VEC];
+  float dwacc[NCHUNK][VEC];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { dwacc[c][i] = 0.f; if (wrow == 0) wsh[NORM_COL(c) + i] = load_rt(a.w, g0 + NORM_COL(c) + i, a.wdt); }
+  block_sync();
+  const int64_t niter = (a.rows + RPB - 1) / RPB;
+  for (int64_t it = bi; it < niter; it += nbg) {
+    const int64_t rraw = it * RPB + wrow;
+    const bool rlive = rraw < a.rows;
+    const int64_t row = rlive ? rraw : a.rows - 1;
+    vec_t<TX, VEC> rx[NCHUNK], rz[NCHUNK], rd[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      rx[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(x + row * a.xs + g0 + NORM_COL(c));
+      rd[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(dy + row * a.dys + g0 + NORM_COL(c));
+      rz[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(z + row * a.zs + g0 + NORM_COL(c));
+    }
+    float gv[NCHUNK][VEC], wdy[NCHUNK][VEC], sig[NCHUNK][VEC];
+    float s2 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        const float zf = to_f32(rz[c].e[i]);
+        sig[c][i] = sigmoid_fast(zf);
+        const float wv = wsh[NORM_COL(c) + i];
+        gv[c][i] = to_f32(rx[c].e[i]) * (zf * sig[c][i]);      // x silu(z): what the norm sees
+        wdy[c][i] = rlive ? to_f32(rd[c].e[i]) * wv : 0.f;
+        s2 += gv[c][i] * gv[c][i];
+        t2 += gv[c][i] * wdy[c][i];
+      }
+    row_sum2<WPR>(s2, t2, red, wave, rpar);
+    const float rstd = rsqrtf(s2 * inv_n + a.eps);
+    const float c1 = rstd * t2 * inv_n;
+    // (the staging registers made opaque: the second pass converts the packed inputs again instead of keeping 48 fp32 copies alive)
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      static_assert(sizeof(vec_t<TX, VEC>) == 16, "16-byte staging registers");
+      u32x4 qx = __builtin_bit_cast(u32x4, rx[c]), qz = __builtin_bit_cast(u32x4, rz[c]), qd = __builtin_bit_cast(u32x4, rd[c]);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { OMK_OPAQUE(qx[e]); OMK_OPAQUE(qz[e]); OMK_OPAQUE(qd[e]); }
+      rx[c] = __builtin_bit_cast(vec_t<TX, VEC>, qx); rz[c] = __builtin_bit_cast(vec_t<TX, VEC>, qz); rd[c] = __builtin_bit_cast(vec_t<TX, VEC>, qd);
+    }
+    if (rlive) {
+#pragma unroll
+      for (int c = 0; c < NCHUNK; c++) {
+        float ox[VEC], oz[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          const float xhat = gv[c][i] * rstd;
+          dwacc[c][i] += to_f32(rd[c].e[i]) * xhat;
+          const float dg = (wdy[c][i] - xhat * c1) * rstd;     // grad wrt the normalised input x silu(z)
+          const float zf = to_f32(rz[c].e[i]), sg = sig[c][i], ds = dg * sg;
+          ox[i] = ds * zf;
+          oz[i] = ds * to_f32(rx[c].e[i]) * (1.f + zf * (1.f - sg));
+        }
+        st<TX, VEC>(dx + rraw * a.dxs + g0 + NORM_COL(c), ox);
+        st<TX, VEC>(dz + rraw * a.dzs + g0 + NORM_COL(c), oz);
+      }
+    }
+  }
+  const int64_t part = bi * RPB + wrow;   // partial rows of this group
+  if (a.dw_part) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) a.dw_part[part * a.cols + g0 + NORM_COL(c) + i] = dwacc[c][i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -463,6 +624,7 @@ static int norm_blocks(int64_t rows, int ngroups, const VecPlan& pl) {
   const int rpb = NORM_WAVES / pl.wpr;
   int64_t per_group = (rows + rpb - 1) / rpb;
   int64_t cap = NORM_MAX_BLOCKS / ngroups;
+  if (const char* e = getenv("OMK_NORM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= 8192) cap = v / ngroups; }   // developer A/B
   if (cap < 1) cap = 1;
   if (per_group > cap) per_group = cap;
   if (per_group < 1) per_group = 1;
@@ -593,6 +755,16 @@ extern "C" int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream) {
   a.rows = rows; a.cols = (int)cols; a.ngroups = (int)(cols / gs); a.wdt = p->weight.dtype; a.bdt = p->bias.dtype; a.eps = p->eps;
   a.rms = 1; a.norm_before_gate = p->norm_before_gate;
   dim3 grid(norm_blocks(rows, a.ngroups, plan)), block(NORM_THREADS);
+  // the reference's mode on full segments (every lane's columns exist): the software-pipelined kernel
+  const bool lean = present(p->z) && !present(p->bias) && !p->norm_before_gate && plan.vec == 8 && gs == (int64_t)plan.wpr * plan.nchunk * 64 * 8 &&
+                    p->x.dtype == OMK_BF16 && !getenv("OMK_NORM_NO_LEAN");
+  if (lean) {
+    if (const char* e = getenv("OMK_NORM_ABL")) a.rms |= atoi(e) & 62;
+    if (plan.wpr == 1) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 4, 1>), grid, block, 0, stream, a);
+    else if (plan.nchunk == 2) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 2, 4>), grid, block, 0, stream, a);
+    else OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 4, 4>), grid, block, 0, stream, a);
+    return finish_launch("norm_gated_fwd");
+  }
   OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_fwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
   return finish_launch("norm_gated_fwd");
 }
@@ -631,6 +803,14 @@ extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
   a.dzs = present(p->dz) ? p->dz.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = ng; a.wdt = p->weight.dtype; a.rms = 1; a.eps = p->eps; a.norm_before_gate = p->norm_before_gate;
   dim3 grid(norm_blocks(rows, ng, plan)), block(NORM_THREADS);
+  const int64_t gsz = cols / ng;
+  const bool lean = present(p->z) && present(p->dz) && !p->norm_before_gate && plan.vec == 8 && gsz == (int64_t)plan.wpr * plan.nchunk * 64 * 8 &&
+                    p->x.dtype == OMK_BF16 && !getenv("OMK_NORM_NO_LEAN");
+  if (lean) {
+    if (plan.wpr == 1) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 1>), grid, block, 0, stream, a);
+    else if (plan.nchunk == 2) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 2, 4>), grid, block, 0, stream, a);
+    else OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 4>), grid, block, 0, stream, a);
+  } else
   OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_bwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
   if (a.dw_part) launch_reduce(a.dw_part, nparts, cols, (float*)p->dweight.data, stream);
   return finish_launch("norm_gated_bwd");

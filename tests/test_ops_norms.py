@@ -74,3 +74,34 @@ def test_norm_gated(dev, dtype, cols, gs, nbg, has_z):
     assert rel(xr.grad.cpu(), xd.grad) < gtol and rel(wr.grad.cpu(), wd.grad) < gtol
     if zr is not None:
         assert rel(zr.grad.cpu(), zd.grad) < gtol
+
+
+@pytest.mark.parametrize("cols", [2048, 4096, 8192])
+def test_norm_gated_lean_kernels_walk_several_rows_per_block(dev, monkeypatch, cols):
+    """The reference's mode on full segments (bf16, gate, norm_before_gate = 0, no bias) takes the software-pipelined forward and the
+    one-sigmoid backward of norms.hip; a grid capped at 64 blocks makes every block walk several rows (next-row loads in flight,
+    ragged last iteration), which the 7-row cases above never do.  Same results as the general kernels, and the oracle's."""
+    from omnimamba_amd.layernorm_gated import rmsnorm_fn
+    monkeypatch.setenv("OMK_NORM_BLOCKS", "64")
+    torch.manual_seed(3)
+    rows = 150 if cols <= 4096 else 70
+    x, z, w = torch.randn(rows, cols).bfloat16(), torch.randn(rows, cols).bfloat16(), torch.randn(cols)
+    gy = torch.randn(rows, cols).bfloat16()
+
+    def run():
+        xr, zr, wr = x.clone().to(dev).requires_grad_(), z.clone().to(dev).requires_grad_(), w.clone().to(dev).requires_grad_()
+        y = rmsnorm_fn(xr, wr, None, z=zr, eps=1e-5, group_size=None, norm_before_gate=False)
+        y.backward(gy.to(dev))
+        return [t.detach().float().cpu() for t in (y, xr.grad, zr.grad, wr.grad)]
+
+    lean = run()
+    monkeypatch.setenv("OMK_NORM_NO_LEAN", "1")
+    gen = run()
+    for a_, b_ in zip(lean, gen):
+        assert rel(a_, b_) < 3e-3
+    xd, zd, wd = x.double().requires_grad_(), z.double().requires_grad_(), w.double().requires_grad_()
+    yd = O.rmsnorm_gated_ref(xd, wd, None, z=zd, eps=1e-5, group_size=None, norm_before_gate=False, compute_dtype=torch.float64)
+    yd.backward(gy.double())
+    assert rel(lean[0], yd) < 6e-3
+    for got, want in zip(lean[1:], (xd.grad, zd.grad, wd.grad)):
+        assert rel(got, want) < 1.5e-2

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd.ssd_combined import ssd_scan_fwd
 
 dev = torch.device("cuda:0")
-B, L, H, P, N, G = 8, int(os.environ.get("SEQ", "4096")), 64, 64, 128, 1
+B, L, H, P, N, G = int(os.environ.get("PB", "8")), int(os.environ.get("SEQ", "4096")), 64, 64, 128, 1
 torch.manual_seed(0)
 xBC = torch.randn(B, L, H * P + 2 * G * N, device=dev).bfloat16()
 x = xBC[..., :H * P].view(B, L, H, P)
