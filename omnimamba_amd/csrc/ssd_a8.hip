@@ -22,9 +22,6 @@
 #include "ssd_scan.h"
 #include "ssd_tiles.h"
 
-#ifndef OMK_A8_DMA
-#define OMK_A8_DMA 0   // K / Q / U tiles reach LDS by DMA (buffer_load ... lds); 0: through staging registers and ds_write
-#endif
 #ifndef OMK_A8_CU
 #define OMK_A8_CU 1    // the compute waves stage the U tile of their own head (half each); 0: the helpers do
 #endif
@@ -143,27 +140,8 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
 #pragma unroll
       for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[r]);
     };
-    // ---- staging by DMA: a request moves 64 x 16 bytes to 1 KB of LDS in lane order, so the lane picks the SOURCE segment that belongs at
-    // its place of the swizzled tile (kx3 / ux3: place p of row i holds segment p ^ swz(i)).  Helper hw moves rows 16 r + 4 hw .. + 3 of the
-    // K and Q tiles (four rows of 256 bytes per request) and rows 16 r + 8 w .. + 7 of its head's U tile (eight rows of 128 bytes), r = 0..3.
-    // No staging registers, no ds_write pass, and the helper waits for its requests ONCE, in front of the barrier of the chunk.
-    const int hw = wave & 3;
-    const int lrk = 4 * hw + (lane >> 4), lru = 8 * w + (lane >> 3);
-    const uint32_t kdo = 2u * (uint32_t)((rev ? 15 - lrk : lrk) * ksl) + 16u * (uint32_t)((lane & 15) ^ swzK(lrk));
-    const uint32_t qdo = 2u * (uint32_t)((rev ? 15 - lrk : lrk) * qsl) + 16u * (uint32_t)((lane & 15) ^ swzK(lrk));
-    const uint32_t udo = 2u * (uint32_t)((rev ? 15 - lru : lru) * usl) + 16u * (uint32_t)((lane & 7) ^ swzU(lru));
-    auto dma_k = [&](int kb, int tl) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) buf_ld16_lds(Kr, &sm.K[kb][(16 * r + 4 * hw) * 128], kdo, 2u * (uint32_t)((tl + (rev ? 16 * (3 - r) : 16 * r)) * ksl));
-    };
-    auto dma_q = [&](int kb, int tl) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) buf_ld16_lds(Qr, &sm.Q[kb][(16 * r + 4 * hw) * 128], qdo, 2u * (uint32_t)((tl + (rev ? 16 * (3 - r) : 16 * r)) * qsl));
-    };
-    auto dma_u = [&](int ub, int tl) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) buf_ld16_lds(Ur, &sm.U[ub][hh][(16 * r + 8 * w) * 64], udo, 2u * (uint32_t)((tl + (rev ? 16 * (3 - r) : 16 * r)) * usl));
-    };
+    // (LDS-DMA staging -- buffer_load ... lds, the swizzle on the source address -- was measured here as in ssd_a6.hip: correct and SLOWER, 207 us
+    // against 183: the DMA path of a CU lands ~12 bytes per cycle, a chunk needs 48 KB; profiles/r05_a8_experiments.txt, git history)
     const float Ah2 = a.A[h] * LOG2E;
     auto scalars = [&](int kb, int mb) {   // helper waves with w == 0 (ssd_a6.hip: the same scalars, lazy decay and factored tile decay)
       {
@@ -280,23 +258,6 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       }
     };
     FragB fb;
-#if OMK_A8_DMA
-    // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built
-    dma_k(0, chunk_lo(c0)); dma_q(0, chunk_lo(c0)); dma_u(0, chunk_lo(c0));
-    prefetch_dt(chunk_lo(c0));
-    if (w == 0) scalars(0, 0);
-    dma_k(1, chunk_lo(clipc(c0 + 1))); dma_q(1, chunk_lo(clipc(c0 + 1)));
-    prefetch_dt(chunk_lo(clipc(c0 + 1)));
-    if (w == 0) scalars(1, 1);
-    prefetch_dt(chunk_lo(clipc(c0 + 2)));
-    OMK_VMCNT(0);
-    block_sync_lds();
-    build_loads(fb, 0, 0);
-    build_flags(fb);
-    build_tile(fb, 0, 0);
-    if (w == 1) build_tile(fb, 0, 1);
-    block_sync_lds();
-#else
     // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built
     prefetch_kq(chunk_lo(c0));
     if (!OMK_A8_CU) prefetch_u(chunk_lo(c0));
@@ -314,7 +275,6 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     prefetch_kq(chunk_lo(clipc(c0 + 2)));
     if (!OMK_A8_CU) prefetch_u(chunk_lo(clipc(c0 + 1)));
     block_sync();
-#endif
     int kb1 = 1, kb2 = 2, kb0 = 0;
     PT8_START();
 #if !defined(OMK_EMU)
@@ -323,34 +283,6 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     for (int c = c0; c < c1; c++) {
       const int ub0 = (c - c0) & 1, ub1 = ub0 ^ 1;
       constexpr bool more = true;   // (behind the last chunk the builders redo its tiles from the re-staged buffers: nobody reads them, no branch)
-#if OMK_A8_DMA
-      // the tiles of chunk c + 1, the requests for chunk c + 2 (K / Q) and c + 1 (U), the scalars of chunk c + 2.  (OMK_A8_VAR ablations,
-      // wrong results: 16 no tile build, 32 no scalars, 128 no requests.)  The steps are fenced: left alone the compiler moved the builder's
-      // LDS reads down to their first use.
-      if (more && !(OMK_A8_VAR & 16)) build_loads(fb, kb1, ub1);
-      OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 128)) { dma_k(kb2, chunk_lo(clipc(c + 2))); dma_q(kb2, chunk_lo(clipc(c + 2))); }
-      OMK_SCHED_FENCE();
-      if (more && !(OMK_A8_VAR & 16)) build_flags(fb);
-      PT8(0);
-      if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 0);
-      PT8(1);
-      OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 128)) dma_u(ub1, chunk_lo(clipc(c + 1)));
-      OMK_SCHED_FENCE();
-      PT8(2);
-      if (w == 0) {
-        if (!(OMK_A8_VAR & 32)) scalars(kb2, ub0);
-        prefetch_dt(chunk_lo(clipc(c + 3)));
-      } else if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 1);
-      PT8(3);
-      OMK_VMCNT(0);
-      PT8(4);
-      block_sync_lds();
-      PT8(5);
-      { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
-      continue;
-#endif
       // the tiles of chunk c + 1, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U), the loads of c + 3 / c + 2
       // (OMK_A8_VAR ablations, wrong results: 16 no tile build, 32 no scalars, 64 no commits, 128 no loads.)  The steps are fenced: left
       // alone the compiler moved the builder's LDS reads down to their first use.
