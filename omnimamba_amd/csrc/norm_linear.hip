@@ -17,6 +17,17 @@
 #include <type_traits>
 #include "omk_common.h"
 
+// the weight stream of a decode step: every byte is read once per step by ONE CU -- non-temporal loads (MI355X_MICROARCH.md, nt-weights:
+// issued -> landed - 18 %); OMK_NL_NT=0 at compile time for the A/B
+#ifndef OMK_NL_NT
+#define OMK_NL_NT 1
+#endif
+#if OMK_NL_NT && !defined(OMK_EMU)
+#define OMK_NL_WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+#else
+#define OMK_NL_WLOAD(p) (*reinterpret_cast<const u32x4*>(p))
+#endif
+
 namespace omk {
 
 constexpr int NL_MAXR = 16;       // LoRA rank
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
 #define NLF_ISSUE_ROW(r0_, j_) do {                                                                  \
     const int rj_ = (r0_) + (j_) * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                        \
     const TW* wp_ = W + (int64_t)rc_ * a.Ws + lane * VEC;                                              \
-    _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j_][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
+    _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j_][u] = OMK_NL_WLOAD(wp_ + u * 64 * VEC); \
   } while (0)
 #pragma unroll
   for (int j = 0; j < RW; j++) NLF_ISSUE_ROW(row0, j);
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(NL_THREADS, 2) void norm_linear_batched_kernel(NlAr
     _Pragma("unroll") for (int j = 0; j < RW; j++) {                                                   \
       const int rj_ = (r0_) + j * nwaves, rc_ = rj_ < a.Out ? rj_ : a.Out - 1;                         \
       const TW* wp_ = W + (int64_t)rc_ * a.Ws + lane * VEC;                                            \
-      _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = *reinterpret_cast<const u32x4*>(wp_ + u * 64 * VEC); \
+      _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j][u] = OMK_NL_WLOAD(wp_ + u * 64 * VEC); \
     } } while (0)
   NLB_ISSUE(row0);
   // ---- preamble, CB sequences at a time (sequences past B repeat the last one; nothing of theirs is stored).  Every

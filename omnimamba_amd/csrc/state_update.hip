@@ -177,7 +177,8 @@ extern "C" int omk_selective_state_update(const OmkStateUpdate* p, omk_stream st
   {
     const int lpr = a.N / 4;
     const bool tied = vec && a.asn == 0 && a.asp == 0 && a.dsp == 0 && (!present(p->dt_bias) || a.tsp == 0) && (lpr == 32 || lpr == 16) && a.N % 4 == 0 &&
-                      p->z.dtype == p->x.dtype && p->out.dtype == p->x.dtype && (int64_t)a.B * a.H * a.P * a.N >= ((int64_t)1 << 21);
+                      (!present(p->z) || p->z.dtype == p->x.dtype) && p->out.dtype == p->x.dtype &&   // (an ABSENT gate has dtype 0 = fp32: the bf16 decode at batch 8 fell to the row kernel)
+                      (int64_t)a.B * a.H * a.P * a.N >= ((int64_t)1 << 21);
     const int rpb = tied ? (64 / lpr) * 4 : 1;
     if (tied && a.P % (rpb * 4) == 0 && !getenv("OMK_STATE_UPDATE_GENERIC")) {
       dim3 grid((unsigned)((int64_t)a.B * a.H * (a.P / (rpb * 4))));
