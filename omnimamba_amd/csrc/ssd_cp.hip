@@ -450,6 +450,23 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       dBt[j] = mfma32x32x16_bf16(fc, tr_frag3<true>(Wlo, 16 * ks, 32 * mbB, lane), dBt[j]);
     }
   }
+  // ---- one head subset (every shape with >= 256 windows): the sums ARE the gradients -- straight out in the gradient's dtype, no fp32
+  // partial round trip (2 x 16.8 MB written + read at B 8, L 4096) and no fold launch
+  if (a.direct) {
+    if (t0 + mrow < a.L) {
+      uint16_t* dCp = (uint16_t*)a.dC + (int64_t)b * a.dcsb + (int64_t)(t0 + mrow) * a.dcsl + (int64_t)g * a.dcsg;
+      uint16_t* dBp = (uint16_t*)a.dB + (int64_t)b * a.dbsb + (int64_t)(t0 + mrow) * a.dbsl + (int64_t)g * a.dbsg;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int n = 32 * (2 * nh + j) + 8 * q + 4 * h32;
+          *reinterpret_cast<u32x2*>(dCp + n) = u32x2{pack_bf16x2(dCt[j][4 * q], dCt[j][4 * q + 1]), pack_bf16x2(dCt[j][4 * q + 2], dCt[j][4 * q + 3])};
+          *reinterpret_cast<u32x2*>(dBp + n) = u32x2{pack_bf16x2(dBt[j][4 * q], dBt[j][4 * q + 1]), pack_bf16x2(dBt[j][4 * q + 2], dBt[j][4 * q + 3])};
+        }
+    }
+    return;
+  }
   // ---- fp32 partials of this head subset: [hs][b][t][g][n]
   if (t0 + mrow < a.L) {
     const int64_t row = ((((int64_t)hs * a.B + b) * a.L + t0 + mrow) * a.G + g) * 128;
@@ -510,6 +527,10 @@ int ssd_cp_heads_split(int B, int L, int H, int G) {
 int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
   CpArgs a = a0;
   if (const char* e = getenv("OMK_CP_ABLATE")) a.ablate = atoi(e);
+  // 8-byte stores of four bf16: rows and group blocks of dB / dC 8-byte aligned (OMK_CP_DIRECT=0: the partial buffers + fold launch)
+  const bool al = (((uintptr_t)a.dB | (uintptr_t)a.dC) & 7) == 0 && ((a.dbsb | a.dbsl | a.dbsg | a.dcsb | a.dcsl | a.dcsg) & 3) == 0;
+  const char* de = getenv("OMK_CP_DIRECT");
+  a.direct = (a.nhs == 1 && a.dB_dt == OMK_BF16 && a.dC_dt == OMK_BF16 && al && !(de && de[0] == '0')) ? 1 : 0;
   const size_t smem = sizeof(SmemCp);
   if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
   dim3 grid((unsigned)((int64_t)a.B * a.G * a.nW * a.nhs)), block(512);
@@ -535,6 +556,7 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
     }
   }
 #endif
+  if (a.direct) return OMK_OK;   // (written by the kernel itself)   // (written by the kernel itself)
   const int64_t total = (int64_t)a.B * a.L * a.G * 16;
   dim3 fgrid((unsigned)((total + 255) / 256), 2u), fblock(256);
   const FoldOne fC = {(const float*)a.pC, a.dC, a.dcsb, a.dcsl, a.dcsg, a.dC_dt}, fB = {(const float*)a.pB, a.dB, a.dbsb, a.dbsl, a.dbsg, a.dB_dt};

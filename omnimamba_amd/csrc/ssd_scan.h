@@ -129,6 +129,7 @@ struct CpArgs {
   float *pB, *pC;                                                 // fp32 partials [nhs][B][L][G][128]
   void *dB, *dC; int64_t dbsb, dbsl, dbsg, dcsb, dcsl, dcsg; int dB_dt, dC_dt;
   int B, L, H, G, nW, nhs;
+  int direct;   // set by ssd_cp_launch: one head subset and bf16 gradients -- the kernel writes dB / dC itself
   int ablate;   // developer only (OMK_CP_ABLATE): phases to skip, wrong results
   unsigned long long* prof;   // developer only (OMK_PHASE_PROF builds, OMK_CP_PROF=1): per-wave phase cycle sums of workgroup 0
 };
