@@ -371,6 +371,27 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     for (int r = 0; r < 4; r++) ru[r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
   };
   auto commit_u = [&](int ub) {
+    if (OMK_A8_VAR & 2048) {
+      // (K2 fusion step (iii), priced: a depthwise conv of width 4 + SiLU on the 32 staged x values of this lane -- the arithmetic the staging
+      // wave would do if the scan read the PRE-conv x; stand-in taps and halo rows, wrong values, representative instruction count)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float v2[2];
+#pragma unroll
+          for (int hlf = 0; hlf < 2; hlf++) {
+            auto el = [&](int rr) -> float { const uint32_t q = ru[rr & 3][e]; return hlf ? bf_hi(q) : bf_lo(q); };
+            const float acc = 0.1f + 0.5f * el(r) + 0.25f * el(r + 1) + 0.125f * el(r + 2) + 0.0625f * el(r + 3);
+            v2[hlf] = silu_fast(acc);
+          }
+          o[e] = pack_bf16x2(v2[0], v2[1]);
+        }
+        st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], o);
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[r]);
   };
