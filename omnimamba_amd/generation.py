@@ -57,6 +57,17 @@ def _stream_base():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
 
 
+def modify_logit_for_repetition_penalty(logits, prev_output_tokens, repetition_penalty=1.0):
+    """Repetition penalty of arXiv:1909.05858 as the reference applies it (generation.py:73-85): the logits (batch, vocab) of every id in
+    ``prev_output_tokens`` (batch, n) are multiplied by the penalty when negative and divided by it otherwise; in place, returns logits."""
+    if repetition_penalty == 1.0:
+        return logits
+    score = torch.gather(logits, 1, prev_output_tokens)
+    score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+    logits.scatter_(1, prev_output_tokens, score)
+    return logits
+
+
 def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
     """(batch, vocab) -> (batch,) token ids.  top_k == 1 is greedy argmax (what the inference scripts use).  With 1 < top_k <= 64 on
     the MI355X the draw is one omk_sample launch (top-k select, temperature, top-p, Philox inverse-CDF draw: csrc/sample.hip) seeded
@@ -263,8 +274,10 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     ``trace`` (optional list) receives (seqlen_offset, position_id) per model call -- the integer state checked bit-exact;
     ``scores`` (optional list) the logits every sampled token was drawn from (the reference's ``output.scores``)."""
     if repetition_penalty != 1.0:
-        # (never passed by OmniMamba; the reference's branch also appends every sampled id twice to the returned matrix, generation.py:246-252)
-        raise NotImplementedError("repetition_penalty != 1.0 is not supported")
+        # never passed by OmniMamba's scripts; taken through the host loop with the reference's own arithmetic (generation.py:73-85,246-252:
+        # gather / scale / scatter on a clone of the logits).  The reference's branch ALSO appends every sampled id twice to the matrix it
+        # returns (`sequences_cat` is extended inside the branch and again behind it): reproduced, so that a caller sees the same tensor.
+        device_loop = False
     if streamer is not None:
         streamer.put(input_ids.cpu())
         device_loop = False                       # a streamer wants every id as it is sampled: host loop
@@ -359,11 +372,15 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
         first, n_in = False, 1
         if scores is not None:
             scores.append(lg.clone() if graph is not None else lg)     # (a captured step returns its static output buffer)
+        if repetition_penalty != 1.0:
+            lg = modify_logit_for_repetition_penalty(lg.clone(), seqs, repetition_penalty)
         if teacher_outputs is not None and teacher_outputs.shape[1] > inference_params.seqlen_offset:
             tok = teacher_outputs[:, inference_params.seqlen_offset]
         else:
             tok = sample(lg, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temperature)
         last = tok.unsqueeze(1)
+        if repetition_penalty != 1.0:
+            seqs = torch.cat([seqs, last], dim=1)      # (the reference's double append, see above)
         seqs = torch.cat([seqs, last], dim=1)
         if streamer is not None:
             streamer.put(last.cpu())

@@ -168,6 +168,15 @@ def reference_model():
                     f"gen.{key}.scores": torch.stack(res.scores, 1).numpy()})
         top2 = torch.stack(res.scores, 1).topk(2, dim=-1).values
         print(task, "ids", res.sequences.tolist(), "min top-1/top-2 logit margin", float((top2[..., 0] - top2[..., 1]).min()))
+    # (v) round 5: the reference's repetition-penalty branch (generation.py:73-85,246-252), drawn after everything else: greedy ids under a
+    # penalty of 1.3 on the t2i prompt above -- including its quirk of appending every sampled id TWICE to the returned matrix
+    pemb = torch.from_numpy(out["gen.t2i.prompt_emb"])
+    ids = torch.zeros(pemb.shape[0], pemb.shape[1], dtype=torch.long)
+    res = model.generate(input_ids=ids, input_embeddings=pemb, cond=None, max_length=int(out["gen.t2i.max_length"]), temperature=1.0, top_p=0.0,
+                         top_k=1, cg=False, task="t2i", repetition_penalty=1.3, return_dict_in_generate=True, output_scores=True)
+    out["gen.t2i_rep.sequences"] = res.sequences.numpy()
+    out["gen.t2i_rep.penalty"] = np.array(1.3)
+    print("t2i with repetition penalty 1.3: ids", res.sequences.tolist())
     np.savez_compressed(os.path.join(HERE, "reference_model.npz"), **out)
     print("reference_model.npz:", {k: v.shape for k, v in out.items() if not k.startswith("sd.")})
     print("state dict keys:", [k[3:] for k in out if k.startswith("sd.")])
