@@ -292,12 +292,12 @@ def _one_step(stage, tasks, seqlen, batch, cfg_kw):
 def test_cfg4_1p3b_stage1_mmu_step_L2048():
     """configs[3]: stage 'align', MMU only: images_feat (B, 729, 2176) -> FusedMLPProjector 2176 -> 8704 -> 2048 -> 2048,
     text ids of length 2048 - 733, projector + MMU LoRA train."""
-    _one_step("align", ("mmu",), 2048, 2, dict(t2i_task=False, mmu_task=True))
+    _one_step("align", ("mmu",), 2048, 8, dict(t2i_task=False, mmu_task=True))      # batch 8: the shape bench.py times (56 GB)
 
 
 def test_cfg5_1p3b_stage2_step_L8192():
     """configs[4]: stage 'finetune', one T2I + one MMU forward of L = 8192 each, one backward, every parameter trains."""
-    _one_step("finetune", ("t2i", "mmu"), 8192, 1, dict())
+    _one_step("finetune", ("t2i", "mmu"), 8192, 2, dict())      # batch 2 per task: the shape bench.py times (split sequences, B H = 128)
 
 
 def test_device_loop_greedy_decode_equals_host_loop(lm_1p3b):
