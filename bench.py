@@ -432,6 +432,13 @@ def main():
 
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+
+    # stdout carries ONE line, the JSON of rank 0.  Everything else a library writes there -- RCCL prints its version banner through C stdio as
+    # soon as a process group exists (N > 1, --force-dist, the ddp_overhead_ms measurement), buffered on a pipe until exit, i.e. AFTER the
+    # JSON -- goes to stderr: file descriptor 1 now points where 2 does, and the line is written to a duplicate of the original descriptor.
+    sys.stdout.flush()
+    real_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,7 +457,8 @@ def main():
         else:
             ok = True
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "n_gpus": world, "ok": bool(ok)}), flush=True)
+            real_out.write(json.dumps({"dry_launch": True, "n_gpus": world, "ok": bool(ok)}) + "\n")
+            real_out.flush()
         return
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     torch.cuda.set_device(local_rank)
@@ -594,7 +602,10 @@ def main():
         out["scan_target"] = extra_tg
         out["decode_1p3b"] = extra_d
         out["cpu_baseline"] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
-        print(json.dumps(out), flush=True)
+        # the JSON line is the ONLY line on the real stdout (see the top of main)
+        sys.stdout.flush()
+        real_out.write(json.dumps(out) + "\n")
+        real_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 

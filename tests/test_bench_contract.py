@@ -58,8 +58,8 @@ def test_bench_launches_itself_for_n_gpus(n):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-launch"], capture_output=True,
                        text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_launch": True, "n_gpus": n, "ok": True}
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_launch": True, "n_gpus": n, "ok": True}, r.stdout[-2000:]
 
 
 def test_bench_under_an_external_launcher_does_not_relaunch():
@@ -81,7 +81,7 @@ def test_bench_force_dist_runs_the_multi_rank_code_on_rccl_with_one_gpu():
                         "--no-cpu-baseline", "--no-selscan-cfg1", "--no-scan-target", "--no-decode", "--no-train-1p3b"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # the RCCL banner (C stdio, flushed at exit) is not on stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["config"]["process_group"] == "nccl" and j["value"] > 0

@@ -25,8 +25,10 @@ for ln in open(src):
         dur[m.group(2).strip()] = float(m.group(1))
 
 
-def pick(sub):
+def pick(sub, optional=False):
     ks = [k for k in kern if sub in k]
+    if optional and not ks:
+        return None
     assert len(ks) == 1, (sub, ks)
     return ks[0]
 
@@ -43,7 +45,7 @@ method = ("rocprofv3 --pmc in separate passes with --kernel-trace only (tools/pm
           "WRITE_SIZE as reported; dt' preparation launch included; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
 dtp = pick("ssd_dt_prep")
 plain, train, dx = pick("ssd_a8_kernel<0, false, false>"), pick("ssd_a8_kernel<0, true, false>"), pick("ssd_a8_kernel<2, true, false>")
-cp, fold, fin = pick("ssd_cp_kernel"), pick("ssd_cp_fold_kernel"), pick("ssd_bwd_finish_par_kernel")
+cp, fold, fin = pick("ssd_cp_kernel"), pick("ssd_cp_fold_kernel", optional=True), pick("ssd_bwd_finish_par_kernel")   # no fold launch when ssd_cp stores bf16 dB / dC itself
 fwd = {
     "kernel": "ssd_a8_kernel<GS_Y, DUMP=false, KHILO=false> (+ ssd_dt_prep_vec_kernel)",
     "workload": "B=8 L=4096 H=64 P=64 N=128 bf16",
@@ -56,6 +58,7 @@ fwd = {
     "method": method, "source": tag}
 bk = {"ssd_a8_kernel<GS_DX, DUMP> (dx scan + adjoint window states)": dx, "ssd_cp_kernel": cp, "ssd_cp_fold_kernel": fold,
       "ssd_bwd_finish_par_kernel": fin, "ssd_dt_prep_vec_kernel": dtp}
+bk = {n: k for n, k in bk.items() if k is not None}
 bwd = {"kernels": {n: traffic(k) for n, k in bk.items()}, "kernel_us": {n: dur.get(k) for n, k in bk.items()},
        "workload": "B=8 L=4096 H=64 P=64 N=128 bf16, forward window states saved by the training forward",
        "traffic_bytes_per_launch": sum(traffic(k) for k in bk.values()), "mfma_busy": round(busy(list(bk.values())), 4),
