@@ -16,6 +16,7 @@
 // 70 MB) and 12.5 us (gated norm + out_proj, 33.5 MB) per layer-step of the 1.3B model, 12.8 us for the bare in_proj GEMV.
 #include <type_traits>
 #include "omk_common.h"
+#include "ssd_tiles.h"
 
 // the weight stream of a decode step: every byte is read once per step by ONE CU -- non-temporal loads (MI355X_MICROARCH.md, nt-weights:
 // issued -> landed - 18 %); OMK_NL_NT=0 at compile time for the A/B
@@ -654,6 +655,240 @@ __global__ __launch_bounds__(NL_THREADS, 2) void norm_linear_batched_kernel(NlAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two to eight sequences, 16-bit weights: the rows on the MATRIX pipe (round 5).
+//
+// The vector form above spends ~130 issue slots per 16-byte weight vector at eight sequences (8 x 8 multiply-adds + the unpacking of both
+// operands): 33 us for the 35 MB of a bf16 in_proj -- the same as for the 70 MB of the fp32 one, not memory bound.  Here the unit of work is
+// a TILE of 16 output rows; the waves of a workgroup take a slice of the input features each, and a 16-byte weight vector is an operand as
+// it lands: lane (i = lane & 15, g = lane >> 4) loads the 8 features [32 s + 8 g, + 8) of row i of the tile, which IS the A fragment of
+// v_mfma_f32_16x16x32_bf16; the B fragment is the same features of sequence lane & 15 from the bf16 u in LDS (one ds_read_b128; u rows 16
+// bytes apart in bank space).  One matrix instruction per KB of weights instead of ~130 vector instructions; exact fp32 products and sums
+// either way.  D[r] of a lane = row 4 g + r of the tile, sequence i.
+//   * ONE workgroup per CU walks its tiles (blockIdx.x, + gridDim.x, ...): the preamble -- u = norm input of every sequence, 64 values per
+//     thread at eight sequences -- runs once per CU, not once per tile (a workgroup per tile: 21 us for the in_proj of the 1.3B model, a third
+//     of it 532 preambles on 256 CUs);
+//   * two tiles of weights are in flight per workgroup at any time (two register sets, all loads of a wave's slice at once), together with
+//     the operands thread (row i, sequence b) needs to finish its element: LoRA B row, bias, conv taps and conv state;
+//   * x is requested FIRST (the load counter returns in order: a wait for x must not be a wait for the weights);
+//   * the LoRA vector h = A u is one more 8-row tile on the same u, once per workgroup (A from L2, requested when the preamble's registers
+//     are free);
+//   * the waves' partial tiles meet in LDS (two buffers: one barrier per tile); thread (i, b) adds them up: LoRA, rstd, bias, conv tail.
+// NT = 512 threads (eight feature slices) for 2048 and 4096 input features, 256 for 1024.
+template <class TW, class TR, int NQ, int RMAX, int NB, bool GATE, int NT>
+__global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
+  using TU = typename lds_u<TW>::type;
+  constexpr int In = 1024 * NQ, VEC = 16 / sizeof(TW), NWV = NT / 64;
+  constexpr int NQT = In / (4 * NT);                                        // 4-element pieces per thread and sequence
+  constexpr int US = In + 16 / (int)sizeof(TU);
+  constexpr int KL = 4 * VEC, KPW = In / NWV, NLD = KPW / KL;               // features per wave load, per wave; loads per lane and tile
+  static_assert(sizeof(TW) == 2 && NQT >= 1 && NQT * 4 * NT == In && 16 * NB <= NT && NLD <= 16 && RMAX <= 8, "shape");
+  OMK_DYN_SMEM(smem);
+  TU* sn = (TU*)smem;                                            // [NB][US] u
+  float* part = (float*)(smem + (size_t)NB * US * sizeof(TU));   // [waves][NB][8] LoRA partials
+  float* red = part + NWV * NB * 8;                              // [waves][NB] sums of squares
+  float* hs = red + NWV * NB;                                    // [NB][8] LoRA vector, [NB] rstd
+  float* rstd = hs + NB * 8;
+  float* res = rstd + NB;                                        // [2][waves][16 rows][NB] partial tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t16 = lane & 15, g16 = lane >> 4;
+  using TA = typename std::conditional<GATE, TW, TR>::type;      // second input: gate or residual
+  const bool hasaux = GATE ? true : a.res != nullptr;
+  // the inputs of EVERY sequence are requested here, ahead of everything else and as stored (16-bit values stay packed: 48 - 64 registers
+  // at eight sequences): a request issued behind the weights returns behind them (in-order counter) -- a second group of sequences
+  // fetched inside the preamble made it wait for both tiles of weights to land, + 2.4 us at eight sequences
+  constexpr int AW = sizeof(TA) == 4 ? 4 : 2;
+  uint32_t xr[NB][NQT][2], ar[NB][NQT][AW];
+#pragma unroll
+  for (int bb = 0; bb < NB; bb++) {
+    const int b = bb < a.B ? bb : a.B - 1;
+    const TW* xp = (const TW*)a.x + (int64_t)b * a.xs;
+    const TA* ap = GATE ? (const TA*)a.z + (int64_t)b * a.zs : (hasaux ? (const TA*)a.res + (int64_t)b * a.rs : (const TA*)xp);
+#pragma unroll
+    for (int k = 0; k < NQT; k++) {
+      const int c = 4 * (tid + NT * k);
+      const u32x2 q = *reinterpret_cast<const u32x2*>(xp + c);
+      xr[bb][k][0] = q[0]; xr[bb][k][1] = q[1];
+      if constexpr (AW == 4) { const u32x4 r = *reinterpret_cast<const u32x4*>(ap + (hasaux ? c : 0)); ar[bb][k][0] = r[0]; ar[bb][k][1] = r[1]; ar[bb][k][2] = r[2]; ar[bb][k][3] = r[3]; }
+      else { const u32x2 r = *reinterpret_cast<const u32x2*>(ap + (hasaux ? c : 0)); ar[bb][k][0] = r[0]; ar[bb][k][1] = r[1]; }
+    }
+  }
+  float n4[NQT][4];
+#pragma unroll
+  for (int k = 0; k < NQT; k++) load_vec<TW, 4>((const TW*)a.nw + 4 * (tid + NT * k), n4[k]);
+  OMK_SCHED_FENCE();
+  // ---- tiles of this workgroup; what travels with a tile: the wave's slice of its 16 rows, the finish operands of thread (i, b)
+  const int ntile = (a.Out + 15) >> 4, gstep = (int)gridDim.x;
+  const int fi = tid & 15, fb = tid >> 4;
+  constexpr int LBR = RMAX > 0 ? 4 : 1;
+  static_assert(RMAX == 0 || RMAX == 8, "LoRA B rows of 16 bytes");
+  // (raw 16-bit values from clamped, always valid addresses: no branch and no conversion between two loads -- with the selects and
+  // conversions next to the loads every one of the ~12 small loads of a thread became its own branch + s_waitcnt vmcnt(0), ~4 us per call)
+  struct Fin { uint32_t lbq[LBR]; uint32_t hist[3], wt[4], cbias, bias; };   // (one register per value: 16-bit members get packed -- a wait)
+  const bool conv_on = a.cst != nullptr;
+  const int convC = a.cc1 - a.cc0;
+  auto load_w = [&](u32x4 (&w)[NLD], int t) {
+    const int rt = 16 * t + t16;
+    const TW* wp = (const TW*)a.W + (int64_t)(rt < a.Out ? rt : a.Out - 1) * a.Ws + wave * KPW + VEC * g16;
+#pragma unroll
+    for (int s = 0; s < NLD; s++) w[s] = OMK_NL_WLOAD(wp + KL * s);
+  };
+  auto raw16 = [](const TW* p) -> uint32_t { return *reinterpret_cast<const uint16_t*>(p); };
+  auto load_fin = [&](Fin& f, int t) {   // (no branch in here: without the conv tail the taps and the state read a valid dummy address)
+    const int fr = 16 * t + fi, frow = fr < a.Out ? fr : a.Out - 1, fbc = fb < a.B ? fb : a.B - 1;
+    if constexpr (RMAX > 0) {   // the LoRA B row as stored, RMAX 16-bit values = 16 bytes (the launcher checks R == RMAX and the alignment)
+      const u32x4 q = *reinterpret_cast<const u32x4*>((const TW*)a.lb + (int64_t)frow * a.lbs);
+      f.lbq[0] = q[0]; f.lbq[1] = q[1]; f.lbq[2] = q[2]; f.lbq[3] = q[3];
+    } else {
+      f.lbq[0] = 0u;
+    }
+    f.bias = a.bias ? raw16((const TW*)a.bias + frow) : 0u;   // (the projections of the model have none: a uniform branch)
+    const int c_ = frow - a.cc0, ch = c_ < 0 ? 0 : (c_ < convC ? c_ : convC - 1);
+    const TW* wr_ = conv_on ? (const TW*)a.ccw + (int64_t)ch * a.ccws : (const TW*)a.W;
+    const TW* cs = conv_on ? (const TW*)a.cst + (int64_t)fbc * a.csb + (int64_t)ch * a.csc : (const TW*)a.W;
+    const int64_t csl = conv_on ? a.csl : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); f.wt[k] = raw16(wr_ + (col >= 0 ? col : 0)); }
+    f.cbias = raw16(a.ccb ? (const TW*)a.ccb + ch : wr_);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; f.hist[k] = raw16(cs + (int64_t)(sl >= 0 ? sl : 0) * csl); }
+  };
+  // (order of the requests = order of their return: everything small in front of the weights, so that neither the preamble nor the LoRA
+  // tile nor the finish of the first tile waits for the second tile's weights to land)
+  u32x4 wA[NLD], wB[NLD];
+  Fin fA, fB;
+  const int tfirst = (int)blockIdx.x;
+  load_fin(fA, tfirst);
+  if (tfirst + gstep < ntile) load_fin(fB, tfirst + gstep);
+  u32x4 wl[RMAX > 0 ? NLD : 1];
+  constexpr bool LORA_EARLY = RMAX > 0 && NLD <= 8;   // (16 loads per lane next to the preamble's registers: spills at 256)
+  auto load_lora = [&]() {
+    const int r8 = t16 & 7;
+    const TW* lap = (const TW*)a.la + (int64_t)(r8 < a.R ? r8 : 0) * a.las + wave * KPW + VEC * g16;
+#pragma unroll
+    for (int s = 0; s < NLD; s++) wl[s] = *reinterpret_cast<const u32x4*>(lap + KL * s);
+  };
+  if constexpr (LORA_EARLY) load_lora();
+  OMK_SCHED_FENCE();
+  load_w(wA, tfirst);
+  if (tfirst + gstep < ntile) load_w(wB, tfirst + gstep);
+  OMK_SCHED_FENCE();
+  // ---- preamble: u = (x + residual | x silu(z)) * w of every sequence into LDS, sums of squares per wave
+  auto un16 = [](uint32_t r, int i) -> float {   // element i (0 / 1) of a packed pair of TW
+    if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, i ? (r & 0xffff0000u) : (r << 16));
+    else return to_f32(__builtin_bit_cast(TW, (uint16_t)(i ? r >> 16 : r)));
+  };
+#pragma unroll
+  for (int bb = 0; bb < NB; bb++) {
+    float ssq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQT; k++) {
+      const int c = 4 * (tid + NT * k);
+      float vv4[4], t4[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float x_ = un16(xr[bb][k][i >> 1], i & 1), g = 1.f, aux;
+        if constexpr (AW == 4) aux = __builtin_bit_cast(float, ar[bb][k][i]);
+        else aux = un16(ar[bb][k][i >> 1], i & 1);
+        if constexpr (GATE) g = silu_fast(aux);
+        else { x_ += hasaux ? aux : 0.f; t4[i] = x_; }                 // t4: residual_out
+        const float q = (GATE && !a.nbg) ? x_ * g : x_;
+        ssq += q * q;
+        vv4[i] = q * n4[k][i] * ((GATE && a.nbg) ? g : 1.f);
+      }
+      store_vec<TU, 4>(sn + (size_t)bb * US + c, vv4);
+      if constexpr (!GATE) {
+        if (a.ro && blockIdx.x == 0 && bb < a.B) store_vec<TR, 4>((TR*)a.ro + (int64_t)bb * a.ros + c, t4);
+      }
+    }
+    ssq = wave_sum(ssq);
+    if (lane == 0) red[wave * NB + bb] = ssq;
+  }
+  if constexpr (RMAX > 0 && !LORA_EARLY) load_lora();
+  block_sync();
+  const TU* up = sn + (size_t)(t16 & (NB - 1)) * US + wave * KPW + VEC * g16;
+  if constexpr (RMAX > 0) {   // h[rank][sequence] of this wave's slice: ranks 4 g + r (g < 2), sequence lane & 15
+    f32x4 hacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NLD; s++) hacc[s & 1] = mfma16x16x32_bf16(as_s16x8(wl[s]), as_s16x8(ld16(up + KL * s)), hacc[s & 1]);
+    if (t16 < NB && g16 < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) part[(wave * NB + t16) * 8 + 4 * g16 + r] = 4 * g16 + r < a.R ? hacc[0][r] + hacc[1][r] : 0.f;
+    }
+    block_sync();
+  }
+  // the sums over the waves once per workgroup, not once per finishing thread and tile: h[b][r] and rstd[b] (visible behind the barrier of
+  // the first tile)
+  if (RMAX > 0 && tid < 8 * NB) {
+    float h = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NWV; w2++) h += part[w2 * NB * 8 + tid];
+    hs[tid] = h;
+  }
+  if (tid >= NT - NB) {
+    const int b = tid - (NT - NB);
+    float ss = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NWV; w2++) ss += red[w2 * NB + b];
+    rstd[b] = rsqrtf(ss / (float)In + a.eps);
+  }
+  // one tile: products of the landed slice, the slice and the finish operands of the tile two steps on requested into the freed
+  // registers, partial tile to LDS, barrier, finish
+  auto tile_step = [&](u32x4 (&w)[NLD], Fin& f, int t, int par) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NLD; s++) acc[s & 1] = mfma16x16x32_bf16(as_s16x8(w[s]), as_s16x8(ld16(up + KL * s)), acc[s & 1]);
+    const Fin fc = f;
+    const int tn = t + 2 * gstep;
+    if (tn < ntile) { load_w(w, tn); load_fin(f, tn); }
+    float* rs = res + par * (NWV * 16 * NB);
+    if (t16 < NB) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) rs[(wave * 16 + 4 * g16 + r) * NB + t16] = acc[0][r] + acc[1][r];
+    }
+    block_sync();
+    const int frow = 16 * t + fi;
+    if (fb < NB && fb < a.B && frow < a.Out) {
+      // (bf16 from the raw register by a shift: a truncation to 16 bits here becomes an AND the compiler hoists up to the load -- a wait)
+      auto f16 = [](uint32_t r) -> float {
+        if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, r << 16);
+        else return to_f32(__builtin_bit_cast(TW, (uint16_t)r));
+      };
+      float vv = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; w2++) vv += rs[(w2 * 16 + fi) * NB + fb];
+      if constexpr (RMAX > 0) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++)
+          d += ((r & 1) ? f16(fc.lbq[r >> 1] >> 16) : f16(fc.lbq[r >> 1])) * hs[fb * 8 + r];   // (ranks >= R: h is zero)
+        vv += a.scale * d;
+      }
+      vv = vv * rstd[fb] + (a.bias ? f16(fc.bias) : 0.f);
+      const TW xr = from_f32<TW>(vv);
+      const float xin = to_f32(xr);
+      if (conv_on && frow >= a.cc0 && frow < a.cc1) {
+        float wt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wt[k] = k - (4 - a.cW) >= 0 ? f16(fc.wt[k]) : 0.f;
+        const float cv = (a.ccb ? f16(fc.cbias) : 0.f) + wt[0] * f16(fc.hist[0]) + wt[1] * f16(fc.hist[1]) + wt[2] * f16(fc.hist[2]) + wt[3] * xin;
+        vv = a.csilu ? silu_f(cv) : cv;
+        TW* cs = (TW*)a.cst + (int64_t)fb * a.csb + (int64_t)(frow - a.cc0) * a.csc;
+        for (int sl = 0; sl + 1 < a.cS; sl++) {      // roll: the stored values move as they are
+          const int k = sl + 1 - (a.cS - 3);
+          cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, (uint16_t)(k == 0 ? fc.hist[0] : (k == 1 ? fc.hist[1] : fc.hist[2])));
+        }
+        cs[(int64_t)(a.cS - 1) * a.csl] = xr;
+      }
+      ((TW*)a.out)[(int64_t)fb * a.os + frow] = from_f32<TW>(vv);
+    }
+  };
+  for (int t = tfirst; t < ntile; t += 2 * gstep) {
+    tile_step(wA, fA, t, 0);
+    if (t + gstep < ntile) tile_step(wB, fB, t + gstep, 1);
+  }
+}
+
 // compute units of the current device (cached; 256 on the MI355X and under the emulator)
 static int cu_count() {
 #ifdef OMK_EMU
@@ -759,6 +994,30 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       dim3 bgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), bblock(NL_THREADS);
       const bool gate = present(p->z);
       if (gate && present(p->residual)) return fail(OMK_EUNSUPPORTED, "norm_linear: residual and gate together are served by the batch-1 kernel only");
+      // 16-bit weights: the matrix-pipe form, a workgroup per tile of 16 rows (OMK_NL_MFMA=0: the vector form, for the A/B)
+      static const bool use_mfma = !(getenv("OMK_NL_MFMA") && atoi(getenv("OMK_NL_MFMA")) == 0);
+      const bool lora_rows16 = a.R == 0 || (a.R == 8 && a.lbs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.lb) & 15) == 0);   // B rows read as one 16-byte load
+      if (use_mfma && wdt == OMK_BF16 && lora_rows16) {
+        const int nwv = nq == 1 ? 4 : 8, ntile = (a.Out + 15) / 16;
+        const size_t msmem = (size_t)nb * (a.In + 8) * 2 + (size_t)nwv * nb * (9 + 2 * 16) * 4 + (size_t)nb * 9 * 4;
+        int wgs = cu_count();
+        if (const char* e = getenv("OMK_NL_MFMA_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;   // tests: several tiles per workgroup on small matrices
+        dim3 mgrid((unsigned)(ntile < wgs ? ntile : wgs));
+#define NLM_G(TR_, NQ_, RM_, NB_, G_) do { constexpr int NT_ = NQ_ == 1 ? 256 : 512; \
+          if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<bf16_t, TR_, NQ_, RM_, NB_, G_, NT_>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
+          OMK_LAUNCH((norm_linear_mfma_kernel<bf16_t, TR_, NQ_, RM_, NB_, G_, NT_>), mgrid, dim3(NT_), msmem, stream, a); } while (0)
+#define NLM_GO(TR_, NQ_, RM_, NB_) do { if (gate) NLM_G(TR_, NQ_, RM_, NB_, true); else NLM_G(TR_, NQ_, RM_, NB_, false); } while (0)
+#define NLM_B(TR_, NQ_, RM_) do { if (nb == 2) NLM_GO(TR_, NQ_, RM_, 2); else if (nb == 4) NLM_GO(TR_, NQ_, RM_, 4); else NLM_GO(TR_, NQ_, RM_, 8); } while (0)
+#define NLM_R(TR_, NQ_) do { if (a.R > 0) NLM_B(TR_, NQ_, 8); else NLM_B(TR_, NQ_, 0); } while (0)
+#define NLM_Q(TR_) do { if (nq == 1) NLM_R(TR_, 1); else if (nq == 2) NLM_R(TR_, 2); else NLM_R(TR_, 4); } while (0)
+        if (trdt == OMK_F32) NLM_Q(float); else NLM_Q(bf16_t);
+#undef NLM_Q
+#undef NLM_R
+#undef NLM_B
+#undef NLM_GO
+#undef NLM_G
+        return finish_launch("norm_linear");
+      }
 #define NLB_G(TW_, TR_, NQ_, RM_, NB_, G_) do { \
         if (OMK_SET_MAX_DYN_SMEM((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", bsmem); \
         OMK_LAUNCH((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bgrid, bblock, bsmem, stream, a); } while (0)

@@ -147,6 +147,34 @@ def test_batched_variant(dev, B, In, Out, dtype, rdtype, mode):
         assert out.shape == (B, Out) and out.dtype == dtype and rel(out, y0.double()) < tol, step
 
 
+@pytest.mark.parametrize("wgs", [1, 3, 4])
+def test_batched_bf16_matrix_form_walks_several_tiles_per_workgroup(dev, wgs, monkeypatch):
+    """16-bit weights, two to eight sequences: a workgroup of norm_linear_mfma_kernel walks the tiles blockIdx.x, + gridDim.x, ... with two
+    register sets of weights and finish operands in flight (the 1.3B in_proj: 532 tiles on 256 workgroups).  Forced here on a small matrix
+    (OMK_NL_MFMA_WGS): 13 tiles on 1 / 3 / 4 workgroups -- odd and even tile counts per workgroup, a ragged last tile, LoRA, conv tail over
+    two steps; and the same call through the vector form (OMK_NL_MFMA=0 is read once per process, so the comparison is with the composition)."""
+    from omnimamba_amd.norm_linear import norm_linear
+    monkeypatch.setenv("OMK_NL_MFMA_WGS", str(wgs))
+    torch.manual_seed(3)
+    B, In, Out, dtype, C, off, W, S = 5, 2048, 200, torch.bfloat16, 100, 60, 4, 3
+    nw, Wt, bias = (torch.rand(In) + 0.5).to(dtype), (torch.randn(Out, In) * 0.05).to(dtype), torch.randn(Out).to(dtype)
+    la, lb = (torch.randn(8, In) * 0.05).to(dtype), (torch.randn(Out, 8) * 0.05).to(dtype)
+    cw, cb = (torch.randn(C, W) * 0.5).to(dtype), (torch.randn(C) * 0.2).to(dtype)
+    cst = torch.randn(B, S, C).to(dtype).transpose(1, 2)
+    cst_d, cst0 = cst.transpose(1, 2).contiguous().to(dev).transpose(1, 2), cst.clone()
+    for step in range(2):
+        x, res = torch.randn(B, In).to(dtype), torch.randn(B, In)
+        out, ro = norm_linear(x.to(dev), Wt.to(dev), bias.to(dev), norm_weight=nw.to(dev), eps=1e-5, residual=res.to(dev), residual_out_dtype=torch.float32,
+                              lora_a=la.to(dev), lora_b=lb.to(dev), lora_scale=4.0, conv_state=cst_d, conv_weight=cw.to(dev), conv_bias=cb.to(dev), conv_offset=off)
+        q = x.double() + res.double()
+        n0 = (q * torch.rsqrt((q * q).mean(-1, keepdim=True) + 1e-5) * nw.double()).to(dtype).double()
+        y0 = (n0 @ Wt.double().t() + bias.double() + 4.0 * (n0 @ la.double().t()) @ lb.double().t()).to(dtype)
+        y0[:, off:off + C] = O.causal_conv1d_update_ref(y0[:, off:off + C].clone(), cst0, cw, cb, activation="silu")
+        assert rel(ro, q) < 1e-6 and rel(cst_d, cst0.double()) < 6e-3, step
+        assert rel(out, y0.double()) < 1e-2, step
+        assert float((out.double().cpu() - y0.double()).abs().max()) < 0.08, step       # no row or sequence left out / taken twice
+
+
 def test_residual_out_without_incoming_residual(dev):
     """First block of a stack: no residual yet, residual_out must still be x (in the requested dtype)."""
     from omnimamba_amd.norm_linear import norm_linear
