@@ -251,9 +251,10 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
     const TW* wp_ = W + (int64_t)rc_ * a.Ws + lane * VEC;                                              \
     _Pragma("unroll") for (int u = 0; u < UNE; u++) wr[j_][u] = OMK_NL_WLOAD(wp_ + u * 64 * VEC); \
   } while (0)
-#pragma unroll
-  for (int j = 0; j < RW; j++) NLF_ISSUE_ROW(row0, j);
   // ---- preamble: a thread owns the 4-column groups tid, tid + 256, ...
+  // Order of the requests (round 5): the activations and the LoRA A rows FIRST, the weight rows behind them.  The load counter returns in
+  // order, so with the weights in front (rounds 1 - 4) the norm could not start before all sixteen weight requests of the lane had landed
+  // from HBM, and each batch of A rows was one more round trip behind that.
   const bool hasres = a.res != nullptr, hasz = a.z != nullptr;
   const TW* xp = (const TW*)a.x;
   const TR* rp = hasres ? (const TR*)a.res : (const TR*)a.x;      // absent: any valid 16 bytes, the value is not used
@@ -268,7 +269,12 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
     load_vec<TW, 4>((const TW*)a.nw + c, n4[k]);
   }
   // the LoRA A rows ride on the same round trip when they fit the registers (each later wait would be another one)
-  constexpr bool A_UP = false;   // measured at one sequence: requesting all rows up front is 1.3 us SLOWER (18.6 vs 17.3 us)
+  // (all A rows up front: measured slower twice -- round 2 behind the weights 18.6 vs 17.3 us, round 5 in front of them 17.7 / 13.7 us vs
+  // 17.5 / 13.2 us for fp32 / bf16; the activations in front of the weights: out_proj 10.2 -> 10.0 us, 6.6 -> 6.2 us.  OMK_NLF_A_UP=1 for the A/B)
+#ifndef OMK_NLF_A_UP
+#define OMK_NLF_A_UP 0
+#endif
+  constexpr bool A_UP = OMK_NLF_A_UP && RMAX > 0 && RMAX * NQ <= 16;
   float aup[A_UP ? RMAX : 1][NQ][4];
   if constexpr (A_UP) {
 #pragma unroll
@@ -277,6 +283,10 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
       for (int k = 0; k < NQ; k++)
         load_vec<TW, 4>((const TW*)a.la + (int64_t)(r < a.R ? r : 0) * a.las + 4 * (tid + NL_THREADS * k), aup[r][k]);
   }
+  OMK_SCHED_FENCE();
+#pragma unroll
+  for (int j = 0; j < RW; j++) NLF_ISSUE_ROW(row0, j);
+  OMK_SCHED_FENCE();
   float ssq = 0.f;
 #pragma unroll
   for (int k = 0; k < NQ; k++) {
@@ -333,6 +343,43 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
       const f32x4 t = *reinterpret_cast<const f32x4*>(&sn[u * 64 * VEC + lane * VEC + i]);
       ur[u][i] = t[0]; ur[u][i + 1] = t[1]; ur[u][i + 2] = t[2]; ur[u][i + 3] = t[3];
     }
+  // ---- what lane s needs to finish the s-th row of its wave (LoRA B row, bias, conv taps and conv state), requested HERE, ahead of the
+  // row loop: as stored (no conversion next to a load) and from clamped, always valid addresses (no branch between two loads).  In the
+  // finish itself these were three dependent round trips behind the last weight -- LoRA B row, then the bias, then taps and state under
+  // their branches, each an s_waitcnt vmcnt(0): ~ 4 us of the 17.8 us of the 1.3B in_proj step (round 5, same finding as in
+  // norm_linear_mfma_kernel below).
+  auto rawld = [](const TW* p_) -> uint32_t {
+    if constexpr (sizeof(TW) == 4) return *reinterpret_cast<const uint32_t*>(p_);
+    else return *reinterpret_cast<const uint16_t*>(p_);
+  };
+  auto rawf = [](uint32_t r_) -> float {   // (16-bit: by a shift -- a truncation becomes an AND the compiler hoists up to the load, a wait)
+    if constexpr (sizeof(TW) == 4) return __builtin_bit_cast(float, r_);
+    else if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, r_ << 16);
+    else return to_f32(__builtin_bit_cast(TW, (uint16_t)r_));
+  };
+  const int frow_ = wg + lane * nwaves, frow = frow_ < a.Out ? frow_ : a.Out - 1;
+  const bool conv_on = a.cst != nullptr;
+  uint32_t q_lb[RMAX > 0 ? RMAX : 1], q_wt[4], q_hist[3], q_cb, q_bias = 0u;
+  {
+    if constexpr (RMAX > 0) {
+      const TW* lbp = (const TW*)a.lb + (int64_t)frow * a.lbs;
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) q_lb[r] = rawld(lbp + (r < a.R ? r : 0));      // (ranks >= R: their h is zero)
+    } else {
+      q_lb[0] = 0u;
+    }
+    if (a.bias) q_bias = rawld((const TW*)a.bias + frow);                           // (uniform; the projections of the model have none)
+    const int convC = a.cc1 - a.cc0, c_ = frow - a.cc0, ch = c_ < 0 ? 0 : (c_ < convC ? c_ : convC - 1);
+    const TW* wr_ = conv_on ? (const TW*)a.ccw + (int64_t)ch * a.ccws : W;
+    const TW* cs = conv_on ? (const TW*)a.cst + (int64_t)ch * a.csc : W;
+    const int64_t csl = conv_on ? a.csl : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); q_wt[k] = rawld(wr_ + (col >= 0 ? col : 0)); }
+    q_cb = rawld(a.ccb ? (const TW*)a.ccb + ch : wr_);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; q_hist[k] = rawld(cs + (int64_t)(sl >= 0 ? sl : 0) * csl); }
+  }
+  OMK_SCHED_FENCE();
   // ---- rows: a batch = RW rows; as soon as a row's products are done its registers take the same row of the next
   // batch, so (RW - 1) / RW of the requests stay in flight through the reductions.  The trip count is uniform (the
   // host sizes the grid for nbatch full batches per wave) and the loads are unconditional: the compiler counts them.
@@ -356,39 +403,40 @@ __global__ __launch_bounds__(NL_THREADS) void norm_linear_fast_kernel(NlArgs a) 
   }
   const int slot = a.nbatch * RW;
 #undef NLF_ISSUE_ROW
-  // ---- lane s finishes the s-th row of this wave: LoRA B term, norm scale, bias, store
+  // ---- lane s finishes the s-th row of this wave: LoRA B term, norm scale, bias, conv tail, store
   const int row = wg + lane * nwaves;
   if (lane < slot && row < a.Out) {
     float vv = keep;
     if (RMAX > 0) {
-      const TW* lbp = (const TW*)a.lb + (int64_t)row * a.lbs;
       float d = 0.f;
 #pragma unroll
       for (int r = 0; r < RMAX; r++) {
         const float h = part[r] + part[8 + r] + part[16 + r] + part[24 + r];     // zero beyond R
-        d += to_f32(lbp[r < a.R ? r : 0]) * h;
+        d += rawf(q_lb[r]) * h;
       }
       vv += a.scale * d;
     }
     vv *= rstd;
-    if (a.bias) vv += to_f32(((const TW*)a.bias)[row]);
-    if (a.cst && row >= a.cc0 && row < a.cc1) {
+    if (a.bias) vv += rawf(q_bias);
+    if (conv_on && row >= a.cc0 && row < a.cc1) {
       // this row is a new xBC input: causal_conv1d_update for its channel, right here (no other lane touches it)
       const int ch = row - a.cc0;
       TW* cs = (TW*)a.cst + (int64_t)ch * a.csc;
-      const TW* wr_ = (const TW*)a.ccw + (int64_t)ch * a.ccws;
       float hist[3], wt[4];
 #pragma unroll
-      for (int k = 0; k < 3; k++) { const int sl = a.cS - 3 + k; hist[k] = to_f32(cs[(int64_t)(sl >= 0 ? sl : 0) * a.csl]); }
+      for (int k = 0; k < 3; k++) hist[k] = rawf(q_hist[k]);
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int col = k - (4 - a.cW); wt[k] = col >= 0 ? to_f32(wr_[col >= 0 ? col : 0]) : 0.f; }
-      const float xin = to_f32(from_f32<TW>(vv));            // the value upstream would have stored in zxbcdt
-      float cv = (a.ccb ? to_f32(((const TW*)a.ccb)[ch]) : 0.f) + wt[0] * hist[0] + wt[1] * hist[1] + wt[2] * hist[2] + wt[3] * xin;
-      for (int sl = 0; sl + 1 < a.cS; sl++) {                 // roll: slot sl <- slot sl + 1 = hist[sl + 1 - (S - 3)]
+      for (int k = 0; k < 4; k++) wt[k] = k - (4 - a.cW) >= 0 ? rawf(q_wt[k]) : 0.f;
+      const TW xr_ = from_f32<TW>(vv);
+      const float xin = to_f32(xr_);                          // the value upstream would have stored in zxbcdt
+      float cv = (a.ccb ? rawf(q_cb) : 0.f) + wt[0] * hist[0] + wt[1] * hist[1] + wt[2] * hist[2] + wt[3] * xin;
+      for (int sl = 0; sl + 1 < a.cS; sl++) {                 // roll: slot sl <- slot sl + 1 = hist[sl + 1 - (S - 3)] (the stored value moves as it is)
         const int k = sl + 1 - (a.cS - 3);
-        cs[(int64_t)sl * a.csl] = from_f32<TW>(k == 0 ? hist[0] : (k == 1 ? hist[1] : hist[2]));
+        const uint32_t qv = k == 0 ? q_hist[0] : (k == 1 ? q_hist[1] : q_hist[2]);
+        if constexpr (sizeof(TW) == 4) cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, qv);
+        else cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, (uint16_t)qv);
       }
-      cs[(int64_t)(a.cS - 1) * a.csl] = from_f32<TW>(xin);
+      cs[(int64_t)(a.cS - 1) * a.csl] = xr_;
       vv = a.csilu ? silu_f(cv) : cv;
     }
     ((TW*)a.out)[row] = from_f32<TW>(vv);
