@@ -1088,7 +1088,8 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       const int vecw = wdt == OMK_F32 ? 4 : 8;
       const int steps_row = a.In / (64 * vecw), rw = 16 / steps_row;   // rows per batch (16 loads of 16 bytes per lane)
       // waves: every wave takes k full batches of rw rows (k as small as two workgroups per CU allow)
-      const int maxw = 2 * cu_count() * (NL_THREADS / 64);
+      static const int wpc = getenv("OMK_NLF_WPC") ? atoi(getenv("OMK_NLF_WPC")) : 2;   // workgroups per CU the grid is sized for
+      const int maxw = (wpc > 0 ? wpc : 2) * cu_count() * (NL_THREADS / 64);
       const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
       const int nw_ = (a.Out + rw * k - 1) / (rw * k);
       a.nbatch = k;

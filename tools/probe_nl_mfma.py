@@ -10,11 +10,16 @@ if "OMK_NL_MFMA" not in os.environ:
     for m in ("0", "1"):
         subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, OMK_NL_MFMA=m), check=False)
     sys.exit(0)
+if "NL_DT" in os.environ and "OMK_NLF_WPC_LIST" in os.environ and "OMK_NLF_WPC" not in os.environ:   # one sequence: grid sizing of the fast kernel, same box
+    for rnd in range(2):
+        for w in os.environ["OMK_NLF_WPC_LIST"].split(","):
+            subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, OMK_NLF_WPC=w), check=False)
+    sys.exit(0)
 from omnimamba_amd.norm_linear import norm_linear  # noqa: E402
 
 dev = torch.device("cuda:0")
-print(f"OMK_NL_MFMA={os.environ['OMK_NL_MFMA']}")
-for dt in (torch.bfloat16,):
+print(f"OMK_NL_MFMA={os.environ['OMK_NL_MFMA']} OMK_NLF_WPC={os.environ.get('OMK_NLF_WPC', '-')}")
+for dt in [getattr(torch, d) for d in os.environ.get("NL_DT", "bfloat16").split(",")]:
     for var in os.environ.get("NL_VARS", "in_lora_conv,in_plain,out_gate").split(","):
         Out, In = (8512, 2048) if var.startswith("in") else (2048, 4096)
         Ws = [(torch.randn(Out, In, device=dev) * 0.02).to(dt) for _ in range(12)]
