@@ -77,6 +77,24 @@ __device__ __forceinline__ float load_rt_flat(const void* p, int64_t i, int dt) 
   const float f32v = __builtin_bit_cast(float, w), bfv = __builtin_bit_cast(float, bfb), f16v = (float)__builtin_bit_cast(_Float16, hb);
   return dt == OMK_F32 ? f32v : (dt == OMK_BF16 ? bfv : f16v);
 }
+// The same in two halves: the request (no branch, no conversion -- several of them in a row stay in ONE basic block and fly together) and
+// the conversion.  load_rt_flat's selects on the run-time dtype compile to scalar branches with the conversion inside, i.e. to a wait for
+// the value right behind every request: four tied scalars of the decode state update were four dependent round trips (round 5).
+struct RawElem { uint32_t w; uint32_t hi; };
+__device__ __forceinline__ RawElem raw_rt_flat(const void* p, int64_t i, int dt) {
+  const uintptr_t addr = (uintptr_t)p + ((uintptr_t)i << (dt == OMK_F32 ? 2 : 1));
+  RawElem r;
+  r.w = *reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
+  r.hi = (uint32_t)(addr & 2);
+  return r;
+}
+__device__ __forceinline__ float cvt_rt_flat(RawElem r, int dt) {
+  const uint32_t h = r.hi ? (r.w >> 16) : (r.w & 0xffffu);
+  const uint32_t bfb = h << 16;
+  const uint16_t hb = (uint16_t)h;
+  const float f32v = __builtin_bit_cast(float, r.w), bfv = __builtin_bit_cast(float, bfb), f16v = (float)__builtin_bit_cast(_Float16, hb);
+  return dt == OMK_F32 ? f32v : (dt == OMK_BF16 ? bfv : f16v);
+}
 __device__ __forceinline__ void store_rt(void* p, int64_t i, int dt, float v) {
   if (dt == OMK_F32) ((float*)p)[i] = v;
   else if (dt == OMK_BF16) ((uint16_t*)p)[i] = f32_to_bf16(v);

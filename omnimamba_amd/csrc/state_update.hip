@@ -30,11 +30,15 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
   const int pp = live ? p : a.P - 1;                 // keep every lane in the shuffles
   const int g = h / (a.H / a.G);
   // every independent load first: the scalars of the row and (vector path, N <= LPR * VEC: one step) its state / B / C
-  float dt = load_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh + (int64_t)pp * a.dsp, a.dtdt);
-  const float dtbv = load_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh + (int64_t)pp * a.tsp : 0, a.dtb ? a.tbdt : a.dtdt);
-  const float xv = load_rt_flat(a.x, (int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)pp * a.xsp, a.xdt);
+  // (requests first, conversions behind the last request: raw_rt_flat / cvt_rt_flat in omk_common.h; D and the gate of the row ride along
+  // from clamped / dummy addresses instead of sitting under branches behind the reduction)
+  const RawElem q_dt = raw_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh + (int64_t)pp * a.dsp, a.dtdt);
+  const RawElem q_dtb = raw_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh + (int64_t)pp * a.tsp : 0, a.dtb ? a.tbdt : a.dtdt);
+  const RawElem q_x = raw_rt_flat(a.x, (int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)pp * a.xsp, a.xdt);
   const bool tied = a.asn == 0;
-  const float Av = load_rt_flat(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt);
+  const RawElem q_A = raw_rt_flat(a.A, (int64_t)h * a.ash + (int64_t)pp * a.asp, a.adt);
+  const RawElem q_D = raw_rt_flat(a.D ? a.D : a.A, a.D ? (int64_t)h * a.Dsh + (int64_t)pp * a.Dsp : 0, a.D ? a.ddt : a.adt);
+  const RawElem q_z = raw_rt_flat(a.z ? a.z : a.x, a.z ? (int64_t)b * a.zsb + (int64_t)h * a.zsh + (int64_t)pp * a.zsp : 0, a.xdt);
   TS* s = (TS*)a.state + (int64_t)b * a.ssb + (int64_t)h * a.ssh + (int64_t)pp * a.ssp;
   const TX* Bp = (const TX*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
   const TX* Cp = (const TX*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
@@ -44,6 +48,9 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
     const int n0c = lr * VEC < a.N ? lr * VEC : 0;   // clamped: lanes past N re-read the row start and are not stored
     load_vec<TS, VEC>(s + n0c, sv0); load_vec<TX, VEC>(Bp + n0c, bv0); load_vec<TX, VEC>(Cp + n0c, cv0);
   }
+  float dt = cvt_rt_flat(q_dt, a.dtdt);
+  const float dtbv = cvt_rt_flat(q_dtb, a.dtb ? a.tbdt : a.dtdt), xv = cvt_rt_flat(q_x, a.xdt), Av = cvt_rt_flat(q_A, a.adt);
+  const float Dv = cvt_rt_flat(q_D, a.D ? a.ddt : a.adt), zv = cvt_rt_flat(q_z, a.xdt);
   if (a.dtb) dt += dtbv;
   if (a.softplus) dt = softplus_f(dt);
   const float xdt = xv * dt;
@@ -77,8 +84,8 @@ __global__ __launch_bounds__(256) void state_update_kernel(SuArgs a) {
   for (int m = LPR / 2; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
   if (live && lr == 0) {
     float y = acc;
-    if (a.D) y += xv * load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)p * a.Dsp, a.ddt);
-    if (a.z) y *= silu_f(load_rt(a.z, (int64_t)b * a.zsb + (int64_t)h * a.zsh + (int64_t)p * a.zsp, a.xdt));
+    if (a.D) y += xv * Dv;
+    if (a.z) y *= silu_f(zv);
     store_rt(a.out, (int64_t)b * a.osb + (int64_t)h * a.osh + (int64_t)p * a.osp, a.xdt, y);
   }
 }
@@ -101,11 +108,26 @@ __global__ __launch_bounds__(256) void state_update_tied_kernel(SuArgs a) {
   for (int k = 0; k < RPT; k++) load_vec<TS, VEC>(s + (int64_t)(p0 + k * RPB) * a.ssp, sv[k]);
   load_vec<TX, VEC>((const TX*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + n0, bv);
   load_vec<TX, VEC>((const TX*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + n0, cv);
+  // every other request of the thread right behind them, none under a branch and none followed by its conversion (raw_rt_flat /
+  // cvt_rt_flat): x, gate and D of its four rows, the three tied scalars.  Before round 5 dt, dt_bias, A were three dependent round trips
+  // in front of the arithmetic and D, gate two more per row behind the reduction: 19.9 us for 33.5 MB at eight fp32 sequences.
+  TX xq[RPT], zq[RPT];
+  RawElem Dq[RPT];
 #pragma unroll
-  for (int k = 0; k < RPT; k++) xv[k] = to_f32(((const TX*)a.x)[(int64_t)b * a.xsb + (int64_t)h * a.xsh + (int64_t)(p0 + k * RPB) * a.xsp]);
-  float dt = load_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh, a.dtdt);
-  const float dtbv = load_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh : 0, a.dtb ? a.tbdt : a.dtdt);
-  const float Av = load_rt_flat(a.A, (int64_t)h * a.ash, a.adt);
+  for (int k = 0; k < RPT; k++) {
+    const int64_t p = p0 + k * RPB;
+    const int64_t xi = (int64_t)b * a.xsb + (int64_t)h * a.xsh + p * a.xsp;
+    xq[k] = ((const TX*)a.x)[xi];
+    zq[k] = ((const TX*)(a.z ? a.z : a.x))[a.z ? (int64_t)b * a.zsb + (int64_t)h * a.zsh + p * a.zsp : xi];   // (no gate: x once more, not used)
+    Dq[k] = raw_rt_flat(a.D ? a.D : a.A, a.D ? (int64_t)h * a.Dsh + p * a.Dsp : 0, a.D ? a.ddt : a.adt);
+  }
+  const RawElem q_dt = raw_rt_flat(a.dt, (int64_t)b * a.dsb + (int64_t)h * a.dsh, a.dtdt);
+  const RawElem q_dtb = raw_rt_flat(a.dtb ? a.dtb : a.dt, a.dtb ? (int64_t)h * a.tsh : 0, a.dtb ? a.tbdt : a.dtdt);
+  const RawElem q_A = raw_rt_flat(a.A, (int64_t)h * a.ash, a.adt);
+#pragma unroll
+  for (int k = 0; k < RPT; k++) xv[k] = to_f32(xq[k]);
+  float dt = cvt_rt_flat(q_dt, a.dtdt);
+  const float dtbv = cvt_rt_flat(q_dtb, a.dtb ? a.tbdt : a.dtdt), Av = cvt_rt_flat(q_A, a.adt);
   if (a.dtb) dt += dtbv;
   if (a.softplus) dt = softplus_f(dt);
   const float dA = expf(dt * Av);
@@ -130,8 +152,8 @@ __global__ __launch_bounds__(256) void state_update_tied_kernel(SuArgs a) {
     for (int k = 0; k < RPT; k++) {
       const int p = p0 + k * RPB;
       float y = acc[k];
-      if (a.D) y += xv[k] * load_rt(a.D, (int64_t)h * a.Dsh + (int64_t)p * a.Dsp, a.ddt);
-      if (a.z) y *= silu_f(to_f32(((const TX*)a.z)[(int64_t)b * a.zsb + (int64_t)h * a.zsh + (int64_t)p * a.zsp]));
+      if (a.D) y += xv[k] * cvt_rt_flat(Dq[k], a.ddt);
+      if (a.z) y *= silu_f(to_f32(zq[k]));
       ((TX*)a.out)[(int64_t)b * a.osb + (int64_t)h * a.osh + (int64_t)p * a.osp] = from_f32<TX>(y);
     }
   }
