@@ -730,7 +730,8 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   constexpr int NQT = In / (4 * NT);                                        // 4-element pieces per thread and sequence
   constexpr int US = In + 16 / (int)sizeof(TU);
   constexpr int KL = 4 * VEC, KPW = In / NWV, NLD = KPW / KL;               // features per wave load, per wave; loads per lane and tile
-  static_assert(sizeof(TW) == 2 && NQT >= 1 && NQT * 4 * NT == In && 16 * NB <= NT && NLD <= 16 && RMAX <= 8, "shape");
+  constexpr bool W32 = sizeof(TW) == 4;                                     // fp32 weights: four v_mfma_f32_16x16x4_f32 per 16-byte vector
+  static_assert(NQT >= 1 && NQT * 4 * NT == In && 16 * NB <= NT && NLD <= 16 && RMAX <= 8, "shape");
   OMK_DYN_SMEM(smem);
   TU* sn = (TU*)smem;                                            // [NB][US] u
   float* part = (float*)(smem + (size_t)NB * US * sizeof(TU));   // [waves][NB][8] LoRA partials
@@ -746,7 +747,8 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   // at eight sequences): a request issued behind the weights returns behind them (in-order counter) -- a second group of sequences
   // fetched inside the preamble made it wait for both tiles of weights to land, + 2.4 us at eight sequences
   constexpr int AW = sizeof(TA) == 4 ? 4 : 2;
-  uint32_t xr[NB][NQT][2], ar[NB][NQT][AW];
+  constexpr int XW = W32 ? 4 : 2;
+  uint32_t xr[NB][NQT][XW], ar[NB][NQT][AW];
 #pragma unroll
   for (int bb = 0; bb < NB; bb++) {
     const int b = bb < a.B ? bb : a.B - 1;
@@ -755,8 +757,8 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
 #pragma unroll
     for (int k = 0; k < NQT; k++) {
       const int c = 4 * (tid + NT * k);
-      const u32x2 q = *reinterpret_cast<const u32x2*>(xp + c);
-      xr[bb][k][0] = q[0]; xr[bb][k][1] = q[1];
+      if constexpr (W32) { const u32x4 q = *reinterpret_cast<const u32x4*>(xp + c); xr[bb][k][0] = q[0]; xr[bb][k][1] = q[1]; xr[bb][k][2] = q[2]; xr[bb][k][3] = q[3]; }
+      else { const u32x2 q = *reinterpret_cast<const u32x2*>(xp + c); xr[bb][k][0] = q[0]; xr[bb][k][1] = q[1]; }
       if constexpr (AW == 4) { const u32x4 r = *reinterpret_cast<const u32x4*>(ap + (hasaux ? c : 0)); ar[bb][k][0] = r[0]; ar[bb][k][1] = r[1]; ar[bb][k][2] = r[2]; ar[bb][k][3] = r[3]; }
       else { const u32x2 r = *reinterpret_cast<const u32x2*>(ap + (hasaux ? c : 0)); ar[bb][k][0] = r[0]; ar[bb][k][1] = r[1]; }
     }
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   // ---- tiles of this workgroup; what travels with a tile: the wave's slice of its 16 rows, the finish operands of thread (i, b)
   const int ntile = (a.Out + 15) >> 4, gstep = (int)gridDim.x;
   const int fi = tid & 15, fb = tid >> 4;
-  constexpr int LBR = RMAX > 0 ? 4 : 1;
+  constexpr int LBR = RMAX > 0 ? (W32 ? 8 : 4) : 1;
   static_assert(RMAX == 0 || RMAX == 8, "LoRA B rows of 16 bytes");
   // (raw 16-bit values from clamped, always valid addresses: no branch and no conversion between two loads -- with the selects and
   // conversions next to the loads every one of the ~12 small loads of a thread became its own branch + s_waitcnt vmcnt(0), ~4 us per call)
@@ -781,12 +783,16 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
 #pragma unroll
     for (int s = 0; s < NLD; s++) w[s] = OMK_NL_WLOAD(wp + KL * s);
   };
-  auto raw16 = [](const TW* p) -> uint32_t { return *reinterpret_cast<const uint16_t*>(p); };
+  auto raw16 = [](const TW* p) -> uint32_t {
+    if constexpr (sizeof(TW) == 4) return *reinterpret_cast<const uint32_t*>(p);
+    else return *reinterpret_cast<const uint16_t*>(p);
+  };
   auto load_fin = [&](Fin& f, int t) {   // (no branch in here: without the conv tail the taps and the state read a valid dummy address)
     const int fr = 16 * t + fi, frow = fr < a.Out ? fr : a.Out - 1, fbc = fb < a.B ? fb : a.B - 1;
-    if constexpr (RMAX > 0) {   // the LoRA B row as stored, RMAX 16-bit values = 16 bytes (the launcher checks R == RMAX and the alignment)
-      const u32x4 q = *reinterpret_cast<const u32x4*>((const TW*)a.lb + (int64_t)frow * a.lbs);
-      f.lbq[0] = q[0]; f.lbq[1] = q[1]; f.lbq[2] = q[2]; f.lbq[3] = q[3];
+    if constexpr (RMAX > 0) {   // the LoRA B row as stored, RMAX values = 16 / 32 bytes (the launcher checks R == RMAX and the alignment)
+      const u32x4* lq = reinterpret_cast<const u32x4*>((const TW*)a.lb + (int64_t)frow * a.lbs);
+#pragma unroll
+      for (int j = 0; j < LBR / 4; j++) { const u32x4 q = lq[j]; f.lbq[4 * j] = q[0]; f.lbq[4 * j + 1] = q[1]; f.lbq[4 * j + 2] = q[2]; f.lbq[4 * j + 3] = q[3]; }
     } else {
       f.lbq[0] = 0u;
     }
@@ -808,15 +814,17 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   const int tfirst = (int)blockIdx.x;
   load_fin(fA, tfirst);
   if (tfirst + gstep < ntile) load_fin(fB, tfirst + gstep);
-  u32x4 wl[RMAX > 0 ? NLD : 1];
-  constexpr bool LORA_EARLY = RMAX > 0 && NLD <= 8;   // (16 loads per lane next to the preamble's registers: spills at 256)
-  auto load_lora = [&]() {
+  // LoRA A rows: eight loads per lane at a time (NLD = 16: two halves, each requested when the registers of the one before are free)
+  constexpr int NLH = NLD < 8 ? NLD : 8;
+  u32x4 wl[RMAX > 0 ? NLH : 1];
+  constexpr bool LORA_EARLY = RMAX > 0 && NLD <= 8 && !W32;   // (next to the preamble's registers only when everything fits 256)
+  auto load_lora = [&](int s0) {
     const int r8 = t16 & 7;
     const TW* lap = (const TW*)a.la + (int64_t)(r8 < a.R ? r8 : 0) * a.las + wave * KPW + VEC * g16;
 #pragma unroll
-    for (int s = 0; s < NLD; s++) wl[s] = *reinterpret_cast<const u32x4*>(lap + KL * s);
+    for (int s = 0; s < NLH; s++) wl[s] = *reinterpret_cast<const u32x4*>(lap + KL * (s0 + s));
   };
-  if constexpr (LORA_EARLY) load_lora();
+  if constexpr (LORA_EARLY) load_lora(0);
   OMK_SCHED_FENCE();
   load_w(wA, tfirst);
   if (tfirst + gstep < ntile) load_w(wB, tfirst + gstep);
@@ -824,6 +832,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   // ---- preamble: u = (x + residual | x silu(z)) * w of every sequence into LDS, sums of squares per wave
   auto un16 = [](uint32_t r, int i) -> float {   // element i (0 / 1) of a packed pair of TW
     if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, i ? (r & 0xffff0000u) : (r << 16));
+    else if constexpr (sizeof(TW) == 4) return __builtin_bit_cast(float, r);     // (not used: fp32 values are not packed)
     else return to_f32(__builtin_bit_cast(TW, (uint16_t)(i ? r >> 16 : r)));
   };
 #pragma unroll
@@ -835,7 +844,9 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
       float vv4[4], t4[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        float x_ = un16(xr[bb][k][i >> 1], i & 1), g = 1.f, aux;
+        float x_, g = 1.f, aux;
+        if constexpr (W32) x_ = __builtin_bit_cast(float, xr[bb][k][i]);
+        else x_ = un16(xr[bb][k][i >> 1], i & 1);
         if constexpr (AW == 4) aux = __builtin_bit_cast(float, ar[bb][k][i]);
         else aux = un16(ar[bb][k][i >> 1], i & 1);
         if constexpr (GATE) g = silu_fast(aux);
@@ -852,13 +863,29 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
     ssq = wave_sum(ssq);
     if (lane == 0) red[wave * NB + bb] = ssq;
   }
-  if constexpr (RMAX > 0 && !LORA_EARLY) load_lora();
+  if constexpr (RMAX > 0 && !LORA_EARLY) load_lora(0);
   block_sync();
   const TU* up = sn + (size_t)(t16 & (NB - 1)) * US + wave * KPW + VEC * g16;
+  // one landed 16-byte vector of a row against the same features of the sequences: one bf16 matrix instruction, or -- fp32 -- element e of the
+  // vector in instruction e on both operands (feature 4 g + e of the step).  (The elements through a bit cast of the VECTOR:
+  // __builtin_bit_cast(float, wv[e]) reads element 0 for every e with this compiler.)
+  auto mma = [&](const u32x4& wv, int s_, f32x4 (&ac)[2]) {
+    if constexpr (W32) {
+      const f32x4 uv = *reinterpret_cast<const f32x4*>(up + KL * s_), wf = __builtin_bit_cast(f32x4, wv);
+#pragma unroll
+      for (int e = 0; e < 4; e++) ac[e & 1] = mfma16x16x4_f32(wf[e], uv[e], ac[e & 1]);
+    } else {
+      ac[s_ & 1] = mfma16x16x32_bf16(as_s16x8(wv), as_s16x8(ld16(up + KL * s_)), ac[s_ & 1]);
+    }
+  };
   if constexpr (RMAX > 0) {   // h[rank][sequence] of this wave's slice: ranks 4 g + r (g < 2), sequence lane & 15
     f32x4 hacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int s = 0; s < NLD; s++) hacc[s & 1] = mfma16x16x32_bf16(as_s16x8(wl[s]), as_s16x8(ld16(up + KL * s)), hacc[s & 1]);
+    for (int s0 = 0; s0 < NLD; s0 += NLH) {
+      if (s0 > 0) load_lora(s0);
+#pragma unroll
+      for (int s = 0; s < NLH; s++) mma(wl[s], s0 + s, hacc);
+    }
     if (t16 < NB && g16 < 2) {
 #pragma unroll
       for (int r = 0; r < 4; r++) part[(wave * NB + t16) * 8 + 4 * g16 + r] = 4 * g16 + r < a.R ? hacc[0][r] + hacc[1][r] : 0.f;
@@ -885,7 +912,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   auto tile_step = [&](u32x4 (&w)[NLD], Fin& f, int t, int par) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int s = 0; s < NLD; s++) acc[s & 1] = mfma16x16x32_bf16(as_s16x8(w[s]), as_s16x8(ld16(up + KL * s)), acc[s & 1]);
+    for (int s = 0; s < NLD; s++) mma(w[s], s, acc);
     const Fin fc = f;
     const int tn = t + 2 * gstep;
     if (tn < ntile) { load_w(w, tn); load_fin(f, tn); }
@@ -899,7 +926,8 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
     if (fb < NB && fb < a.B && frow < a.Out) {
       // (bf16 from the raw register by a shift: a truncation to 16 bits here becomes an AND the compiler hoists up to the load -- a wait)
       auto f16 = [](uint32_t r) -> float {
-        if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, r << 16);
+        if constexpr (sizeof(TW) == 4) return __builtin_bit_cast(float, r);
+        else if constexpr (std::is_same<TW, bf16_t>::value) return __builtin_bit_cast(float, r << 16);
         else return to_f32(__builtin_bit_cast(TW, (uint16_t)r));
       };
       float vv = 0.f;
@@ -909,7 +937,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
         float d = 0.f;
 #pragma unroll
         for (int r = 0; r < RMAX; r++)
-          d += ((r & 1) ? f16(fc.lbq[r >> 1] >> 16) : f16(fc.lbq[r >> 1])) * hs[fb * 8 + r];   // (ranks >= R: h is zero)
+          d += (W32 ? f16(fc.lbq[W32 ? r : 0]) : ((r & 1) ? f16(fc.lbq[r >> 1] >> 16) : f16(fc.lbq[r >> 1]))) * hs[fb * 8 + r];   // (ranks >= R: h is zero)
         vv += a.scale * d;
       }
       vv = vv * rstd[fb] + (a.bias ? f16(fc.bias) : 0.f);
@@ -924,7 +952,9 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
         TW* cs = (TW*)a.cst + (int64_t)fb * a.csb + (int64_t)(frow - a.cc0) * a.csc;
         for (int sl = 0; sl + 1 < a.cS; sl++) {      // roll: the stored values move as they are
           const int k = sl + 1 - (a.cS - 3);
-          cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, (uint16_t)(k == 0 ? fc.hist[0] : (k == 1 ? fc.hist[1] : fc.hist[2])));
+          const uint32_t hq = k == 0 ? fc.hist[0] : (k == 1 ? fc.hist[1] : fc.hist[2]);
+          if constexpr (W32) cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, hq);
+          else cs[(int64_t)sl * a.csl] = __builtin_bit_cast(TW, (uint16_t)hq);
         }
         cs[(int64_t)(a.cS - 1) * a.csl] = xr;
       }
@@ -1044,21 +1074,29 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       if (gate && present(p->residual)) return fail(OMK_EUNSUPPORTED, "norm_linear: residual and gate together are served by the batch-1 kernel only");
       // 16-bit weights: the matrix-pipe form, a workgroup per tile of 16 rows (OMK_NL_MFMA=0: the vector form, for the A/B)
       static const bool use_mfma = !(getenv("OMK_NL_MFMA") && atoi(getenv("OMK_NL_MFMA")) == 0);
-      const bool lora_rows16 = a.R == 0 || (a.R == 8 && a.lbs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.lb) & 15) == 0);   // B rows read as one 16-byte load
-      if (use_mfma && wdt == OMK_BF16 && lora_rows16) {
-        const int nwv = nq == 1 ? 4 : 8, ntile = (a.Out + 15) / 16;
-        const size_t msmem = (size_t)nb * (a.In + 8) * 2 + (size_t)nwv * nb * (9 + 2 * 16) * 4 + (size_t)nb * 9 * 4;
+      // B rows of the LoRA read as 16-byte loads
+      const bool lora_rows16 = a.R == 0 || (a.R == 8 && (a.lbs * (wdt == OMK_F32 ? 4 : 2)) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.lb) & 15) == 0);
+      // fp32 weights (four v_mfma_f32_16x16x4_f32 per 16-byte vector): only where it was measured ahead of the vector form -- eight sequences
+      // with LoRA, rows of up to 2048 features: 29.7 against 31.5 us for the 1.3B in_proj; behind it at two sequences (28.8 / 19.5 us) and
+      // without LoRA (23.9 / 19.7 us) -- profiles/r05_decode_projections.txt.  (4096 features: 32 loads per lane and tile, no room for two tiles.)
+      static const bool mfma_f32 = !(getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 0);
+      const bool f32_ok = wdt == OMK_F32 && nq <= 2 && mfma_f32 && ((nb == 8 && a.R > 0) || (getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 2));
+      if (use_mfma && lora_rows16 && (wdt == OMK_BF16 || f32_ok)) {
+        const int nwv = nq == 1 ? 4 : 8, ntile = (a.Out + 15) / 16, ub = wdt == OMK_F32 ? 4 : 2;
+        const size_t msmem = (size_t)nb * (a.In + 16 / ub) * ub + (size_t)nwv * nb * (9 + 2 * 16) * 4 + (size_t)nb * 9 * 4;
         int wgs = cu_count();
         if (const char* e = getenv("OMK_NL_MFMA_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;   // tests: several tiles per workgroup on small matrices
         dim3 mgrid((unsigned)(ntile < wgs ? ntile : wgs));
-#define NLM_G(TR_, NQ_, RM_, NB_, G_) do { constexpr int NT_ = NQ_ == 1 ? 256 : 512; \
-          if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<bf16_t, TR_, NQ_, RM_, NB_, G_, NT_>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
-          OMK_LAUNCH((norm_linear_mfma_kernel<bf16_t, TR_, NQ_, RM_, NB_, G_, NT_>), mgrid, dim3(NT_), msmem, stream, a); } while (0)
-#define NLM_GO(TR_, NQ_, RM_, NB_) do { if (gate) NLM_G(TR_, NQ_, RM_, NB_, true); else NLM_G(TR_, NQ_, RM_, NB_, false); } while (0)
-#define NLM_B(TR_, NQ_, RM_) do { if (nb == 2) NLM_GO(TR_, NQ_, RM_, 2); else if (nb == 4) NLM_GO(TR_, NQ_, RM_, 4); else NLM_GO(TR_, NQ_, RM_, 8); } while (0)
-#define NLM_R(TR_, NQ_) do { if (a.R > 0) NLM_B(TR_, NQ_, 8); else NLM_B(TR_, NQ_, 0); } while (0)
-#define NLM_Q(TR_) do { if (nq == 1) NLM_R(TR_, 1); else if (nq == 2) NLM_R(TR_, 2); else NLM_R(TR_, 4); } while (0)
-        if (trdt == OMK_F32) NLM_Q(float); else NLM_Q(bf16_t);
+#define NLM_G(TW_, TR_, NQ_, RM_, NB_, G_) do { constexpr int NT_ = NQ_ == 1 ? 256 : 512; \
+          if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
+          OMK_LAUNCH((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_>), mgrid, dim3(NT_), msmem, stream, a); } while (0)
+#define NLM_GO(TW_, TR_, NQ_, RM_, NB_) do { if (gate) NLM_G(TW_, TR_, NQ_, RM_, NB_, true); else NLM_G(TW_, TR_, NQ_, RM_, NB_, false); } while (0)
+#define NLM_B(TW_, TR_, NQ_, RM_) do { if (nb == 2) NLM_GO(TW_, TR_, NQ_, RM_, 2); else if (nb == 4) NLM_GO(TW_, TR_, NQ_, RM_, 4); else NLM_GO(TW_, TR_, NQ_, RM_, 8); } while (0)
+#define NLM_R(TW_, TR_, NQ_) do { if (a.R > 0) NLM_B(TW_, TR_, NQ_, 8); else NLM_B(TW_, TR_, NQ_, 0); } while (0)
+#define NLM_Q(TW_, TR_) do { if (nq == 1) NLM_R(TW_, TR_, 1); else if (nq == 2) NLM_R(TW_, TR_, 2); else NLM_R(TW_, TR_, 4); } while (0)
+#define NLM_Q2(TW_, TR_) do { if (nq == 1) NLM_R(TW_, TR_, 1); else NLM_R(TW_, TR_, 2); } while (0)
+        if (wdt == OMK_F32) NLM_Q2(float, float); else if (trdt == OMK_F32) NLM_Q(bf16_t, float); else NLM_Q(bf16_t, bf16_t);
+#undef NLM_Q2
 #undef NLM_Q
 #undef NLM_R
 #undef NLM_B
