@@ -40,22 +40,40 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
   T* out = (T*)a.out + (int64_t)b * a.osb + c0;
   // win[k] holds the input at position l - (W-1) + k  (k = W-1 is the current token)
   float w[W][VEC], bias[VEC], win[W][VEC];
+  // The prologue of a thread -- taps, bias, the W - 1 rows in front of its tile -- as ONE batch of requests, conversions behind the last
+  // of them (raw_rt_flat / cvt_rt_flat, omk_common.h).  Written as `cond ? load_rt(...) : 0` (rounds 1 - 4) every one of these ~ 20 small
+  // loads was a branch with s_waitcnt vmcnt(0) behind it: ~ 20 dependent round trips in front of a main loop of 8 (tools/isa_waits.py).
+  {
+    RawElem qb[VEC], qw[W][VEC], qi[W][VEC];
+    vec_t<T, VEC> qx[W];
 #pragma unroll
-  for (int i = 0; i < VEC; i++) {
-    bias[i] = a.bias ? load_rt(a.bias, c0 + i, a.bdt) : 0.f;
+    for (int i = 0; i < VEC; i++) {
+      qb[i] = raw_rt_flat(a.bias ? a.bias : a.w, a.bias ? c0 + i : 0, a.bias ? a.bdt : a.wdt);
 #pragma unroll
-    for (int k = 0; k < W; k++) w[k][i] = load_rt(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
-  }
-  // before the first shift slot s (1..W-1) holds position l0 - W + s
+      for (int k = 0; k < W; k++) qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+    }
+    // before the first shift slot s (1..W-1) holds position l0 - W + s: the row itself (clamped), or the initial state in front of the sequence
 #pragma unroll
-  for (int s = 1; s < W; s++) {
-    const int l = l0 - W + s;
-    if (l >= 0) {
-      load_vec<T, VEC>(x + (int64_t)l * a.xsl, win[s]);
-    } else {
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      qx[s] = *reinterpret_cast<const vec_t<T, VEC>*>(x + (int64_t)(l >= 0 ? l : 0) * a.xsl);
+      const bool ini = a.init != nullptr && l < 0 && W - 1 + l >= 0;
 #pragma unroll
       for (int i = 0; i < VEC; i++)
-        win[s][i] = a.init ? load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt) : 0.f;
+        qi[s][i] = raw_rt_flat(ini ? a.init : a.w, ini ? (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl : 0, ini ? a.idt : a.wdt);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      bias[i] = a.bias ? cvt_rt_flat(qb[i], a.bdt) : 0.f;
+#pragma unroll
+      for (int k = 0; k < W; k++) w[k][i] = cvt_rt_flat(qw[k][i], a.wdt);
+    }
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) win[s][i] = l >= 0 ? to_f32(qx[s].e[i]) : (ini ? cvt_rt_flat(qi[s][i], a.idt) : 0.f);
     }
   }
   const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
@@ -160,13 +178,15 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
   const T* dout = (const T*)a.dout + (int64_t)b * a.dosb + c0;
   T* dx = (T*)a.dx + (int64_t)b * a.dxsb + c0;
   float w[W][VEC], bias[VEC], dwacc[W][VEC], dbacc[VEC];
+  // (taps, bias and the rows in front of the tile: one batch of requests, conversions behind -- see conv1d_fwd_cl_kernel)
+  RawElem qb[VEC], qw[W][VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
-    bias[i] = a.bias ? load_rt(a.bias, c0 + i, a.bdt) : 0.f;
+    qb[i] = raw_rt_flat(a.bias ? a.bias : a.w, a.bias ? c0 + i : 0, a.bias ? a.bdt : a.wdt);
     dbacc[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < W; k++) {
-      w[k][i] = load_rt(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+      qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
       dwacc[k][i] = 0.f;
     }
   }
@@ -178,11 +198,32 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
   for (int s = 0; s < W; s++)
 #pragma unroll
     for (int i = 0; i < VEC; i++) { xw[s][i] = 0.f; dp[s][i] = 0.f; }
+  {
+    T qx[W][VEC];
+    RawElem qi[W][VEC];
 #pragma unroll
-  for (int s = 1; s < W; s++) {
-    const int l = l0 - W + s;
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && a.W - 1 + l >= 0;
 #pragma unroll
-    for (int i = 0; i < VEC; i++) xw[s][i] = conv_in<T>(a, x, b, c0 + i, l);
+      for (int i = 0; i < VEC; i++) {
+        qx[s][i] = x[(int64_t)b * a.xsb + (int64_t)(c0 + i) * a.xsc + (int64_t)(l >= 0 ? l : 0) * a.xsl];
+        qi[s][i] = raw_rt_flat(ini ? a.init : a.w, ini ? (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(a.W - 1 + l) * a.isl : 0, ini ? a.idt : a.wdt);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      bias[i] = a.bias ? cvt_rt_flat(qb[i], a.bdt) : 0.f;
+#pragma unroll
+      for (int k = 0; k < W; k++) w[k][i] = cvt_rt_flat(qw[k][i], a.wdt);
+    }
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && a.W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) xw[s][i] = l >= 0 ? to_f32(qx[s][i]) : (ini ? cvt_rt_flat(qi[s][i], a.idt) : 0.f);
+    }
   }
   // dpre of the W-1 positions before l0 is NOT needed: dx[lo] only uses dpre[lo .. lo+W-1], lo >= l0.
   const int pend = lend + W - 1;
