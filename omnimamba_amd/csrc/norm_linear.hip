@@ -723,7 +723,10 @@ __global__ __launch_bounds__(NL_THREADS, 2) void norm_linear_batched_kernel(NlAr
 //     are free);
 //   * the waves' partial tiles meet in LDS (two buffers: one barrier per tile); thread (i, b) adds them up: LoRA, rstd, bias, conv tail.
 // NT = 512 threads (eight feature slices) for 2048 and 4096 input features, 256 for 1024.
-template <class TW, class TR, int NQ, int RMAX, int NB, bool GATE, int NT>
+// ROWS = 16 or 8 rows per tile: with 8 the lanes i >= 8 of a fragment repeat the rows of the lanes i - 8 (same addresses: no more HBM
+// traffic, twice the matrix instructions per byte, which are free here) -- twice as many units of work, for matrices with few tiles per CU
+// (out_proj of the 1.3B model: 128 tiles of 16 rows on 256 CUs; in_proj: 532 tiles = 2 or 3 per workgroup).
+template <class TW, class TR, int NQ, int RMAX, int NB, bool GATE, int NT, int ROWS>
 __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   using TU = typename lds_u<TW>::type;
   constexpr int In = 1024 * NQ, VEC = 16 / sizeof(TW), NWV = NT / 64;
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   constexpr int US = In + 16 / (int)sizeof(TU);
   constexpr int KL = 4 * VEC, KPW = In / NWV, NLD = KPW / KL;               // features per wave load, per wave; loads per lane and tile
   constexpr bool W32 = sizeof(TW) == 4;                                     // fp32 weights: four v_mfma_f32_16x16x4_f32 per 16-byte vector
-  static_assert(NQT >= 1 && NQT * 4 * NT == In && 16 * NB <= NT && NLD <= 16 && RMAX <= 8, "shape");
+  static_assert(NQT >= 1 && NQT * 4 * NT == In && 16 * NB <= NT && NLD <= 16 && RMAX <= 8 && (ROWS == 8 || ROWS == 16), "shape");
   OMK_DYN_SMEM(smem);
   TU* sn = (TU*)smem;                                            // [NB][US] u
   float* part = (float*)(smem + (size_t)NB * US * sizeof(TU));   // [waves][NB][8] LoRA partials
@@ -768,8 +771,8 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   for (int k = 0; k < NQT; k++) load_vec<TW, 4>((const TW*)a.nw + 4 * (tid + NT * k), n4[k]);
   OMK_SCHED_FENCE();
   // ---- tiles of this workgroup; what travels with a tile: the wave's slice of its 16 rows, the finish operands of thread (i, b)
-  const int ntile = (a.Out + 15) >> 4, gstep = (int)gridDim.x;
-  const int fi = tid & 15, fb = tid >> 4;
+  const int ntile = (a.Out + ROWS - 1) / ROWS, gstep = (int)gridDim.x;
+  const int fi = tid & (ROWS - 1), fb = tid / ROWS;
   constexpr int LBR = RMAX > 0 ? (W32 ? 8 : 4) : 1;
   static_assert(RMAX == 0 || RMAX == 8, "LoRA B rows of 16 bytes");
   // (raw 16-bit values from clamped, always valid addresses: no branch and no conversion between two loads -- with the selects and
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
   const bool conv_on = a.cst != nullptr;
   const int convC = a.cc1 - a.cc0;
   auto load_w = [&](u32x4 (&w)[NLD], int t) {
-    const int rt = 16 * t + t16;
+    const int rt = ROWS * t + (t16 & (ROWS - 1));
     const TW* wp = (const TW*)a.W + (int64_t)(rt < a.Out ? rt : a.Out - 1) * a.Ws + wave * KPW + VEC * g16;
 #pragma unroll
     for (int s = 0; s < NLD; s++) w[s] = OMK_NL_WLOAD(wp + KL * s);
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
     else return *reinterpret_cast<const uint16_t*>(p);
   };
   auto load_fin = [&](Fin& f, int t) {   // (no branch in here: without the conv tail the taps and the state read a valid dummy address)
-    const int fr = 16 * t + fi, frow = fr < a.Out ? fr : a.Out - 1, fbc = fb < a.B ? fb : a.B - 1;
+    const int fr = ROWS * t + fi, frow = fr < a.Out ? fr : a.Out - 1, fbc = fb < a.B ? fb : a.B - 1;
     if constexpr (RMAX > 0) {   // the LoRA B row as stored, RMAX values = 16 / 32 bytes (the launcher checks R == RMAX and the alignment)
       const u32x4* lq = reinterpret_cast<const u32x4*>((const TW*)a.lb + (int64_t)frow * a.lbs);
 #pragma unroll
@@ -916,13 +919,13 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
     const Fin fc = f;
     const int tn = t + 2 * gstep;
     if (tn < ntile) { load_w(w, tn); load_fin(f, tn); }
-    float* rs = res + par * (NWV * 16 * NB);
-    if (t16 < NB) {
+    float* rs = res + par * (NWV * ROWS * NB);
+    if (t16 < NB && 4 * g16 < ROWS) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) rs[(wave * 16 + 4 * g16 + r) * NB + t16] = acc[0][r] + acc[1][r];
+      for (int r = 0; r < 4; r++) rs[(wave * ROWS + 4 * g16 + r) * NB + t16] = acc[0][r] + acc[1][r];
     }
     block_sync();
-    const int frow = 16 * t + fi;
+    const int frow = ROWS * t + fi;
     if (fb < NB && fb < a.B && frow < a.Out) {
       // (bf16 from the raw register by a shift: a truncation to 16 bits here becomes an AND the compiler hoists up to the load -- a wait)
       auto f16 = [](uint32_t r) -> float {
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(NT, 1) void norm_linear_mfma_kernel(NlArgs a) {
       };
       float vv = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < NWV; w2++) vv += rs[(w2 * 16 + fi) * NB + fb];
+      for (int w2 = 0; w2 < NWV; w2++) vv += rs[(w2 * ROWS + fi) * NB + fb];
       if constexpr (RMAX > 0) {
         float d = 0.f;
 #pragma unroll
@@ -1082,14 +1085,22 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       static const bool mfma_f32 = !(getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 0);
       const bool f32_ok = wdt == OMK_F32 && nq <= 2 && mfma_f32 && ((nb == 8 && a.R > 0) || (getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 2));
       if (use_mfma && lora_rows16 && (wdt == OMK_BF16 || f32_ok)) {
-        const int nwv = nq == 1 ? 4 : 8, ntile = (a.Out + 15) / 16, ub = wdt == OMK_F32 ? 4 : 2;
-        const size_t msmem = (size_t)nb * (a.In + 16 / ub) * ub + (size_t)nwv * nb * (9 + 2 * 16) * 4 + (size_t)nb * 9 * 4;
+        // tiles of 8 rows when there are fewer 16-row tiles than workgroups (out_proj of the 1.3B model: 11.1 -> 10.1 us at eight sequences,
+        // 8.4 -> 7.3 us at two; with several tiles per workgroup 8 rows are behind: in_proj 16.2 -> 17.7 us).  OMK_NL_MFMA_ROWS = 8 / 16 for the A/B
         int wgs = cu_count();
         if (const char* e = getenv("OMK_NL_MFMA_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;   // tests: several tiles per workgroup on small matrices
+        int rows = (a.Out + 15) / 16 < wgs ? 8 : 16;
+        if (const char* e = getenv("OMK_NL_MFMA_ROWS")) rows = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : rows);
+        const int nwv = nq == 1 ? 4 : 8, ntile = (a.Out + rows - 1) / rows, ub = wdt == OMK_F32 ? 4 : 2;
+        const size_t msmem = (size_t)nb * (a.In + 16 / ub) * ub + (size_t)nwv * nb * (9 + 2 * 16) * 4 + (size_t)nb * 9 * 4;
         dim3 mgrid((unsigned)(ntile < wgs ? ntile : wgs));
 #define NLM_G(TW_, TR_, NQ_, RM_, NB_, G_) do { constexpr int NT_ = NQ_ == 1 ? 256 : 512; \
-          if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
-          OMK_LAUNCH((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_>), mgrid, dim3(NT_), msmem, stream, a); } while (0)
+          if (rows == 8) { \
+            if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_, 8>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
+            OMK_LAUNCH((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_, 8>), mgrid, dim3(NT_), msmem, stream, a); \
+          } else { \
+            if (OMK_SET_MAX_DYN_SMEM((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_, 16>), msmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", msmem); \
+            OMK_LAUNCH((norm_linear_mfma_kernel<TW_, TR_, NQ_, RM_, NB_, G_, NT_, 16>), mgrid, dim3(NT_), msmem, stream, a); } } while (0)
 #define NLM_GO(TW_, TR_, NQ_, RM_, NB_) do { if (gate) NLM_G(TW_, TR_, NQ_, RM_, NB_, true); else NLM_G(TW_, TR_, NQ_, RM_, NB_, false); } while (0)
 #define NLM_B(TW_, TR_, NQ_, RM_) do { if (nb == 2) NLM_GO(TW_, TR_, NQ_, RM_, 2); else if (nb == 4) NLM_GO(TW_, TR_, NQ_, RM_, 4); else NLM_GO(TW_, TR_, NQ_, RM_, 8); } while (0)
 #define NLM_R(TW_, TR_, NQ_) do { if (a.R > 0) NLM_B(TW_, TR_, NQ_, 8); else NLM_B(TW_, TR_, NQ_, 0); } while (0)
