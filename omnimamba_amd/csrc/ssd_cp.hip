@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   }
   // ---- per-head staging: x, dy rows (two 16-byte segments per thread each), the two state images (two each)
   u32x4 rx[2], ry[2], rs[2], rg[2];
-  float rd0 = 0.f, rd1 = 0.f, rdn = 0.f;
+  float rd0 = 0.f, rd1 = 0.f, rdn = 0.f, rA = 0.f;
   // Who does the per-head bookkeeping.  Measured per head (tools: OMK_PHASE_PROF build, OMK_CP_PROF=1): the first-dispatched half of
   // the workgroup (waves 0 - 3) wins the SIMD arbitration and waits 3.4 - 4.7 k of 15.4 k cycles at the first barrier, waves 4 - 7 set
   // the pace -- so the scalars of the next head (SW), the restart values and the token readout sit on waves 1, 0 and 2.
@@ -106,6 +106,9 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
       rd0 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + lane), 0u);
       rd1 = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + 64 + lane), 0u);
       rdn = buf_ld_f32(Dr, 4u * (uint32_t)(t0 + TW), 0u);
+      // A of the head rides along: loaded inside scalars() it was one more round trip there, and -- the load counter returns in order --
+      // a wait for everything this wave has in flight, the state images of the next head included
+      rA = a.A[h];
     }
   };
   auto issue_sg = [&](int h) {   // the two state images: issued behind Phase B (the register peak), in flight during Phase A
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
     if (lane == 0) { sm.ddgs[ring][w][0] = dd; sm.ddgs[ring][w][1] = gs; }
   };
   auto scalars = [&](int h, int sb, int ring) {   // wave 0; lanes = tokens 0 .. 63 and 64 .. 127 of the window
-    const float Ah2 = a.A[h] * LOG2E;
+    const float Ah2 = rA * LOG2E;
     const float c0 = wave_incl_scan_add(rd0 * Ah2);
     const float tot0 = wave_read_lane(c0, 63);
     const float c1 = wave_incl_scan_add(rd1 * Ah2) + tot0;
