@@ -6,7 +6,9 @@
 // W-1 previous inputs held in registers: every input byte is fetched once per tile (+ a W-1 token halo that
 // hits L2).  Any other layout (channel-first, odd sizes, fp32 rows not 16-byte aligned) takes the strided
 // scalar kernel, whose fastest thread index follows the unit-stride dimension.
+#include <type_traits>
 #include "omk_common.h"
+#include "ssd_tiles.h"
 
 namespace omk {
 
@@ -304,6 +306,171 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same walk for two 16-bit channels per lane (the shipped configuration), round 5.  conv1d_bwd_cl_kernel is VALU bound: ~ 125
+// instructions per token and lane, of which ~ 60 are v_cndmask / v_mov for the tile- and sequence-edge masks and ~ 14 are 64-bit address
+// arithmetic per request.  Here
+//   * the token position of a wave is a SCALAR (strip = readfirstlane): row offsets are s_mul / s_add, every edge test a scalar branch;
+//   * rows move through buffer resources: the lane part of an address is one constant VGPR (idle lanes of the last channel block point
+//     behind the range: their loads read zeros and their stores are dropped), the row part the instruction's scalar offset;
+//   * the token step exists twice: the seven interior groups of a 64-token tile take a copy without any test -- the window shifts are
+//     register renames there.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef TGX
+#define TGX 4   // tokens requested per group: 4 = 102 registers, four waves per SIMD (8: 142 registers, three waves; 298 - 307 against 306 - 314 us)
+#endif
+template <class T, int TL, int W, int TG>
+__global__ __launch_bounds__(256) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // (142 registers, three waves per SIMD; bounded to 128 it spills 14 and runs 353 us against 315)
+  constexpr int VEC = 2;
+  static_assert(sizeof(T) == 2, "two 16-bit channels = one dword per lane");
+  __shared__ float sred[4][64][VEC * (W + 1)];
+  const int CV = a.C / VEC, NT4 = (a.L + 4 * TL - 1) / (4 * TL), CVB = (CV + 63) / 64;
+  const int cvb = blockIdx.x % CVB, t4 = (blockIdx.x / CVB) % NT4, b = blockIdx.x / (CVB * NT4);
+  const int cvl = threadIdx.x & 63, strip = uniform_i(threadIdx.x >> 6);
+  const int cv = cvb * 64 + cvl;
+  const bool cvok = cv < CV;
+  const int c0 = (cvok ? cv : 0) * VEC, l0 = (t4 * 4 + strip) * TL;
+  const T* x = (const T*)a.x;
+  float w[W][VEC], bias[VEC], dwacc[W][VEC], dbacc[VEC];
+  RawElem qb[VEC], qw[W][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    qb[i] = raw_rt_flat(a.bias ? a.bias : a.w, a.bias ? c0 + i : 0, a.bias ? a.bdt : a.wdt);
+    dbacc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+      dwacc[k][i] = 0.f;
+    }
+  }
+  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;   // (scalar; idle lanes walk along on zeros)
+  float xw[W][VEC], dp[W][VEC];
+#pragma unroll
+  for (int s = 0; s < W; s++)
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { xw[s][i] = 0.f; dp[s][i] = 0.f; }
+  {
+    T qx[W][VEC];
+    RawElem qi[W][VEC];
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && a.W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        qx[s][i] = x[(int64_t)b * a.xsb + (int64_t)(c0 + i) * a.xsc + (int64_t)(l >= 0 ? (l < a.L ? l : a.L - 1) : 0) * a.xsl];
+        qi[s][i] = raw_rt_flat(ini ? a.init : a.w, ini ? (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(a.W - 1 + l) * a.isl : 0, ini ? a.idt : a.wdt);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      bias[i] = a.bias ? cvt_rt_flat(qb[i], a.bdt) : 0.f;
+#pragma unroll
+      for (int k = 0; k < W; k++) w[k][i] = cvt_rt_flat(qw[k][i], a.wdt);
+    }
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && a.W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) xw[s][i] = l >= 0 ? to_f32(qx[s][i]) : (ini ? cvt_rt_flat(qi[s][i], a.idt) : 0.f);
+    }
+  }
+  const int pend = lend + W - 1;
+  // rows of this batch element as buffers; lane part of every address: the channel pair (idle lanes: behind the range)
+  const uint32_t vch = cvok ? 2u * (uint32_t)c0 : 0x7ffffff0u;
+  const BufRes xr = make_buf(x + (int64_t)b * a.xsb, (uint32_t)(((int64_t)(a.L - 1) * a.xsl + a.C) * 2));
+  const BufRes gr = make_buf((const T*)a.dout + (int64_t)b * a.dosb, (uint32_t)(((int64_t)(a.L - 1) * a.dosl + a.C) * 2));
+  const BufRes dr = make_buf((T*)a.dx + (int64_t)b * a.dxsb, (uint32_t)(((int64_t)(a.L - 1) * a.dxsl + a.C) * 2));
+  const uint32_t xrow = 2u * (uint32_t)a.xsl, grow = 2u * (uint32_t)a.dosl, drow = 2u * (uint32_t)a.dxsl;
+  const bool silu_on = a.silu != 0;
+  auto un2 = [](uint32_t r, float (&o)[VEC]) {
+    if constexpr (std::is_same<T, bf16_t>::value) { o[0] = __builtin_bit_cast(float, r << 16); o[1] = __builtin_bit_cast(float, r & 0xffff0000u); }
+    else { o[0] = to_f32(__builtin_bit_cast(T, (uint16_t)r)); o[1] = to_f32(__builtin_bit_cast(T, (uint16_t)(r >> 16))); }
+  };
+  auto token = [&](auto fast_c, uint32_t rx_, uint32_t rg_, int p) {   // p: scalar
+    constexpr bool FAST = decltype(fast_c)::value;
+    if (FAST || p < pend) {
+#pragma unroll
+      for (int s = 0; s + 1 < W; s++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { xw[s][i] = xw[s + 1][i]; dp[s][i] = dp[s + 1][i]; }
+      const bool inside = FAST ? true : p < a.L;
+      float go[VEC], xn[VEC];
+      un2(rx_, xn);
+      un2(rg_, go);
+#pragma unroll
+      for (int i = 0; i < VEC; i++) { xw[W - 1][i] = inside ? xn[i] : 0.f; go[i] = inside ? go[i] : 0.f; }
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        float d = go[i];
+        if (silu_on) {
+          float pre = bias[i];
+#pragma unroll
+          for (int k = 0; k < W; k++) pre += w[k][i] * xw[k][i];
+          d *= silu_grad(pre);
+        }
+        dp[W - 1][i] = d;
+        if (FAST || p < lend) {   // dw/db: each position is counted by exactly one tile (behind the sequence d is zero)
+          dbacc[i] += d;
+#pragma unroll
+          for (int k = 0; k < W; k++) dwacc[k][i] += d * xw[k][i];
+        }
+      }
+      const int lo = p - (W - 1);
+      if (FAST || (lo >= l0 && lo < lend)) {
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < W; k++) acc += w[k][i] * dp[W - 1 - k][i];
+          o[i] = acc;
+        }
+        T o2[VEC] = {from_f32<T>(o[0]), from_f32<T>(o[1])};
+        const uint32_t pk = (uint32_t)__builtin_bit_cast(uint16_t, o2[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o2[1]) << 16);
+        buf_st_f32(dr, __builtin_bit_cast(float, pk), vch, drow * (uint32_t)lo);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int pg = l0; pg < pend; pg += TG) {
+    uint32_t rawx[TG], rawg[TG];
+#pragma unroll
+    for (int j = 0; j < TG; j++) {
+      const int pc = pg + j < a.L ? pg + j : a.L - 1;   // (scalar clamp; masked in the edge copy of the step)
+      rawx[j] = __builtin_bit_cast(uint32_t, buf_ld_f32(xr, vch, xrow * (uint32_t)pc));
+      rawg[j] = __builtin_bit_cast(uint32_t, buf_ld_f32(gr, vch, grow * (uint32_t)pc));
+    }
+    if (pg >= l0 + W - 1 && pg + TG <= lend) {   // interior group (lend <= L)
+#pragma unroll
+      for (int j = 0; j < TG; j++) { token(std::true_type{}, rawx[j], rawg[j], pg + j); OMK_SCHED_FENCE(); }   // (fence: eight steps scheduled as one block keep 146 registers live)
+    } else {
+#pragma unroll
+      for (int j = 0; j < TG; j++) token(std::false_type{}, rawx[j], rawg[j], pg + j);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    sred[strip][cvl][i * (W + 1) + W] = dbacc[i];
+#pragma unroll
+    for (int k = 0; k < W; k++) sred[strip][cvl][i * (W + 1) + k] = dwacc[k][i];
+  }
+  block_sync();
+  if (strip == 0 && cvok) {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+#pragma unroll
+      for (int k = 0; k <= W; k++) {
+        const int j = i * (W + 1) + k;
+        const float v = sred[0][cvl][j] + sred[1][cvl][j] + sred[2][cvl][j] + sred[3][cvl][j];
+        if (k < W) atomic_add_f32(a.dw + (int64_t)(c0 + i) * W + k, v);
+        else if (a.db) atomic_add_f32(a.db + c0 + i, v);
+      }
+    }
+  }
+}
+
 // strided scalar backward: thread = (b, c), sequential over L (fallback for channel-first / odd layouts)
 template <class T>
 __global__ void conv1d_bwd_generic_kernel(ConvArgs a) {
@@ -519,7 +686,20 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
       else if (v == 1648) CONV_BWD_X(1, 64, 8);
       else return fail(OMK_EINVAL, "OMK_CONV_BWD_VAR: unknown variant %d", v);
 #undef CONV_BWD_X
-    } else if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 8); else CONV_BWD_V(f16_t, 2, 8);
+    } else {
+      // the scalar-position kernel (conv1d_bwd_cl4_kernel) when every row offset fits 31 bits (OMK_CONV_BWD_CL4=0: the round-3 kernel)
+      static const bool cl4 = !(getenv("OMK_CONV_BWD_CL4") && getenv("OMK_CONV_BWD_CL4")[0] == '0');
+      const int64_t far = (int64_t)a.L * 2 * (a.xsl > a.dosl ? (a.xsl > a.dxsl ? a.xsl : a.dxsl) : (a.dosl > a.dxsl ? a.dosl : a.dxsl));
+      if (cl4 && far < ((int64_t)1 << 31) && a.xsc == 1 && a.dosc == 1 && a.dxsc == 1) {
+        const int CVB = (a.C / 2 + 63) / 64, NT4 = (a.L + 4 * TL - 1) / (4 * TL);
+        dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB));
+#define CONV_BWD_4(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 4, TGX>), grid, block, 0, stream, a); \
+          else if (a.W == 3) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 3, TGX>), grid, block, 0, stream, a); \
+          else OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 2, TGX>), grid, block, 0, stream, a); } while (0)
+        if (p->x.dtype == OMK_BF16) CONV_BWD_4(bf16_t); else CONV_BWD_4(f16_t);
+#undef CONV_BWD_4
+      } else if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 8); else CONV_BWD_V(f16_t, 2, 8);
+    }
 #undef CONV_BWD_V
   } else {
     int64_t n = (int64_t)a.B * a.C;
