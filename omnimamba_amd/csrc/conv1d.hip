@@ -135,6 +135,129 @@ __device__ __forceinline__ float conv_in(const ConvArgs& a, const T* x, int b, i
   return 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The forward walk with scalar token positions (round 5; see conv1d_bwd_cl4_kernel): four 16-bit channels (8 bytes) per lane, a wave =
+// one strip of TL tokens x 64 channel quads, the strip index through readfirstlane -- row offsets are scalar, rows move through buffer
+// resources (idle lanes of the last channel block point behind the range), the interior groups of a tile run a test-free token step.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef TGF
+#define TGF 8   // tokens requested per group
+#endif
+template <class T, int TL, int W, int TG>
+__global__ __launch_bounds__(256) void conv1d_fwd_cl8_kernel(ConvArgs a) {
+  constexpr int VEC = 4;
+  static_assert(sizeof(T) == 2, "four 16-bit channels = 8 bytes per lane");
+  const int CV = a.C / VEC, NT4 = (a.L + 4 * TL - 1) / (4 * TL), CVB = (CV + 63) / 64;
+  const int cvb = blockIdx.x % CVB, t4 = (blockIdx.x / CVB) % NT4, b = blockIdx.x / (CVB * NT4);
+  const int cvl = threadIdx.x & 63, strip = uniform_i(threadIdx.x >> 6);
+  const int cv = cvb * 64 + cvl;
+  const bool cvok = cv < CV;
+  const int c0 = (cvok ? cv : 0) * VEC, l0 = (t4 * 4 + strip) * TL;
+  if (l0 >= a.L) return;                                           // (scalar: the whole wave)
+  const T* x = (const T*)a.x + (int64_t)b * a.xsb + c0;
+  float w[W][VEC], bias[VEC], win[W][VEC];
+  {
+    RawElem qb[VEC], qw[W][VEC], qi[W][VEC];
+    vec_t<T, VEC> qx[W];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      qb[i] = raw_rt_flat(a.bias ? a.bias : a.w, a.bias ? c0 + i : 0, a.bias ? a.bdt : a.wdt);
+#pragma unroll
+      for (int k = 0; k < W; k++) qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
+    }
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      qx[s] = *reinterpret_cast<const vec_t<T, VEC>*>(x + (int64_t)(l >= 0 ? l : 0) * a.xsl);
+      const bool ini = a.init != nullptr && l < 0 && W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++)
+        qi[s][i] = raw_rt_flat(ini ? a.init : a.w, ini ? (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl : 0, ini ? a.idt : a.wdt);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      bias[i] = a.bias ? cvt_rt_flat(qb[i], a.bdt) : 0.f;
+#pragma unroll
+      for (int k = 0; k < W; k++) w[k][i] = cvt_rt_flat(qw[k][i], a.wdt);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) win[0][i] = 0.f;
+#pragma unroll
+    for (int s = 1; s < W; s++) {
+      const int l = l0 - W + s;
+      const bool ini = a.init != nullptr && l < 0 && W - 1 + l >= 0;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) win[s][i] = l >= 0 ? to_f32(qx[s].e[i]) : (ini ? cvt_rt_flat(qi[s][i], a.idt) : 0.f);
+    }
+  }
+  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;
+  const uint32_t vch = cvok ? 2u * (uint32_t)c0 : 0x7ffffff0u;
+  const BufRes xr = make_buf((const T*)a.x + (int64_t)b * a.xsb, (uint32_t)(((int64_t)(a.L - 1) * a.xsl + a.C) * 2));
+  const BufRes orr = make_buf((T*)a.out + (int64_t)b * a.osb, (uint32_t)(((int64_t)(a.L - 1) * a.osl + a.C) * 2));
+  const uint32_t xrow = 2u * (uint32_t)a.xsl, orow = 2u * (uint32_t)a.osl;
+  const bool silu_on = a.silu != 0;
+  auto un4 = [](u32x2 r, float (&o)[VEC]) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      o[0] = __builtin_bit_cast(float, r[0] << 16); o[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
+      o[2] = __builtin_bit_cast(float, r[1] << 16); o[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    } else {
+      o[0] = to_f32(__builtin_bit_cast(T, (uint16_t)r[0])); o[1] = to_f32(__builtin_bit_cast(T, (uint16_t)(r[0] >> 16)));
+      o[2] = to_f32(__builtin_bit_cast(T, (uint16_t)r[1])); o[3] = to_f32(__builtin_bit_cast(T, (uint16_t)(r[1] >> 16)));
+    }
+  };
+  auto token = [&](auto fast_c, u32x2 rx_, int l) {   // l: scalar
+    constexpr bool FAST = decltype(fast_c)::value;
+    if (FAST || l < lend) {
+#pragma unroll
+      for (int s = 0; s + 1 < W; s++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) win[s][i] = win[s + 1][i];
+      un4(rx_, win[W - 1]);
+      T o4[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        float acc = bias[i];
+#pragma unroll
+        for (int k = 0; k < W; k++) acc += w[k][i] * win[k][i];
+        o4[i] = from_f32<T>(silu_on ? silu_fast(acc) : acc);
+      }
+      u32x2 pk;
+      pk[0] = (uint32_t)__builtin_bit_cast(uint16_t, o4[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o4[1]) << 16);
+      pk[1] = (uint32_t)__builtin_bit_cast(uint16_t, o4[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o4[3]) << 16);
+      buf_st8(orr, pk, vch, orow * (uint32_t)l);
+    }
+  };
+#pragma unroll 1
+  for (int lg = l0; lg < lend; lg += TG) {
+    u32x2 raw[TG];
+#pragma unroll
+    for (int j = 0; j < TG; j++) {
+      const int l = lg + j < lend ? lg + j : lend - 1;   // (scalar clamp)
+      raw[j] = buf_ld8(xr, vch, xrow * (uint32_t)l);
+    }
+    if (lg + TG <= lend) {
+#pragma unroll
+      for (int j = 0; j < TG; j++) token(std::true_type{}, raw[j], lg + j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TG; j++) token(std::false_type{}, raw[j], lg + j);
+    }
+  }
+  if (a.fin && lend == a.L && cvok) {
+    // final_states[j] = xpad[L + (W - 1) - FW + j], xpad = [init | x]: the last FW >= W - 1 inputs (FW = W: the conv_state of Mamba2's cache)
+    for (int j = 0; j < a.FW; j++) {
+      const int l = a.L + j - a.FW;
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        float v = 0.f;
+        if (l >= 0) v = to_f32(x[(int64_t)l * a.xsl + i]);
+        else if (a.init && W - 1 + l >= 0) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt);
+        store_rt(a.fin, (int64_t)b * a.fsb + (int64_t)(c0 + i) * a.fsc + (int64_t)j * a.fsl, a.fdt, v);
+      }
+    }
+  }
+}
+
 template <class T>
 __global__ void conv1d_fwd_generic_kernel(ConvArgs a, int l_fastest) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -616,9 +739,23 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
       else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 2, TG_>), grid, block, 0, stream, a); } while (0)
     const char* tle = getenv("OMK_CONV_FWD_TL");   // developer A/B of the tokens per thread (bf16)
     const int tl = (tle && *tle) ? atoi(tle) : (a.L >= 1024 ? 64 : 32);   // 64: -4 % on the 1.3B slice (halo rows), 128: worse again
+    static const bool cl8 = !(getenv("OMK_CONV_FWD_CL8") && getenv("OMK_CONV_FWD_CL8")[0] == '0');
+    const int64_t farf = (int64_t)a.L * 2 * (a.xsl > a.osl ? a.xsl : a.osl);
     const char* vce = getenv("OMK_CONV_FWD_VEC");   // developer A/B: "8" = 16 bytes per lane, 4 tokens in flight
     if (p->x.dtype == OMK_BF16 && vce && vce[0] == '8' && a.C % 8 == 0) {
       if (vce[1] == '8') CONV_FWD_V(bf16_t, 8, 64, 8); else if (vce[1] == '2') CONV_FWD_V(bf16_t, 8, 32, 4); else CONV_FWD_V(bf16_t, 8, 64, 4);
+    } else
+    if (cl8 && !(tle && *tle) && !(vce && *vce) && (p->x.dtype == OMK_BF16 || p->x.dtype == OMK_F16) && a.L >= 256 && a.C % 4 == 0 && farf < ((int64_t)1 << 31) &&
+        a.xsc == 1 && a.osc == 1) {
+      // scalar token positions (conv1d_fwd_cl8_kernel); OMK_CONV_FWD_CL8=0: the per-thread tiles of rounds 1 - 4
+      constexpr int TLF = 64;
+      const int CVB = (a.C / 4 + 63) / 64, NT4 = (a.L + 4 * TLF - 1) / (4 * TLF);
+      dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB)), block(256);
+#define CONV_FWD_8(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 4, TGF>), grid, block, 0, stream, a); \
+        else if (a.W == 3) OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 3, TGF>), grid, block, 0, stream, a); \
+        else OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 2, TGF>), grid, block, 0, stream, a); } while (0)
+      if (p->x.dtype == OMK_BF16) CONV_FWD_8(bf16_t); else CONV_FWD_8(f16_t);
+#undef CONV_FWD_8
     } else
     if (p->x.dtype == OMK_BF16) {
       if (tl == 128) CONV_FWD_V(bf16_t, 4, 128, 8); else if (tl == 64) CONV_FWD_V(bf16_t, 4, 64, 8); else if (tl == 16) CONV_FWD_V(bf16_t, 4, 16, 8);

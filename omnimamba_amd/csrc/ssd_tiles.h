@@ -99,6 +99,15 @@ template <> __device__ __forceinline__ void buf_st_t<f16_t>(const BufRes& b, flo
   const _Float16 h = (_Float16)v;
   buf_st_u16(b, __builtin_bit_cast(uint16_t, h), voff, soff);
 }
+__device__ __forceinline__ u32x2 buf_ld8(const BufRes& b, uint32_t voff, uint32_t soff) {
+#ifdef OMK_EMU
+  const uint32_t o = voff + soff;
+  if (o >= b.nbytes) return u32x2{0u, 0u};
+  return *reinterpret_cast<const u32x2*>(b.base + o);
+#else
+  return __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
+#endif
+}
 __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
   const uint32_t o = voff + soff;
