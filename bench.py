@@ -276,7 +276,20 @@ def scan_target(dev):
     """The north-star target shape: the Mamba-2 chunked scan (omk_ssd_scan_fwd through mamba_chunk_scan_combined) at L = 8192,
     d_model 2048 (H 64, P 64, N 128, one group), bf16, B = 8 and B = 1, and the plain (inference-form) forward at the shape of the
     timed step (B 8, L 4096); HIP events on the launch stream, algorithmic bytes of SURVEY.md section 8d (17 024 B per token)."""
-    from omnimamba_amd.ssd_combined import mamba_chunk_scan_combined
+    from omnimamba_amd.ssd_combined import mamba_chunk_scan_combined, scan_options
+
+    def time_it(run, n=40):
+        with torch.no_grad():
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
     out = {}
     for L, Bsz in ((4096, 8), (8192, 8), (8192, 1)):   # (the first: the plain forward at the shape of the timed step, whose own forward also writes window states)
         torch.manual_seed(0)
@@ -286,22 +299,19 @@ def scan_target(dev):
         Bm, Cm = (torch.randn(Bsz, L, 1, D_STATE, device=dev, dtype=torch.bfloat16) for _ in range(2))
         D, dtb = torch.ones(H, device=dev), torch.randn(H, device=dev) * 0.5 - 2
         run = lambda: mamba_chunk_scan_combined(x, dt, A, Bm, Cm, 256, D=D, dt_bias=dtb, dt_softplus=True)
-        with torch.no_grad():
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 40
-            e0.record()
-            for _ in range(n):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
+        ms = time_it(run)
         nb = Bsz * L * SCAN_FWD_BYTES_PER_TOK
         out[f"B{Bsz}_L{L}"] = {"launch_ms": round(ms, 4), "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
                                "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "M_elements_per_s": round(Bsz * L * D_SCAN / (ms * 1e-3) / 1e6, 1)}
+        if Bsz == 8:
+            # the same launch with the per-call parity options (OmkSsdFwd.flags): what the bare 1e-3 on slow-decay heads costs
+            with scan_options(khilo=True):
+                mk = time_it(run, 20)
+            with scan_options(precise=True):
+                mp = time_it(run, 20)
+            out[f"B{Bsz}_L{L}"]["options"] = {"khilo_launch_ms": round(mk, 4), "khilo_price": round(mk / ms - 1, 3),
+                                               "precise_launch_ms": round(mp, 4), "precise_price": round(mp / ms - 1, 3)}
     return out
 
 

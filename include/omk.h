@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 5
+#define OMK_ABI_VERSION 6
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -296,7 +296,20 @@ typedef struct {
   int32_t dt_softplus;
   int32_t chunk_size;       /* API parity only: the result does not depend on it */
   int32_t force_generic;    /* 1 = use the shape-generic fp32 VALU kernel even when the MFMA kernel applies */
+  int32_t flags;            /* ABI 6: OMK_SSD_* bits below, 0 = the default kernels.  Per call -- the library reads no environment
+                             * variable that changes which scan kernel runs or what it computes */
 } OmkSsdFwd;
+/* OmkSsdFwd::flags / OmkSsdBwd::flags */
+#define OMK_SSD_PRECISE      1  /* forward, bf16 MFMA scan: the carried state meets C as a bf16 hi + lo pair and the state-update operand is
+                                 * hi + lo: y within 1e-3 (arithmetic, rel-L2) of the fp32 recurrence on EVERY head, slow-decay heads
+                                 * included (the default rounds both to bf16 once, as the reference pipeline does: 1.3e-3 .. 2.3e-3 there).
+                                 * Price: profiles/r06_precise.txt.  Window states cannot be saved by a PRECISE forward */
+#define OMK_SSD_KHILO        2  /* forward: only the state-update operand as hi + lo (the carried state / final_states exact to fp32
+                                 * accumulation); implied whenever final_states is asked for */
+#define OMK_SSD_EVERY_CHUNK  4  /* specialised-wave kernel: rescale the carried state at every chunk end instead of only where its basis
+                                 * drifts by 2^60 (the arithmetic of the column-slice kernel, bit for bit; tests) */
+#define OMK_SSD_NO_SPLIT     8  /* never cut the sequence into segments (few (batch, head) sequences normally are: csrc/ssd_scan.h) */
+#define OMK_SSD_COLUMN_SLICE 16 /* class A scans on the column-slice kernel (ssd_a6.hip) instead of the specialised-wave kernel */
 size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p);
 /* bytes of window_states for these arguments (window_states itself is not looked at); 0 = this forward cannot save them (shape
  * outside the MFMA kernel, gate / out_x requested, fp32 activations): pass none */
@@ -326,7 +339,9 @@ typedef struct {
   int32_t dt_softplus;
   int32_t chunk_size;
   int32_t force_generic;
+  int32_t flags;             /* ABI 6: OMK_SSD_NO_SPLIT, OMK_SSD_COLUMN_SLICE, OMK_SSD_EVERY_CHUNK, OMK_SSD_SEQUENTIAL_BWD */
 } OmkSsdBwd;
+#define OMK_SSD_SEQUENTIAL_BWD 32 /* backward: the three sequential MFMA scans of rounds 1 - 2 instead of the chunk-parallel dB / dC */
 size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p);
 int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream);
 

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 5
+OMK_ABI_VERSION = 6
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
@@ -75,11 +75,13 @@ LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b", "mask")] + [
 LoraUpBwd = _S("OmkLoraUpBwd", [(n, _t) for n in ("dy", "lora_b", "h", "dh", "dlora_b")])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states", "window_states")] + _ws
-            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
+            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i), ("flags", _i)])
+# OmkSsdFwd.flags / OmkSsdBwd.flags (include/omk.h)
+SSD_PRECISE, SSD_KHILO, SSD_EVERY_CHUNK, SSD_NO_SPLIT, SSD_COLUMN_SLICE, SSD_SEQUENTIAL_BWD = 1, 2, 4, 8, 16, 32
 SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "dt_bias", "initial_states", "y", "dout",
                                             "dfinal_states", "dx", "ddt", "dA", "dB", "dC", "dD", "ddt_bias",
                                             "dinitial_states", "window_states")] + _ws
-            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i)])
+            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i), ("flags", _i)])
 
 CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("losses", _t), ("grad_scale", C.c_void_p),
                                       ("ignore_index", _i64), ("write_grad", _i)])

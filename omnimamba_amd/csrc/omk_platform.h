@@ -268,6 +268,13 @@ __device__ __forceinline__ float wave_pair_boundary(float v) {
 #else
 #define OMK_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
+// A lambda that must be inlined at every call site (a large body called twice is otherwise left as a function: everything it captures by
+// reference -- accumulator tiles, staging registers -- then lives in scratch memory)
+#ifdef OMK_EMU
+#define OMK_ALWAYS_INLINE_LAMBDA
+#else
+#define OMK_ALWAYS_INLINE_LAMBDA __attribute__((always_inline))
+#endif
 // Keep a value alive without using it (ablation builds)
 #ifdef OMK_EMU
 #define OMK_KEEP(x) do { } while (0)

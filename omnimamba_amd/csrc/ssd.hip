@@ -588,8 +588,7 @@ extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
 static size_t fwd_window_states_bytes(const OmkSsdFwd* p) {
   if (!p || p->force_generic || !present(p->out) || present(p->z) || present(p->out_x)) return 0;
   if (p->x.ndim != 4 || p->Bm.ndim != 4 || p->x.dtype != OMK_BF16 || p->x.shape[3] != 64 || p->Bm.shape[3] != 128) return 0;
-  if (const char* e = getenv("OMK_SSD_KHILO")) if (e[0] == '1') return 0;
-  if (const char* e = getenv("OMK_SSD_PRECISE")) if (e[0] == '1') return 0;
+  if (p->flags & (OMK_SSD_KHILO | OMK_SSD_PRECISE)) return 0;
   const int64_t B = p->x.shape[0], L = p->x.shape[1], H = p->x.shape[2];
   // the same dry check the launch makes (strides, alignment, 32-bit row span): a forward the MFMA kernel cannot take must answer 0
   // here, so that the caller allocates nothing and omk_ssd_scan_fwd takes its ordinary fall-back chain (advisor finding, round 3:
@@ -643,7 +642,8 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
 #ifdef OMK_PHASE_PROF
   if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
 #endif
-  if (ssd_seg_bytes(d.B * d.H, d.L) && !getenv("OMK_SSD_NO_SPLIT")) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
+  g.flags = p->flags & (GSF_PRECISE | GSF_KHILO | GSF_FLUSH | GSF_NO_SPLIT | GSF_COLUMN_SLICE);
+  if (ssd_seg_bytes(d.B * d.H, d.L) && !(p->flags & OMK_SSD_NO_SPLIT)) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
   if (state_only) {
     rc = (p->force_generic || p->x.dtype != OMK_BF16) ? OMK_EUNSUPPORTED : ssd_mfma_state_only(g, stream);
     if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the state-only pass exists for the MFMA shape only (bf16, headdim 64, d_state 128); run the scan and drop its output");
@@ -701,6 +701,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
   auto base = [&](int mode) {
     GScan g = {};
     g.mode = mode; g.dtp = w.dtp; g.A = (const float*)p->A.data; g.B = d.B; g.H = d.H; g.G = d.G; g.L = d.L;
+    g.flags = p->flags & (GSF_FLUSH | GSF_NO_SPLIT | GSF_COLUMN_SLICE);
 #ifdef OMK_PHASE_PROF
     if (const char* e = getenv("OMK_ABLATE_B")) g.ablate = atoi(e);
 #endif
@@ -730,7 +731,7 @@ static void bwd_scans(const OmkSsdBwd* p, const SsdDims& d, const BwdWs& w, bool
       g.fin = (float*)p->dinitial_states.data; g.fin_extra_decay = 1;
       g.fsb = p->dinitial_states.stride[0]; g.fsh = p->dinitial_states.stride[1]; g.fsu = p->dinitial_states.stride[2]; g.fsk = p->dinitial_states.stride[3];
     }
-    g.seg = getenv("OMK_SSD_NO_SPLIT") ? nullptr : w.seg;
+    g.seg = (p->flags & OMK_SSD_NO_SPLIT) ? nullptr : w.seg;
     g.out = p->dx.data; g.osb = p->dx.stride[0]; g.osl = p->dx.stride[1]; g.osh = p->dx.stride[2]; g.out_dt = p->dx.dtype;
     if (present(p->D)) { g.D = p->D.data; g.D_dt = p->D.dtype; g.Dsh = p->D.stride[0]; g.Dsp = p->D.ndim == 2 ? p->D.stride[1] : 0; }
     *gdx = g;
@@ -761,7 +762,7 @@ static bool bwd_mfma_applies(const OmkSsdBwd* p, const SsdDims& d) {
 
 // the chunk-parallel form: bf16 block shape (the MFMA scans apply), one D per head, rows addressable through 32-bit buffer offsets
 static bool bwd_cp_applies(const OmkSsdBwd* p, const SsdDims& d) {
-  if (const char* e = getenv("OMK_SSD_BWD_CP")) if (e[0] == '0') return false;
+  if (p->flags & OMK_SSD_SEQUENTIAL_BWD) return false;
   if (present(p->D) && p->D.ndim != 1) return false;
   if (p->x.dtype != OMK_BF16 || d.P != 64 || d.N != 128) return false;
   const int64_t lim = (int64_t)0xfffff000;
@@ -819,7 +820,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
       gf.init = p->initial_states.data; gf.init_dt = p->initial_states.dtype;
       gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
     }
-    gf.seg = w.segf;
+    gf.seg = w.segf; gf.flags = gdx.flags;
     int fmt_f = 0, fmt_a = 0;   // element order each pass left its states in (ssd_scan.h: seg_fmt)
     if (!(cp && present(p->window_states)) && (rc = ssd_mfma_prepare_segments(gf, stream, &fmt_f))) return rc;   // (saved window states: no forward state pass at all)
     if ((rc = ssd_mfma_prepare_segments(gdx, stream, &fmt_a))) return rc;
@@ -838,6 +839,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
       gf.init = p->initial_states.data; gf.init_dt = p->initial_states.dtype;
       gf.isb = p->initial_states.stride[0]; gf.ish = p->initial_states.stride[1]; gf.isu = p->initial_states.stride[2]; gf.isk = p->initial_states.stride[3];
     }
+    gf.flags = gdx.flags;
     if (gdc.seg_ready) { gf.seg = w.segf; gf.seg_ready = 1; gf.seg_fmt = gdc.seg_fmt; }
     // (a training forward that saved its window states spares this pass: the same images, written by the same code)
     const uint16_t* Sf = w.Sf;

@@ -614,10 +614,9 @@ int ssd_a6_launch(const GScan& g, omk_stream stream) {
   }
   dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
   const size_t smem = sizeof(SmemA6);
-  const char* khe = getenv("OMK_SSD_KHILO");
   // the scaled U operand of the state update as hi + lo whenever the caller keeps the final state (prefill -> decode hand-off,
   // context-parallel shards): the carried state is then exact to fp32 accumulation (8 more MFMAs per sub-chunk)
-  const bool khilo = khe ? khe[0] == '1' : (a.fin != nullptr);
+  const bool khilo = (a.flags & (GSF_KHILO | GSF_PRECISE)) || a.fin != nullptr;
 #define OMK_A6K(MODE_, EX_, DF_, DU_, KH_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), grid, block, smem, stream, a); } while (0)

@@ -44,7 +44,10 @@ struct SmemA8 {            // (the layout of SmemA6)
 };
 static_assert(sizeof(SmemA8) <= 160 * 1024, "one workgroup per CU");
 
-template <int MODE, bool DUMP, bool KHILO>
+// PRECISE (OmkSsdFwd::flags & OMK_SSD_PRECISE, forward only): the bf16 copy of the state slice that meets Q^T is a hi + lo pair -- twice the
+// MFMAs of phase 1 and six instead of one VALU operation per packed pair -- and KHILO is on: no operand of the scan is rounded to 8 bits
+// any more, y is within the bare 1e-3 of the fp32 recurrence on every head (tests/test_configs_gpu.py, profiles/r06_precise.txt)
+template <int MODE, bool DUMP, bool KHILO, bool PRECISE = false>
 __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   OMK_DYN_SMEM(smem_raw);
   SmemA8& sm = *reinterpret_cast<SmemA8*>(smem_raw);
@@ -101,65 +104,102 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     const uint32_t kvo = 2u * (uint32_t)((rev ? 15 - rowk : rowk) * ksl + ck8), qvo = 2u * (uint32_t)((rev ? 15 - rowk : rowk) * qsl + ck8);
     const uint32_t uvo = 2u * (uint32_t)((rev ? 15 - rowu : rowu) * usl + cu8);
     const uint32_t dvo = 4u * (uint32_t)rowtok(lane), dvo_a = 4u * (uint32_t)(rowtok(lane) + (rev ? 1 : 0));
-    u32x4 rk[4], rq[4], ru[4];
-    float rdt = 0.f, rda = 0.f, rwv = 0.f;
-    int stlo = 0;
+    // OMK_A8_PF2 = 1 (round 6 experiment, measured neutral: profiles/r06_a8_experiments.txt): TWO chunks of K / Q / dt' loads in flight per
+    // helper -- register set (c - c0) & 1 is committed in iteration c (chunk c + 2) and refilled at once (chunk c + 4), the other set holds
+    // chunk c + 3.  The ablations without commits / without loads are both ~30 us faster, which reads like memory latency x bytes in
+    // flight; twice the bytes in flight changed nothing (bit-identical results, 169.7 - 177.6 against 172.2 - 174.9 us), so it is not.
+#ifndef OMK_A8_PF2
+#define OMK_A8_PF2 0
+#endif
+    constexpr int NSET = OMK_A8_PF2 ? 2 : 1;
+    u32x4 rk[NSET][4], rq[NSET][4], ru[NSET][4];
+    float rdt_[NSET], rda_[NSET], rwv = 0.f;
+    int stlo[NSET];
+#pragma unroll
+    for (int i = 0; i < NSET; i++) { rdt_[i] = 0.f; rda_[i] = 0.f; stlo[i] = 0; }
     // (the loads of an iteration are issued in pieces, each right behind the commit that frees its registers: four waves issuing 14 loads
-    // in one burst sat ~600 cycles in the issue queue of the CU's memory pipeline, and a load issued early has a whole iteration to land)
-    auto prefetch_k = [&](int tl) {
+    // in one burst sat ~600 cycles in the issue queue of the CU's memory pipeline)
+    auto prefetch_k = [&](auto ps, int tl) {
+      constexpr int S = decltype(ps)::value;
       const uint32_t sk = 2u * (uint32_t)(tl * ksl);
 #pragma unroll
-      for (int r = 0; r < 4; r++) rk[r] = buf_ld16(Kr, kvo, sk + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * ksl));
+      for (int r = 0; r < 4; r++) rk[S][r] = buf_ld16(Kr, kvo, sk + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * ksl));
     };
-    auto prefetch_q = [&](int tl) {
+    auto prefetch_q = [&](auto ps, int tl) {
+      constexpr int S = decltype(ps)::value;
       const uint32_t sq = 2u * (uint32_t)(tl * qsl);
 #pragma unroll
-      for (int r = 0; r < 4; r++) rq[r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * qsl));
+      for (int r = 0; r < 4; r++) rq[S][r] = buf_ld16(Qr, qvo, sq + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * qsl));
     };
-    auto prefetch_dt = [&](int tl) {
-      stlo = tl;
-      rdt = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
-      rda = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
+    auto prefetch_dt = [&](auto ps, int tl) {
+      constexpr int S = decltype(ps)::value;
+      stlo[S] = tl;
+      rdt_[S] = buf_ld_f32(Dr, dvo, 4u * (uint32_t)tl);
+      rda_[S] = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
     };
-    auto prefetch_kq = [&](int tl) { prefetch_k(tl); prefetch_q(tl); prefetch_dt(tl); };
-    auto prefetch_u = [&](int tl) {
+    auto prefetch_kq = [&](auto ps, int tl) { prefetch_k(ps, tl); prefetch_q(ps, tl); prefetch_dt(ps, tl); };
+    auto prefetch_u = [&](auto ps, int tl) {   // (OMK_A8_CU = 0 only)
+      constexpr int S = decltype(ps)::value;
       const uint32_t su_ = 2u * (uint32_t)(tl * usl);
 #pragma unroll
-      for (int r = 0; r < 4; r++) ru[r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
+      for (int r = 0; r < 4; r++) ru[S][r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
     };
     const int o_ck = kx3(rowk, ck8), o_cu = ux3(rowu, cu8);
-    auto commit_k = [&](int kb) {
+    auto commit_k = [&](auto ps, int kb) {
+      constexpr int S = decltype(ps)::value;
 #pragma unroll
-      for (int r = 0; r < 4; r++) st16(&sm.K[kb][o_ck + 16 * 128 * r], rk[r]);
+      for (int r = 0; r < 4; r++) st16(&sm.K[kb][o_ck + 16 * 128 * r], rk[S][r]);
     };
-    auto commit_q = [&](int kb) {
+    auto commit_q = [&](auto ps, int kb) {
+      constexpr int S = decltype(ps)::value;
 #pragma unroll
-      for (int r = 0; r < 4; r++) st16(&sm.Q[kb][o_ck + 16 * 128 * r], rq[r]);
+      for (int r = 0; r < 4; r++) st16(&sm.Q[kb][o_ck + 16 * 128 * r], rq[S][r]);
     };
-    auto commit_u = [&](int ub) {
+    auto commit_u = [&](auto ps, int ub) {
+      constexpr int S = decltype(ps)::value;
 #pragma unroll
-      for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[r]);
+      for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[S][r]);
     };
     // (LDS-DMA staging -- buffer_load ... lds, the swizzle on the source address -- was measured here as in ssd_a6.hip: correct and SLOWER, 207 us
     // against 183: the DMA path of a CU lands ~12 bytes per cycle, a chunk needs 48 KB; profiles/r05_a8_experiments.txt, git history)
     const float Ah2 = a.A[h] * LOG2E;
-    auto scalars = [&](int kb, int mb) {   // helper waves with w == 0 (ssd_a6.hip: the same scalars, lazy decay and factored tile decay)
+    // The carried state of a head lives in a BASIS: the compute waves hold S' = S(true, at the basis point) and everything that meets it
+    // carries the missing decay -- rl = 2^(c_l - basis) on the output side, ws = w 2^(basis' - c_s) on the update side -- so the 64 accumulator
+    // registers of a wave are multiplied by a decay only when the basis MOVES.  ssd_a6.hip moves it to the chunk end at every chunk
+    // (and to the end of the first sub-chunk when that sub-chunk alone decays by more than 2^-60); here the basis stays where it is for as
+    // long as it is less than 2^60 of decay behind (round 6: the decay multiplies were 62 of the 535 instructions of a chunk, most of
+    // them packed fp32, which does not overlap with the matrix pipe), and is pulled up where somebody needs the true state: in front of a
+    // window-state image, behind the last chunk (final state / next segment), and at every chunk when the caller asks for the
+    // arithmetic of the column-slice kernel (GSF_FLUSH).  `base` = log2 decay coordinate of the basis relative to the start of the chunk
+    // whose scalars are computed next (>= 0: in the past).
+    float base = 0.f;
+    auto dumps_at = [&](int cc) -> bool {
+      if (!(DUMP && a.dump)) return false;
+      const int cid = rev ? nC - 1 - cc : cc;
+      return rev ? (cid == nC - 1 || (cid & 1)) : !(cid & 1);
+    };
+    auto scalars = [&](auto ps, int kb, int mb, int cc) {   // helper waves with w == 0 (ssd_a6.hip: the same scalars and factored tile decay); cc: chunk in scan order
+      constexpr int S = decltype(ps)::value;
+      float rdt, rda;
       {
-        const int t = stlo + rowtok(lane);
+        const int t = stlo[S] + rowtok(lane);
         const bool okd = t < a.L, oka = okd && (rev ? t + 1 : t) < a.L;
-        rwv = okd ? (a.w_is_dt ? rdt : 1.f) : 0.f;
-        rdt = okd ? rdt : 0.f;
-        rda = oka ? rda : 0.f;
+        rwv = okd ? (a.w_is_dt ? rdt_[S] : 1.f) : 0.f;
+        rdt = okd ? rdt_[S] : 0.f;
+        rda = oka ? rda_[S] : 0.f;
       }
       const float cs = wave_incl_scan_add(rda * Ah2);
       const float e31 = wave_read_lane(cs, 31), e63 = wave_read_lane(cs, 63);
-      const float csb = lane < 32 ? 0.f : e31;
       const float rsc = MODE == GS_DX ? rdt : 1.f;
-      const bool lazy = e31 > -60.f;
-      const float csb_r = lazy ? 0.f : csb, cse_w = lane < 32 ? (lazy ? 0.f : e31) : e63;
-      sm.rl[kb][hh][lane] = exp2_fast(cs - csb_r) * rsc;
-      sm.ws[kb][hh][lane] = rwv * exp2_fast(cse_w - cs);
-      if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = lane < 32 ? (lazy ? 1.f : exp2_fast(e31)) : exp2_fast(lazy ? e63 : e63 - e31);
+      const bool flush_end = (a.flags & GSF_FLUSH) != 0 || cc >= c1 - 1 || dumps_at(cc + 1);
+      const float b0 = base;                                                  // basis under the first sub-chunk's output rows
+      const float b0p = (b0 - e31 <= 60.f) ? b0 : e31;                        // ... behind its state update
+      const float b1p = (!flush_end && b0p - e63 <= 60.f) ? b0p : e63;        // ... behind the second one
+      base = b1p - e63;
+      sm.rl[kb][hh][lane] = exp2_fast(cs - (lane < 32 ? b0 : b0p)) * rsc;
+      sm.ws[kb][hh][lane] = rwv * exp2_fast((lane < 32 ? b0p : b1p) - cs);
+      // (1.f exactly = the basis stays: the compute waves test the bits and skip the multiply)
+      if ((lane & 31) == 31) sm.dec[kb][hh][lane >> 5] = lane < 32 ? (b0p == b0 ? 1.f : exp2_fast(b0p - b0)) : (b1p == b0p ? 1.f : exp2_fast(b1p - b0p));
       const bool blk1 = (lane & 16) != 0;
       const float cmid = wave_row_bcast<7>(cs), cbnd = wave_pair_boundary(cs);   // cs of lane b16 + 7 / of lane blk1 ? b16 - 1 : b16 + 15
       const bool wide = ballot_any(fabsf(cs - cmid) > 90.f);
@@ -258,57 +298,69 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       }
     };
     FragB fb;
-    // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built
-    prefetch_kq(chunk_lo(c0));
-    if (!OMK_A8_CU) prefetch_u(chunk_lo(c0));
-    commit_k(0); commit_q(0);
-    if (!OMK_A8_CU) commit_u(0);
-    if (w == 0) scalars(0, 0);
-    prefetch_kq(chunk_lo(clipc(c0 + 1)));
-    commit_k(1); commit_q(1);
-    if (w == 0) scalars(1, 1);
+    // ---- prologue: chunks c0 and c0 + 1 staged, tiles of c0 built, chunks c0 + 2 (and c0 + 3) requested
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NSET - 1>;
+    prefetch_kq(S0{}, chunk_lo(c0));
+    if (!OMK_A8_CU) prefetch_u(S0{}, chunk_lo(c0));
+    commit_k(S0{}, 0); commit_q(S0{}, 0);
+    if (!OMK_A8_CU) commit_u(S0{}, 0);
+    if (w == 0) scalars(S0{}, 0, 0, c0);
+    prefetch_kq(S0{}, chunk_lo(clipc(c0 + 1)));
+    commit_k(S0{}, 1); commit_q(S0{}, 1);
+    if (w == 0) scalars(S0{}, 1, 1, c0 + 1);
     block_sync();
     build_loads(fb, 0, 0);
     build_flags(fb);
     build_tile(fb, 0, 0);
     if (w == 1) build_tile(fb, 0, 1);
-    prefetch_kq(chunk_lo(clipc(c0 + 2)));
-    if (!OMK_A8_CU) prefetch_u(chunk_lo(clipc(c0 + 1)));
+    prefetch_kq(S0{}, chunk_lo(clipc(c0 + 2)));
+    if (NSET == 2) prefetch_kq(S1{}, chunk_lo(clipc(c0 + 3)));
+    if (!OMK_A8_CU) { prefetch_u(S0{}, chunk_lo(clipc(c0 + 1))); if (NSET == 2) prefetch_u(S1{}, chunk_lo(clipc(c0 + 2))); }
     block_sync();
     int kb1 = 1, kb2 = 2, kb0 = 0;
     PT8_START();
 #if !defined(OMK_EMU)
     if (OMK_A8_VAR & 1) __builtin_amdgcn_s_setprio(3);
 #endif
-    for (int c = c0; c < c1; c++) {
+    // one iteration: the tiles of chunk c + 1, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U) out of register set ps, the
+    // loads of chunk c + 2 + NSET into the set just freed
+    auto iter = [&](auto ps, int c) OMK_ALWAYS_INLINE_LAMBDA {
       const int ub0 = (c - c0) & 1, ub1 = ub0 ^ 1;
       constexpr bool more = true;   // (behind the last chunk the builders redo its tiles from the re-staged buffers: nobody reads them, no branch)
-      // the tiles of chunk c + 1, the staging of chunk c + 2 (K / Q / scalars) and c + 1 (U), the loads of c + 3 / c + 2
       // (OMK_A8_VAR ablations, wrong results: 16 no tile build, 32 no scalars, 64 no commits, 128 no loads.)  The steps are fenced: left
       // alone the compiler moved the builder's LDS reads down to their first use.
       if (more && !(OMK_A8_VAR & 16)) build_loads(fb, kb1, ub1);
       OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 64)) commit_k(kb2);
-      if (!(OMK_A8_VAR & 128)) prefetch_k(chunk_lo(clipc(c + 3)));
+      if (!(OMK_A8_VAR & 64)) commit_k(ps, kb2);
+      if (!(OMK_A8_VAR & 128)) prefetch_k(ps, chunk_lo(clipc(c + 2 + NSET)));
       OMK_SCHED_FENCE();
       if (more && !(OMK_A8_VAR & 16)) build_flags(fb);
       PT8(0);
       if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 0);
       PT8(1);
       OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 64)) commit_q(kb2);
-      if (!(OMK_A8_VAR & 128)) prefetch_q(chunk_lo(clipc(c + 3)));
+      if (!(OMK_A8_VAR & 64)) commit_q(ps, kb2);
+      if (!(OMK_A8_VAR & 128)) prefetch_q(ps, chunk_lo(clipc(c + 2 + NSET)));
       OMK_SCHED_FENCE();
       PT8(2);
-      if (w == 0) { if (!(OMK_A8_VAR & 32)) scalars(kb2, ub0); } else if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 1);
+      if (w == 0) { if (!(OMK_A8_VAR & 32)) scalars(ps, kb2, ub0, c + 2); } else if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 1);
       PT8(3);
       OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 64) && !OMK_A8_CU) commit_u(ub1);
-      if (!(OMK_A8_VAR & 128)) { if (!OMK_A8_CU) prefetch_u(chunk_lo(clipc(c + 2))); prefetch_dt(chunk_lo(clipc(c + 3))); }
+      if (!(OMK_A8_VAR & 64) && !OMK_A8_CU) commit_u(ps, ub1);
+      if (!(OMK_A8_VAR & 128)) { if (!OMK_A8_CU) prefetch_u(ps, chunk_lo(clipc(c + 1 + NSET))); prefetch_dt(ps, chunk_lo(clipc(c + 2 + NSET))); }
       PT8(4);
       block_sync();
       PT8(5);
       { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
+    };
+    if (NSET == 2) {
+      for (int c = c0; c < c1; c += 2) {
+        iter(S0{}, c);
+        if (c + 1 < c1) iter(S1{}, c + 1);
+      }
+    } else {
+      for (int c = c0; c < c1; c++) iter(S0{}, c);
     }
     PT8_END();
     };
@@ -364,13 +416,22 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   const int urow = 8 * w + (lane >> 3);
   const uint32_t uvo = 2u * (uint32_t)((rev ? 15 - urow : urow) * usl + 8 * (lane & 7));
   const int o_cu = ux3(urow, 8 * (lane & 7));
-  u32x4 ru[4];
-  auto prefetch_u = [&](int tl) {
+#ifndef OMK_A8_UPF2
+#define OMK_A8_UPF2 0   // 1: two chunks of U loads in flight per compute wave (9 spilled registers: + 3 %); the helpers' loads: OMK_A8_PF2
+#endif
+  constexpr int USET = OMK_A8_UPF2 ? 2 : 1;
+  using U0 = std::integral_constant<int, 0>;
+  using U1 = std::integral_constant<int, USET - 1>;
+  u32x4 ruu[USET][4];
+  auto prefetch_u = [&](auto ps, int tl) {
+    constexpr int S = decltype(ps)::value;
     const uint32_t su_ = 2u * (uint32_t)(tl * usl);
 #pragma unroll
-    for (int r = 0; r < 4; r++) ru[r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
+    for (int r = 0; r < 4; r++) ruu[S][r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
   };
-  auto commit_u = [&](int ub) {
+  auto commit_u = [&](auto ps, int ub) {
+    constexpr int S = decltype(ps)::value;
+    u32x4 (&ru)[4] = ruu[S];
     if (OMK_A8_VAR & 2048) {
       // (K2 fusion step (iii), priced: a depthwise conv of width 4 + SiLU on the 32 staged x values of this lane -- the arithmetic the staging
       // wave would do if the scan read the PRE-conv x; stand-in taps and halo rows, wrong values, representative instruction count)
@@ -396,9 +457,10 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[r]);
   };
   if (OMK_A8_CU) {
-    prefetch_u(chunk_lo(c0));
-    commit_u(0);
-    prefetch_u(chunk_lo(clipc(c0 + 1)));
+    prefetch_u(U0{}, chunk_lo(c0));
+    commit_u(U0{}, 0);
+    prefetch_u(U0{}, chunk_lo(clipc(c0 + 1)));
+    if (USET == 2) prefetch_u(U1{}, chunk_lo(clipc(c0 + 2)));
   }
   block_sync();   // (the helpers' prologue: two barriers)
   block_sync();
@@ -489,9 +551,17 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       if (KHILO) ul[cg][2 * s2 + p2] = pack_bf16x2(us[2 * p2] - bf_lo(hi), us[2 * p2 + 1] - bf_hi(hi));
     }
   };
+  auto pack_pair_lo = [&](int cg, int i, const u32x4& hi) -> u32x4 {   // PRECISE: what the bf16 rounding of pack_pair left behind
+    u32x4 sp;
+    sp[0] = pack_bf16x2(accS[cg][2 * i][0] - bf_lo(hi[0]), accS[cg][2 * i][1] - bf_hi(hi[0]));
+    sp[1] = pack_bf16x2(accS[cg][2 * i][2] - bf_lo(hi[1]), accS[cg][2 * i][3] - bf_hi(hi[1]));
+    sp[2] = pack_bf16x2(accS[cg][2 * i + 1][0] - bf_lo(hi[2]), accS[cg][2 * i + 1][1] - bf_hi(hi[2]));
+    sp[3] = pack_bf16x2(accS[cg][2 * i + 1][2] - bf_lo(hi[3]), accS[cg][2 * i + 1][3] - bf_hi(hi[3]));
+    return sp;
+  };
   // ---- phase 1 of a sub-chunk: pack of the state slice + S_in^T Q^T on the Q row fragments of its two strips; in the shadows of the MFMA
   // pairs: the pack of the next tile pair, the requests for the phase-2 operands (nf), the scaled U operand
-  auto phase1 = [&](const FragR& f, bool dump_slot, bool dump_here, uint32_t dso, FragC& nf, int nkb, int nub, int njj) {
+  auto phase1 = [&](const FragR& f, bool dump_slot, bool dump_here, uint32_t dso, FragC& nf, int nkb, int nub, int njj) OMK_ALWAYS_INLINE_LAMBDA {
     u32x4 sp = pack_pair(0, 0);
     load_cols(nf, nkb, nub, njj, 0);
     OMK_SCHED_FENCE();
@@ -505,6 +575,11 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       } else {
         accA0[cg] = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q0[i]), accA0[cg]);
         accA1[cg] = mfma16x16x32_bf16(as_s16x8(sp), as_s16x8(f.q1[i]), accA1[cg]);
+      }
+      if (PRECISE) {
+        const u32x4 spl = pack_pair_lo(cg, i, sp);
+        accA0[cg] = mfma16x16x32_bf16(as_s16x8(spl), as_s16x8(f.q0[i]), accA0[cg]);
+        accA1[cg] = mfma16x16x32_bf16(as_s16x8(spl), as_s16x8(f.q1[i]), accA1[cg]);
       }
       if (n < 7) sp = pack_pair((n + 1) & 1, (n + 1) >> 1);
       if (n < 6) load_cols(nf, nkb, nub, njj, n + 1);
@@ -522,11 +597,9 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   };
   // ---- phase 2: U^T M^T (intra block), state update, output rows; in the shadows: decay of the next tile, the output arithmetic, the
   // requests for the Q row fragments of the next sub-chunk (nr)
-  // (MUL: the decay multiply of the state slice in the shadows of the MFMAs -- the second sub-chunk, which applies d0 d1 of a lazily carried
-  // chunk.  The first sub-chunk of a chunk multiplies only when it is not carried lazily (dec != 1.f, the scalar wave's mark: heads that
-  // decay by more than 2^-60 in 32 tokens), in one block in front of its MFMAs.)
-  auto phase2 = [&](auto mul_tag, const FragC& f, int jj, uint32_t so, FragR& nr, int nkb, int njj) {
-    constexpr bool MUL = decltype(mul_tag)::value;
+  // (the decay multiply of the state slice: only when the basis of the carried state moves -- dec != 1.f, the scalar wave's mark -- in one
+  // block in front of the MFMAs of the state update)
+  auto phase2 = [&](const FragC& f, int jj, uint32_t so, FragR& nr, int nkb, int njj) OMK_ALWAYS_INLINE_LAMBDA {
     f32x4 accB0[2], accB1[2];
 #pragma unroll
     for (int cg = 0; cg < 2; cg++) {
@@ -535,10 +608,7 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     }
 #pragma unroll
     for (int cg = 0; cg < 2; cg++) accB1[cg] = mfma16x16x32_bf16(f.u01[cg], as_s16x8(f.ml), accB1[cg]);   // (not right behind the MFMA it accumulates on)
-    if (MUL) {
-#pragma unroll
-      for (int cg = 0; cg < 2; cg++) accS[cg][0] = accS[cg][0] * f.dec;
-    } else if (uniform_i((int)__builtin_bit_cast(uint32_t, f.dec)) != 0x3f800000) {
+    if (uniform_i((int)__builtin_bit_cast(uint32_t, f.dec)) != 0x3f800000) {
 #pragma unroll
       for (int cg = 0; cg < 2; cg++)
 #pragma unroll
@@ -560,7 +630,6 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
         accS[c1_][t1] = mfma16x16x32_bf16(k1, as_s16x8(ul[c1_]), accS[c1_][t1]);
       }
       if (KHILO && n == 15) accS[1][7] = mfma16x16x32_bf16(kk, as_s16x8(ul[1]), accS[1][7]);
-      if (MUL && n + 2 < 16) accS[(n + 2) & 1][(n + 2) >> 1] = accS[(n + 2) & 1][(n + 2) >> 1] * f.dec;
       if (n == 4) out_rows(accA0[0] * f.rl0 + accB0[0], accA0[1] * f.rl0 + accB0[1], jj, 0, so);
       if (n == 8) out_rows(accA1[0] * f.rl1 + accB1[0], accA1[1] * f.rl1 + accB1[1], jj, 1, so);
       if (n == 10) load_rows(nr, nkb, njj, 0);
@@ -575,7 +644,8 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   load_rows(fr, 0, 0, 1);
   int kb0 = 0, kb1 = 1, kb2 = 2;
   PT8_START();
-  for (int c = c0; c < c1; c++) {
+  // one chunk; ps: the register set that holds the U tile of chunk c + 1 (committed here, refilled with chunk c + 1 + USET)
+  auto citer = [&](auto ps, int c) OMK_ALWAYS_INLINE_LAMBDA {
     const int ub0 = (c - c0) & 1;
     const uint32_t so = 2u * (uint32_t)(chunk_lo(c) * osl);
     bool dump_here = false;
@@ -588,18 +658,26 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     if (!(OMK_A8_VAR & 1024)) {   // (ablation 1024: the compute waves only stage and meet the barrier)
     phase1(fr, true, dump_here, dso, fc, kb0, ub0, 0);
     PT8(0);
-    phase2(std::false_type{}, fc, 0, so, fr, kb0, 1);
+    phase2(fc, 0, so, fr, kb0, 1);
     PT8(1);
     phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
     }
-    if (OMK_A8_CU && !(OMK_A8_VAR & 64)) commit_u(ub0 ^ 1);                                   // U of chunk c + 1
-    if (OMK_A8_CU && !(OMK_A8_VAR & 128)) prefetch_u(chunk_lo(clipc(c + 2)));
+    if (OMK_A8_CU && !(OMK_A8_VAR & 64)) commit_u(ps, ub0 ^ 1);                                   // U of chunk c + 1
+    if (OMK_A8_CU && !(OMK_A8_VAR & 128)) prefetch_u(ps, chunk_lo(clipc(c + 1 + USET)));
     PT8(2);
     block_sync();   // behind the last request for the buffers of chunk c
     PT8(3);
-    if (!(OMK_A8_VAR & 1024)) phase2(std::true_type{}, fc, 1, so, fr, kb1, 0);
+    if (!(OMK_A8_VAR & 1024)) phase2(fc, 1, so, fr, kb1, 0);
     PT8(4);
     { const int t_ = kb0; kb0 = kb1; kb1 = kb2; kb2 = t_; }
+  };
+  if (USET == 2) {
+    for (int c = c0; c < c1; c += 2) {
+      citer(U0{}, c);
+      if (c + 1 < c1) citer(U1{}, c + 1);
+    }
+  } else {
+    for (int c = c0; c < c1; c++) citer(U0{}, c);
   }
   PT8_END();
   if (a.fin && seg == a.nseg - 1) {
@@ -616,9 +694,9 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   }
 }
 
-// the plain class A scans (one D per head or none, no gate, no pre-gate copy); OMK_SSD_A8=0: ssd_a6.hip takes them
+// the plain class A scans (one D per head or none, no gate, no pre-gate copy); GSF_COLUMN_SLICE: ssd_a6.hip takes them
 bool ssd_a8_applies(const GScan& g) {
-  if (const char* e = getenv("OMK_SSD_A8")) if (e[0] == '0') return false;
+  if (g.flags & GSF_COLUMN_SLICE) return false;
   if (g.mode != GS_Y && g.mode != GS_DX) return false;
   if (g.H % 2 != 0 || (g.H / g.G) % 2 != 0 || g.state_only) return false;
   if (g.Z.p || g.outx || (g.D && g.Dsp != 0)) return false;
@@ -626,26 +704,30 @@ bool ssd_a8_applies(const GScan& g) {
 }
 
 int ssd_a8_launch(const GScan& g, omk_stream stream) {
-  if (getenv("OMK_SSD_TRACE")) fprintf(stderr, "[omk] ssd_a8 mode %d B %d L %d H %d dump %d fin %d seg %d\n", g.mode, g.B, g.L, g.H, g.dump != nullptr, g.fin != nullptr, g.seg != nullptr);
+  if (getenv("OMK_SSD_TRACE")) fprintf(stderr, "[omk] ssd_a8 mode %d B %d L %d H %d dump %d fin %d seg %d flags %d\n", g.mode, g.B, g.L, g.H, g.dump != nullptr, g.fin != nullptr, g.seg != nullptr, g.flags);
   GScan a = g;
   const SegPlan sp = a.seg ? ssd_segments(a.B * a.H, a.L) : SegPlan{1, (a.L + QA8 - 1) / QA8};
   a.nseg = sp.nseg; a.cps = sp.cps;
+  const bool precise = a.mode == GS_Y && (a.flags & GSF_PRECISE);
+  if (precise && a.dump) return fail(OMK_EINVAL, "ssd_a8: a PRECISE forward does not save window states");
   if (a.nseg > 1 && !a.seg_ready) {
     int rc = ssd_mfma_prepare_segments(g, stream);
     if (rc) return rc;
   }
   dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
   const size_t smem = sizeof(SmemA8);
-  const char* khe = getenv("OMK_SSD_KHILO");
-  const bool khilo = a.mode == GS_Y && (khe ? khe[0] == '1' : (a.fin != nullptr));
-#define OMK_A8K(MODE_, DU_, KH_) do { \
-    if (OMK_SET_MAX_DYN_SMEM((ssd_a8_kernel<MODE_, DU_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_a8: cannot raise dynamic LDS to %zu", smem); \
-    OMK_LAUNCH((ssd_a8_kernel<MODE_, DU_, KH_>), grid, block, smem, stream, a); } while (0)
+  // the scaled U operand of the state update as hi + lo whenever the caller keeps the final state (prefill -> decode hand-off,
+  // context-parallel shards) or asks for it (OMK_SSD_KHILO / OMK_SSD_PRECISE)
+  const bool khilo = a.mode == GS_Y && ((a.flags & (GSF_KHILO | GSF_PRECISE)) || a.fin != nullptr);
+#define OMK_A8K(MODE_, DU_, KH_, PR_) do { \
+    if (OMK_SET_MAX_DYN_SMEM((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), smem)) return fail(OMK_ELAUNCH, "ssd_a8: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), grid, block, smem, stream, a); } while (0)
   if (a.mode == GS_Y) {
-    if (a.dump) { if (khilo) OMK_A8K(GS_Y, true, true); else OMK_A8K(GS_Y, true, false); }
-    else { if (khilo) OMK_A8K(GS_Y, false, true); else OMK_A8K(GS_Y, false, false); }
+    if (precise) OMK_A8K(GS_Y, false, true, true);
+    else if (a.dump) { if (khilo) OMK_A8K(GS_Y, true, true, false); else OMK_A8K(GS_Y, true, false, false); }
+    else { if (khilo) OMK_A8K(GS_Y, false, true, false); else OMK_A8K(GS_Y, false, false, false); }
   } else {
-    if (a.dump) OMK_A8K(GS_DX, true, false); else OMK_A8K(GS_DX, false, false);
+    if (a.dump) OMK_A8K(GS_DX, true, false, false); else OMK_A8K(GS_DX, false, false, false);
   }
 #undef OMK_A8K
   return OMK_OK;

@@ -25,7 +25,7 @@ namespace omk {
 
 constexpr int QC = 64;     // chunk length (tokens)
 #ifndef OMK_SSD_KHILO_DEFAULT
-#define OMK_SSD_KHILO_DEFAULT 0   // decided by measurement (profiles/r03_khilo.txt); OMK_SSD_KHILO=0/1 overrides at run time
+#define OMK_SSD_KHILO_DEFAULT 0   // decided by measurement (profiles/r03_khilo.txt); OmkSsdFwd::flags & OMK_SSD_KHILO asks for it per call
 #endif
 #ifndef OMK_SSD_BWD_HILO
 #define OMK_SSD_BWD_HILO 0   // 1: the dx scan also splits M into bf16 hi + lo (the forward and the dB / dC scans always do)
@@ -981,8 +981,7 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
   // the state pass does not depend on the mode (no output); it reads U, K, dt' and the scan direction only.  When the caller keeps the
   // final state (prefill -> decode hand-off, context-parallel shards) the segment states carry the hi + lo operand like the scan proper
   // does then: a kept final state of a SPLIT sequence (B = 1 prefill) is exact to fp32 accumulation too, not 1e-3 off.
-  const char* khe = getenv("OMK_SSD_KHILO");
-  const bool khilo = g.mode == GS_Y && (khe ? khe[0] == '1' : (g.fin != nullptr));
+  const bool khilo = g.mode == GS_Y && ((g.flags & (GSF_KHILO | GSF_PRECISE)) || g.fin != nullptr);
   if (khilo) {
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
     OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false, true>), sgrid, block, smem, stream, a);
@@ -1066,8 +1065,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
 #define OMK_A3K(MODE_, EX_, ST_, DF_, KH_, GRID_) do { \
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), GRID_, block, smem, stream, a); } while (0)
-  const char* khe = getenv("OMK_SSD_KHILO");
-  const bool khilo = khe ? khe[0] == '1' : OMK_SSD_KHILO_DEFAULT != 0;
+  const bool khilo = (g.flags & (GSF_KHILO | GSF_PRECISE)) || OMK_SSD_KHILO_DEFAULT != 0;
 #define OMK_A3(MODE_, EX_, ST_, DF_, GRID_) do { \
     if (MODE_ == GS_Y && khilo) OMK_A3K(MODE_, EX_, ST_, DF_, (MODE_ == GS_Y), GRID_); else OMK_A3K(MODE_, EX_, ST_, DF_, false, GRID_); } while (0)
   if (a.nseg > 1 && !a.seg_ready) {

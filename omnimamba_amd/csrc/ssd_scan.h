@@ -16,6 +16,14 @@
 namespace omk {
 
 enum { GS_Y = 0, GS_DC = 1, GS_DX = 2, GS_DB = 3 };
+// GScan::flags (the OMK_SSD_* bits of OmkSsdFwd::flags / OmkSsdBwd::flags, include/omk.h, reach the kernels through these)
+enum {
+  GSF_PRECISE = 1,    // class A forward: the carried state meets Q as bf16 hi + lo and the state-update operand is hi + lo (bare 1e-3 on every head)
+  GSF_KHILO = 2,      // class A forward: the state-update operand as hi + lo even when no final state is kept
+  GSF_FLUSH = 4,      // ssd_a8: move the basis of the carried state to the chunk end at every chunk (the arithmetic of ssd_a6.hip, bit for bit)
+  GSF_NO_SPLIT = 8,   // never split the sequence into segments
+  GSF_COLUMN_SLICE = 16,   // class A scans on ssd_a6.hip (eight identical waves) instead of ssd_a8.hip
+};
 
 struct Src {            // element (b, t, hh, i) at p[b*sb + t*sl + hh*sh + i]; hh = group index when per_group
   const void* p;
@@ -56,6 +64,7 @@ struct GScan {
   // BEFORE token 128 w; reverse: the adjoint state at the first token BEHIND window w (dfinal_states for the last one) -- as
   // the raw 16 KB LDS image [u][k] (kx3 swizzle, ssd_tiles.h) the kernel publishes for its own Q . S product.
   uint16_t* dump; int dump_nw;
+  int flags;                                                     // GSF_* bits
   int state_only;                                                // class A (MFMA): no output, only the state pass from the initial state to `fin` (context-parallel shards)
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results

@@ -343,12 +343,8 @@ __global__ __launch_bounds__(256, OCC) void ssd_mfma_a6_kernel(GScan a) {
   }
 }
 
-static bool ssd_precise() {
-  const char* e = getenv("OMK_SSD_PRECISE");
-  return e && e[0] == '1';
-}
 bool ssd_v6_applies(const GScan& g) {
-  if (!(ssd_precise() && g.mode == GS_Y)) return false;
+  if (!((g.flags & GSF_PRECISE) && g.mode == GS_Y) || ssd_a8_applies(g)) return false;   // (the plain scans: PRECISE instantiation of ssd_a8.hip)
   if (g.Z.p || g.outx || g.prof) return false;                   // gate / pre-gate copy stay on a3
   if (g.seg && ssd_segments(g.B * g.H, g.L).nseg > 1) return false;   // so do split sequences
   return true;

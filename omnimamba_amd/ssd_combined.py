@@ -28,6 +28,35 @@ def _last_contig(t):
     return t if t is None or t.stride(-1) == 1 else t.contiguous()
 
 
+# ---- per-call options of the scan (OmkSsdFwd.flags / OmkSsdBwd.flags, include/omk.h).  The library reads no environment variable that
+# changes the scan's numerics; a caller picks them per call -- `flags=` on the raw functions, or this context on everything below it
+# (the autograd nodes record the flags of their forward for their backward).
+import contextlib
+import threading
+
+_scan_opts = threading.local()
+
+
+def current_scan_flags() -> int:
+    return getattr(_scan_opts, "flags", 0)
+
+
+@contextlib.contextmanager
+def scan_options(precise=False, khilo=False, every_chunk=False, no_split=False, column_slice=False, sequential_bwd=False):
+    """precise: hi + lo copy of the carried state and of the state-update operand -- the bare 1e-3 of the fp32 recurrence on every
+    head (price: profiles/r06_precise.txt); khilo: only the state-update operand; every_chunk / column_slice / sequential_bwd /
+    no_split: the older kernels and arithmetic orders the tests compare against."""
+    f = ((K.SSD_PRECISE if precise else 0) | (K.SSD_KHILO if khilo else 0) | (K.SSD_EVERY_CHUNK if every_chunk else 0)
+         | (K.SSD_NO_SPLIT if no_split else 0) | (K.SSD_COLUMN_SLICE if column_slice else 0)
+         | (K.SSD_SEQUENTIAL_BWD if sequential_bwd else 0))
+    prev = current_scan_flags()
+    _scan_opts.flags = prev | f
+    try:
+        yield
+    finally:
+        _scan_opts.flags = prev
+
+
 def save_window_states_enabled() -> bool:
     """OMK_SSD_SAVE_WINDOW_STATES=0: a training forward does not keep its window states (16 KB per head and 128 tokens); the
     backward then recomputes them with a state pass over x, as upstream's backward recomputes its chunk states."""
@@ -36,7 +65,7 @@ def save_window_states_enabled() -> bool:
 
 def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=None, dt_softplus=False,
                  dt_limit=(0.0, _INF), return_final_states=False, want_out_x=False, chunk_size=256,
-                 force_generic=False, save_window_states=False):
+                 force_generic=False, save_window_states=False, flags=None):
     """Raw (non-autograd) forward: returns (out, out_x | None, final_states | None), with save_window_states=True a fourth
     element: the opaque window-state tensor omk_ssd_scan_bwd takes (None when this forward cannot produce it)."""
     lib = get_lib()
@@ -59,7 +88,8 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
         p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(B), Cm=K.T(C), D=K.T(D), z=K.T(z), dt_bias=K.T(dt_bias),
                      initial_states=K.T(initial_states), out=K.T(out), out_x=K.T(out_x), final_states=K.T(fin),
                      dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]), dt_softplus=int(dt_softplus),
-                     chunk_size=int(chunk_size), force_generic=int(force_generic))
+                     chunk_size=int(chunk_size), force_generic=int(force_generic),
+                     flags=int(current_scan_flags() if flags is None else flags) & ~K.SSD_SEQUENTIAL_BWD)
         ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
         if save_window_states:
             nbytes = lib.omk_ssd_scan_fwd_window_states_bytes(K.C.byref(p))
@@ -77,7 +107,7 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
 
 def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
                  dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None,
-                 dx_out=None, dB_out=None, dC_out=None, window_states=None):
+                 dx_out=None, dB_out=None, dC_out=None, window_states=None, flags=None):
     """Raw backward: returns dict(dx, ddt, dA, dB, dC, dD, ddt_bias, dinitial_states).  `y` = the forward's pre-gate
     output (D*x included); with it the MFMA path applies."""
     lib = get_lib()
@@ -111,7 +141,8 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
                      initial_states=K.T(initial_states), y=K.T(y), dout=K.T(dout), dfinal_states=K.T(dfinal_states), dx=K.T(dx),
                      ddt=K.T(ddt), dA=K.T(dA), dB=K.T(dB), dC=K.T(dC), dD=K.T(dD), ddt_bias=K.T(ddtb),
                      dinitial_states=K.T(dinit), window_states=K.T(window_states), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
-                     dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic))
+                     dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=int(force_generic),
+                     flags=int(current_scan_flags() if flags is None else flags) & (K.SSD_EVERY_CHUNK | K.SSD_NO_SPLIT | K.SSD_COLUMN_SLICE | K.SSD_SEQUENTIAL_BWD))
         ws = K.workspace(lib, "omk_ssd_scan_bwd_workspace_bytes", p, x)  # noqa: F841
         with _prof.range_("ssd_scan_bwd"):
             K.run(lib, "omk_ssd_scan_bwd", p, x)
@@ -141,7 +172,7 @@ def ssd_final_state_raw(x, dt, A, B, dt_bias=None, initial_states=None, dt_softp
         fin = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=x.device)
         p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A.float().contiguous()), Bm=K.T(B), Cm=K.T(B), dt_bias=K.T(dt_bias),
                      initial_states=K.T(initial_states), final_states=K.T(fin), dt_min=float(dt_limit[0]), dt_max=float(dt_limit[1]),
-                     dt_softplus=int(dt_softplus), chunk_size=256)
+                     dt_softplus=int(dt_softplus), chunk_size=256, flags=int(current_scan_flags()) & ~K.SSD_SEQUENTIAL_BWD)
         ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)  # noqa: F841
         fn = getattr(lib, "omk_ssd_scan_fwd")
         import ctypes as C
@@ -203,6 +234,7 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
                          dt_limit=dt_limit, return_final_states=return_final_states, want_out_x=True, chunk_size=chunk_size,
                          save_window_states=keep_ws)
         (out, out_x, fin), wst = r[:3], (r[3] if keep_ws else None)
+        ctx.scan_flags = current_scan_flags()
         ctx.save_for_backward(x, dt, A, B, C, D, z, dt_bias, initial_states, out_x if z is not None else out, wst)
         ctx.dt_softplus, ctx.dt_limit, ctx.chunk_size = dt_softplus, dt_limit, chunk_size
         ctx.return_final_states = return_final_states
@@ -219,7 +251,8 @@ class MambaChunkScanCombinedFn(torch.autograd.Function):
             dout = (dout.float() * F.silu(zf)).to(x.dtype)
         g = ssd_scan_bwd(dout, x, dt, A, B, C, D=D, dt_bias=dt_bias, initial_states=initial_states,
                          dfinal_states=dfinal, dt_softplus=ctx.dt_softplus, dt_limit=ctx.dt_limit,
-                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None, y=out_x, window_states=wst)
+                         chunk_size=ctx.chunk_size, need_dinit=initial_states is not None, y=out_x, window_states=wst,
+                         flags=ctx.scan_flags)
         dinit = g["dinitial_states"]
         return (g["dx"], g["ddt"].to(dt.dtype), g["dA"].to(A.dtype), g["dB"].to(B.dtype), g["dC"].to(C.dtype), None,
                 None if D is None else g["dD"].to(D.dtype), dz,
@@ -303,6 +336,7 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
                               outproj_bias, initial_states, xBC_c if keep else None,
                               out_n if (keep and use_norm and need_wo) else None, wst)
         ctx.cfg = (H, P, G, N, chunk_size, dt_limit, activation, rmsnorm_eps, norm_before_gate, return_final_states)
+        ctx.scan_flags = current_scan_flags()
         return (out, fin) if return_final_states else out
 
     @staticmethod
@@ -380,7 +414,8 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
                          Cm.unflatten(-1, (G, N)), D=D, dt_bias=dt_bias, initial_states=initial_states,
                          dfinal_states=dfinal, dt_softplus=True, dt_limit=dt_limit, chunk_size=chunk_size,
                          need_dinit=initial_states is not None, y=y_pre, dx_out=dx_v.unflatten(-1, (H, P)),
-                         dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)), window_states=wst)
+                         dB_out=dB_v.unflatten(-1, (G, N)), dC_out=dC_v.unflatten(-1, (G, N)), window_states=wst,
+                         flags=ctx.scan_flags)
         ddt_v.copy_(g["ddt"])
         # ---- conv backward: dx lands in the xBC slice of dzxbcdt
         dw = torch.zeros(conv_w.shape, dtype=torch.float32, device=dev)

@@ -146,10 +146,11 @@ def test_ssd_mfma_fwd(dev, L, H, G, with_z, with_init):
 
 
 def test_ssd_khilo_keeps_the_carried_state_exact(dev, monkeypatch):
-    """OMK_SSD_KHILO=1: the w_l K_l operand of the state update as a bf16 hi + lo pair -- the carried state (and final_states) no
+    """OmkSsdFwd.flags & OMK_SSD_KHILO (scan_options(khilo=True)): the w_l K_l operand of the state update as a bf16 hi + lo pair -- the carried state (and final_states) no
     longer carries one bf16 rounding per chunk: 1.7e-3 -> ~1e-5 (+ 10 % scan time on the MI355X, hence opt-in)."""
-    monkeypatch.setenv("OMK_SSD_KHILO", "1")
-    out, _, fin, _, _, o0, f0, o32 = _mfma_case(dev, 1, 200, 2, 1, False, True, seed=23)
+    import omnimamba_amd.ssd_combined as S
+    with S.scan_options(khilo=True):
+        out, _, fin, _, _, o0, f0, o32 = _mfma_case(dev, 1, 200, 2, 1, False, True, seed=23)
     assert rel(fin, f0) < 1e-4, rel(fin, f0)
     q = rel(o32.bfloat16().float(), o32)
     assert rel(out.float(), o32) < (1.2e-3 ** 2 + q ** 2) ** 0.5
@@ -162,9 +163,10 @@ def test_ssd_mfma_fwd_split_sequence(dev, monkeypatch, L, H, G, with_z, with_ini
     monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))   # production: >= 8 chunks per segment
     torch.manual_seed(21)
     out, out_x, fin, outg, fing, o0, f0, o32 = _mfma_case(dev, 1, L, H, G, with_z, with_init)
-    monkeypatch.setenv("OMK_SSD_NO_SPLIT", "1")
+    import omnimamba_amd.ssd_combined as S
     torch.manual_seed(21)
-    out1, _, fin1, _, _, _, _, _ = _mfma_case(dev, 1, L, H, G, with_z, with_init)
+    with S.scan_options(no_split=True):
+        out1, _, fin1, _, _, _, _, _ = _mfma_case(dev, 1, L, H, G, with_z, with_init)
     torch.manual_seed(21)
     by, bf, up = _budgets(L, H, G, with_z, with_init)
     q = rel(o32.bfloat16().float(), o32)
@@ -213,13 +215,17 @@ def test_ssd_mfma_split_sequence_long_memory(dev, monkeypatch):
 @pytest.mark.parametrize("L,H,G,with_z,with_init,minc", [(130, 2, 1, False, False, None), (70, 4, 2, True, True, None),
                                                                 (200, 2, 1, False, True, 1), (330, 4, 2, False, True, 2),
                                                                 (300, 8, 1, False, True, None)])
-def test_ssd_mfma_bwd(dev, monkeypatch, L, H, G, with_z, with_init, minc, cp):
+def test_ssd_mfma_bwd(dev, monkeypatch, request, L, H, G, with_z, with_init, minc, cp):
     """bf16 MFMA backward vs autograd of the fp64 oracle on identical bf16 inputs, both forms: cp = 1 the chunk-parallel backward
     of round 3 (dx scan + state-only forward pass dump the window states, ssd_cp.hip forms dB / dC / token scalars / dD per
     128-token window with the head sum on chip; the 8-head case splits the heads of the group over two workgroups), cp = 0 the
     three sequential scans of rounds 1 / 2 (still the path for D per (head, column)).  minc: split the sequence of the class A
     scans into segments of that many chunks (see test_ssd_mfma_fwd_split_sequence)."""
-    monkeypatch.setenv("OMK_SSD_BWD_CP", cp)
+    import contextlib
+    import omnimamba_amd.ssd_combined as S
+    es = contextlib.ExitStack()
+    es.enter_context(S.scan_options(sequential_bwd=(cp == "0")))
+    request.addfinalizer(es.close)
     if minc:
         monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
     import omnimamba_amd.ssd_combined as S
@@ -265,7 +271,6 @@ def test_ssd_bwd_with_window_states_saved_by_the_forward(dev, monkeypatch, L, H,
     that receives it skips its own state pass over x.  Same images from the same code: the gradients are IDENTICAL to the ones of
     the recomputing backward (OMK_SSD_SAVE_WINDOW_STATES=0), the forward output identical to the forward without the dumps, and a
     forward that cannot save them (gate requested) reports 0 bytes."""
-    monkeypatch.setenv("OMK_SSD_BWD_CP", "1")   # the path that reads window states (and is deterministic: exact comparison below)
     if minc:
         monkeypatch.setenv("OMK_SSD_SEG_CHUNKS", str(minc))
     import omnimamba_amd.ssd_combined as S
@@ -277,18 +282,33 @@ def test_ssd_bwd_with_window_states_saved_by_the_forward(dev, monkeypatch, L, H,
     src = [x, dt, A, Bm, Cm, D, dtb, init]
     gy = torch.randn(1, L, H, P, generator=torch.Generator().manual_seed(4)).bfloat16()
     grads, outs = {}, {}
-    for mode in ("1", "0"):
+    def run(mode):
         monkeypatch.setenv("OMK_SSD_SAVE_WINDOW_STATES", mode)
         leaves = [None if t is None else t.clone().to(dev).requires_grad_() for t in src]
         xr, dtr, Ar, Br, Cr, Dr, dtbr, ir = leaves
         y = S.mamba_chunk_scan_combined(xr, dtr, Ar, Br, Cr, 256, D=Dr, dt_bias=dtbr, initial_states=ir, dt_softplus=True)
         y.backward(gy.to(dev))
-        grads[mode] = [None if t is None else t.grad.detach().cpu() for t in leaves]
-        outs[mode] = y.detach().cpu()
+        return [None if t is None else t.grad.detach().cpu() for t in leaves], y.detach().cpu()
+    # bit for bit with the basis of the carried state moved at every chunk (the state pass of the recomputing backward is the column-slice
+    # kernel, which does): identical images, identical gradients
+    with S.scan_options(every_chunk=True):
+        for mode in ("1", "0"):
+            grads[mode], outs[mode] = run(mode)
     assert torch.equal(outs["1"], outs["0"])
     for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "dt_bias", "init"], grads["1"], grads["0"]):
         if a is not None:
             assert torch.equal(a, b), n
+    # the default (lazy basis, round 6): the forward that dumps pulls the basis up in front of every image, the plain one only where it
+    # drifts -- equal to a rounding of the fp32 state, not to the bit
+    for mode in ("1", "0"):
+        grads["d" + mode], outs["d" + mode] = run(mode)
+    # (the bf16 copy of the state that meets C is the rounding of S 2^-drift instead of S: another draw of the same 2^-9 rounding error,
+    # so the two outputs differ by about sqrt(2) x the arithmetic error of either -- test_ssd_lazy_basis_of_the_carried_state compares both
+    # with the fp64 recurrence)
+    assert rel(outs["d1"].float(), outs["1"].float()) < 2.5e-3 and rel(outs["d0"].float(), outs["1"].float()) < 2.5e-3
+    for n, a, b in zip(["x", "dt", "A", "B", "C", "D", "dt_bias", "init"], grads["d1"], grads["1"]):
+        if a is not None:
+            assert rel(a.float(), b.float()) < (6e-3 if n in ("A", "dt_bias", "dt") else 3e-3), (n, rel(a.float(), b.float()))
     # the raw call: the window-state tensor exists for the plain scan and not when a gate is asked for
     d = lambda t: None if t is None else t.to(dev)
     r = S.ssd_scan_fwd(d(x), d(dt), d(A), d(Bm), d(Cm), D=d(D), dt_bias=d(dtb), dt_softplus=True, save_window_states=True)
@@ -299,14 +319,15 @@ def test_ssd_bwd_with_window_states_saved_by_the_forward(dev, monkeypatch, L, H,
 
 @pytest.mark.parametrize("L,H,G", [(200, 2, 1), (330, 4, 2)])
 def test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states(dev, monkeypatch, L, H, G):
-    """OMK_SSD_PRECISE=1 (ssd_v6.hip, PRECISE): the bf16 copy of the carried state and the w_l K_l operand of the state update
+    """OmkSsdFwd.flags & OMK_SSD_PRECISE (scan_options(precise=True); the PRECISE instantiation of ssd_a8.hip): the bf16 copy of the carried state and the w_l K_l operand of the state update
     as hi + lo pairs.  From an O(1) random initial state -- the stress case where the default path (and upstream's kernels, which
     round the same two operands to bf16) needs a 1.5e-3 budget for y and 2.5e-3 for the final state -- y stays inside the
     north-star 1e-3 (on top of the output's own bf16 quantisation) and the final state inside 1e-3 of the fp32 recurrence."""
+    import omnimamba_amd.ssd_combined as S
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("OMK_SSD_PRECISE", mode)
-        out, _, fin, _, _, o0, f0, o32 = _mfma_case(dev, 1, L, H, G, False, True, seed=21)
+        with S.scan_options(precise=(mode == "1")):
+            out, _, fin, _, _, o0, f0, o32 = _mfma_case(dev, 1, L, H, G, False, True, seed=21)
         q = rel(o32.bfloat16().float(), o32)
         e = rel(out.float(), o32)
         res[mode] = (max(e * e - q * q, 0.0) ** 0.5, rel(fin, f0))       # arithmetic part of the error of y, error of the final state
@@ -396,10 +417,58 @@ def test_ssd_column_slice_kernel_extreme_decays_take_the_exponent_path(dev):
         assert rel(leaves[0].grad[:, :, h].float().cpu(), ref[0].grad[:, :, h]) < 8e-3, h
 
 
+@pytest.mark.parametrize("regime", ["slow", "mixed", "fast", "extreme"])
+def test_ssd_lazy_basis_of_the_carried_state(dev, regime):
+    """Round 6: ssd_a8.hip moves the basis of the carried state (the decay multiply of its 64 accumulator registers) only where the
+    basis drifts by 2^60, where an image or the final state needs the true state, never otherwise.  Against the every-chunk arithmetic
+    (OMK_SSD_EVERY_CHUNK, bit-equal to ssd_a6.hip) the result must agree to a rounding of the fp32 state -- across decay regimes: slow
+    heads (the basis never moves before the last chunk), heads that cross the 2^-60 drift every few chunks, heads whose every 32-token
+    sub-chunk decays by more than 2^-60, and both in one group; forward with and without final state, the training forward (images), the
+    dx scan of the backward; and against the fp64 recurrence directly."""
+    import omnimamba_amd.ssd_combined as S
+    L, H, P, N, G = 650, 4, 64, 128, 1
+    x, dt, A, Bm, Cm, D, z, dtb, init = make(1, L, H, P, N, G, torch.bfloat16, seed=31)
+    if regime == "slow":
+        A, dtb = -torch.tensor([1.0, 1.5, 2.0, 1.2]), torch.full((H,), -6.0)          # ~0.005 per token: 2^-0.3 per chunk
+    elif regime == "mixed":
+        A, dtb = -torch.tensor([1.0, 16.0, 6.0, 11.0]), torch.tensor([-6.0, -1.0, -2.5, -2.0])   # 2^-0.3 .. 2^-400 per chunk
+    elif regime == "fast":
+        A, dtb = -torch.tensor([16.0, 12.0, 14.0, 9.0]), torch.full((H,), 0.5)        # 2^-70 .. 2^-130 per 32 tokens
+    else:
+        A, dtb = -torch.tensor([16.0, 1.0, 16.0, 3.0]), torch.tensor([3.0, -7.0, 2.0, -1.0])     # 2^-2000 per sub-chunk next to 2^-0.1 per chunk
+    d = lambda t: t.to(dev)
+
+    def run(keep_final, train):
+        leaves = [t.clone().to(dev).requires_grad_(train) for t in (x, dt, A, Bm, Cm, D, dtb, init)]
+        r = S.mamba_chunk_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 256, D=leaves[5], dt_bias=leaves[6],
+                                        initial_states=leaves[7], dt_softplus=True, return_final_states=keep_final)
+        y, fin = r if keep_final else (r, None)
+        g = []
+        if train:
+            y.backward(torch.ones_like(y))
+            g = [t.grad.float().cpu() for t in leaves]
+        return [y.detach().float().cpu(), None if fin is None else fin.detach().cpu()] + g
+
+    y64, f64 = O.ssd_ref_chunked(x, dt, A, Bm, Cm, 64, D=D, dt_bias=dtb, initial_states=init, dt_softplus=True, return_final_states=True,
+                                 round_output=False, compute_dtype=torch.float64)
+    for keep_final, train in ((True, False), (False, False), (False, True)):
+        with S.scan_options(every_chunk=True):
+            ref = run(keep_final, train)
+        got = run(keep_final, train)
+        # y: the bf16 copy of the state that meets C is the rounding of S 2^-drift instead of S -- another draw of the same 2^-9 rounding
+        # error, so the two outputs differ by about sqrt(2) x the arithmetic error of either; against the exact result neither is worse
+        assert rel(got[0], ref[0]) < 2.5e-3, (regime, keep_final, train, rel(got[0], ref[0]))
+        assert rel(got[0], y64) <= rel(ref[0], y64) * 1.1 + 1e-5, (regime, rel(got[0], y64), rel(ref[0], y64))
+        if keep_final:   # (fp32 accumulators, hi + lo operand: the state itself is exact either way)
+            assert rel(got[1], ref[1]) < 5e-6 and rel(got[1], f64) < 2e-5, (regime, rel(got[1], ref[1]), rel(got[1], f64))
+        for nm, a_, b_ in zip(["dx", "d dt", "dA", "dB", "dC", "dD", "d dt_bias", "d init"], got[2:], ref[2:]):
+            assert rel(a_, b_) < (6e-3 if nm in ("dA", "d dt_bias", "d dt") else 3e-3), (regime, nm, rel(a_, b_))
+
+
 @pytest.mark.parametrize("L,minc", [(200, None), (330, 2), (64, None), (97, None)])
 def test_ssd_specialised_wave_kernel_matches_the_column_slice_kernel_bitwise(dev, monkeypatch, L, minc):
     """ssd_a8.hip (four compute waves of 32 state columns + four helper waves per head pair) is the column-slice scan of ssd_a6.hip with
-    another work split and instruction order and the SAME arithmetic: output, final state (hi + lo operand), and the gradients of a
+    another work split and instruction order and -- with OMK_SSD_EVERY_CHUNK -- the SAME arithmetic: output, final state (hi + lo operand), and the gradients of a
     backward that runs its dx scan and its window-state images through it must equal ssd_a6.hip's bit for bit -- unsplit and split
     sequences (minc: chunks per segment), a ragged last chunk, a single chunk."""
     import omnimamba_amd.ssd_combined as S
@@ -418,10 +487,10 @@ def test_ssd_specialised_wave_kernel_matches_the_column_slice_kernel_bitwise(dev
 
     names = ["y", "final state", "dx", "d dt", "dA", "dB", "dC", "dD", "d dt_bias", "d initial_states"]
     for keep_final in (True, False):
-        monkeypatch.setenv("OMK_SSD_A8", "0")
-        ref = run(keep_final)
-        monkeypatch.setenv("OMK_SSD_A8", "1")
-        got = run(keep_final)
+        with S.scan_options(column_slice=True):
+            ref = run(keep_final)
+        with S.scan_options(every_chunk=True):    # (the default moves the basis of the carried state lazily: next test)
+            got = run(keep_final)
         for nm, r, g_ in zip(names, ref, got):
             if r is None:
                 continue

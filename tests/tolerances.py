@@ -13,8 +13,19 @@ reference" is not a fixed distance from the exact answer.  The rule the tests ap
     arith(ours vs fp64)  <=  max(ARITH_BUDGET, 1.05 * arith(upstream-rounding oracle at the reference's chunk size 256 vs fp64))
 
 i.e. inside the north-star budget wherever the reference pipeline itself is, and never further from the exact result than
-the reference pipeline where its own rounding points exceed the budget.  OMK_SSD_PRECISE=1 meets the bare 1e-3 everywhere
-(tests/test_ops_ssd.py::test_ssd_precise_forward_meets_the_1e3_budget_with_initial_states)."""
+the reference pipeline where its own rounding points exceed the budget.
+
+Two more rules live here and nowhere else (round 6):
+
+  * PRECISE (OmkSsdFwd.flags & OMK_SSD_PRECISE, ssd_combined.scan_options(precise=True)): the BARE 1e-3 on every head -- no
+    reference-relative term.  tests/test_configs_gpu.py asserts it on all ten slices of the production shape, slow heads included.
+  * the TRAINING instantiation of the default kernel (no final state kept, window-state images saved: what Stage2Step and
+    bench.py launch) enters the scaled operand of the state update as ONE bf16 value, like the reference pipeline's chunk-state
+    kernel, where the keep-final instantiation uses hi + lo.  It therefore rounds at exactly the reference's two points (that
+    operand, and the state that meets C) and ties with it on state-dominated heads: measured 0.94 .. 1.13 x the upstream-rounding
+    oracle's own error on heads with A dt0 < 0.01, 0.2 .. 0.6 x elsewhere.  A tie cannot be asserted at 1.05 x of a quantity that
+    is itself one draw of a rounding error, so its bound is TRAIN_FACTOR = 1.15 x; callers who need more take KHILO (+ 15 %) or
+    PRECISE (+ 37 %) per call (profiles/r06_precise.txt)."""
 import math
 
 import torch
@@ -23,6 +34,12 @@ import oracle as O
 
 Q_BF16 = 1.65e-3
 ARITH_BUDGET = 1e-3
+TRAIN_FACTOR = 1.15
+
+
+def training_budget(upstream_arith):
+    """y arithmetic bound of the training instantiation (module docstring)."""
+    return max(ARITH_BUDGET, TRAIN_FACTOR * upstream_arith)
 
 
 def rel(a, b):

@@ -22,7 +22,7 @@ for (B, L) in [tuple(int(v) for v in t.split('x')) for t in os.environ.get('AB_S
     x = xBC[..., :H * P].view(B, L, H, P); Bm = xBC[..., H * P:H * P + G * N].view(B, L, G, N); Cm = xBC[..., H * P + G * N:].view(B, L, G, N)
     dt = (torch.randn(B, L, H, device=dev) * 0.5).bfloat16(); A = -(torch.rand(H, device=dev) * 15 + 1); D = torch.ones(H, device=dev)
     dtb = torch.randn(H, device=dev) * 0.5 - 3
-    ms = min(timeit(lambda: ssd_scan_fwd(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True), 20, 5) for _ in range(3))
+    ms = min(timeit(lambda: ssd_scan_fwd(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True, flags=int(os.environ.get('AB_FLAGS', '0'))), 20, 5) for _ in range(3))
     out.append(f"B{B} L{L} {ms*1e3:7.1f} us")
 print(f"{os.environ.get('AB_TAG'):12s}: " + "   ".join(out), flush=True)
 ''' % ROOT

@@ -22,9 +22,9 @@ x = xBC[..., :H * P].view(B, L, H, P); Bm = xBC[..., H * P:H * P + G * N].view(B
 dt = (torch.randn(B, L, H, device=dev) * 0.5).bfloat16(); A = -(torch.rand(H, device=dev) * 15 + 1); D = torch.ones(H, device=dev)
 dtb = torch.randn(H, device=dev) * 0.5 - 3
 dout = torch.randn(B, L, H, P, device=dev).bfloat16()
-f = lambda: ssd_scan_fwd(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True, save_window_states=True)
+f = lambda: ssd_scan_fwd(x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True, save_window_states=True, flags=int(os.environ.get('AB_FLAGS', '0')))
 r = f()
-b = lambda: ssd_scan_bwd(dout, x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True, window_states=r[3])
+b = lambda: ssd_scan_bwd(dout, x, dt, A, Bm, Cm, D=D, dt_bias=dtb, dt_softplus=True, window_states=r[3], flags=int(os.environ.get('AB_FLAGS', '0')))
 mf = min(timeit(f, 20, 5) for _ in range(3)); mb = min(timeit(b, 10, 3) for _ in range(3))
 print(f"{os.environ.get('AB_TAG'):12s}: training fwd {mf*1e3:7.1f} us   bwd {mb*1e3:7.1f} us", flush=True)
 ''' % ROOT

@@ -2,7 +2,6 @@
 compute waves 0..3 and helper waves 4..7 of workgroup 0.   usage: python tools/with_lib.py <prof lib> tools/phase_prof_a8.py"""
 import os, sys
 os.environ["OMK_PROF"] = "1"
-os.environ["OMK_SSD_NO_SPLIT"] = "1"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnimamba_amd import _capi as K
@@ -19,7 +18,7 @@ dtb = torch.randn(H, device=dev) * 0.5 - 3
 lib = get_lib()
 out = torch.empty(B, L, H, P, dtype=x.dtype, device=dev)
 p = K.SsdFwd(x=K.T(x), dt=K.T(dt), A=K.T(A), Bm=K.T(Bm), Cm=K.T(Cm), D=K.T(D), z=K.T(None), dt_bias=K.T(dtb), initial_states=K.T(None), out=K.T(out),
-             out_x=K.T(None), final_states=K.T(None), dt_min=0.0, dt_max=float("inf"), dt_softplus=1, chunk_size=256, force_generic=0)
+             out_x=K.T(None), final_states=K.T(None), dt_min=0.0, dt_max=float("inf"), dt_softplus=1, chunk_size=256, force_generic=0, flags=K.SSD_NO_SPLIT | int(os.environ.get("AB_FLAGS", "0")))
 ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, x)
 for _ in range(2):
     K.run(lib, "omk_ssd_scan_fwd", p, x)
