@@ -546,10 +546,20 @@ def main():
         # HBM bytes per launch from the PMC passes of the same kernels at this shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot be read inside this process
         traffic = {}
+        from omnimamba_amd.ssd_combined import save_window_states_enabled
+        save_ws = save_window_states_enabled()
+        # the kernels the timed launches really were (omk_ssd_last_kernels): a PMC file recorded for OTHER kernels is refused -- traffic and
+        # mfma_busy are then null and traffic_source says why (tests/test_bench_contract.py asserts the match)
+        ran = _prof.kernels()
+        ids = {"fwd": ran.get("ssd_scan_fwd"), "bwd": ran.get("ssd_scan_bwd")}
         for key, fn in (("fwd", "ssd_fwd_traffic.json"), ("bwd", "ssd_bwd_traffic.json")):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     tj = json.load(fh)
+                    want = tj["with_window_states"]["kernel_ids"] if (key == "fwd" and save_ws and "with_window_states" in tj) else tj["kernel_ids"]
+                    if ids[key] is not None and want != ids[key]:
+                        traffic[key] = (None, f"STALE: profiles/{fn} was recorded for [{want}], this run launched [{ids[key]}] -- re-run tools/pmc_r06.sh + tools/make_traffic_json.py")
+                        continue
                     traffic[key] = (int(tj["traffic_bytes_per_launch"]), tj.get("source"))
                     traffic[key + "_mfma"] = tj.get("mfma_busy")
                     if key == "fwd" and "with_window_states" in tj:
@@ -557,8 +567,6 @@ def main():
                         traffic["fwd_ws_mfma"] = tj["with_window_states"].get("mfma_busy")
             except (OSError, KeyError, ValueError):
                 traffic[key] = (None, None)
-        from omnimamba_amd.ssd_combined import save_window_states_enabled
-        save_ws = save_window_states_enabled()
         out = {
             "metric": "selective-scan M-elements/sec", "value": round(value, 1), "unit": "M-elements/s",
             "n_gpus": world, "steps": nsteps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -578,11 +586,13 @@ def main():
                          # share of the SIMD-cycles of the launch the matrix pipe is busy (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),
                          # from the same PMC passes as `traffic`: = the share of the dense bf16 MFMA peak at the clock the kernel runs at)
                          "mfma_busy": (traffic.get("fwd_ws_mfma") if save_ws else traffic.get("fwd_mfma")),
+                         "kernel_ids": ids["fwd"],
                          "algorithmic_bytes_per_launch": fwd_bytes, "launch_ms": round(ms_f, 4), "launches_timed": n_f},
             "roofline_bwd": {"bound": "hbm", "kernel": "omk_ssd_scan_bwd (dt prep + " + ("" if save_ws else "state-only forward pass + ") + "dx scan with window-state dumps + ssd_cp_kernel + folds + finish" + (
                                  "; forward window states saved by the training forward)" if save_ws else ")"),
                              "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
                              "traffic": traffic["bwd"][0], "traffic_source": traffic["bwd"][1], "mfma_busy": traffic.get("bwd_mfma"),
+                             "kernel_ids": ids["bwd"],
                              "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": round(ms_b, 4), "launches_timed": n_b},
             "tokens_per_s": round(world * tok / (elapsed / nsteps), 1),
         }

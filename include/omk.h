@@ -310,6 +310,10 @@ typedef struct {
                                  * drifts by 2^60 (the arithmetic of the column-slice kernel, bit for bit; tests) */
 #define OMK_SSD_NO_SPLIT     8  /* never cut the sequence into segments (few (batch, head) sequences normally are: csrc/ssd_scan.h) */
 #define OMK_SSD_COLUMN_SLICE 16 /* class A scans on the column-slice kernel (ssd_a6.hip) instead of the specialised-wave kernel */
+/* Measurement aid (ABI 6): the scan kernels the LAST omk_ssd_scan_fwd / omk_ssd_scan_bwd call of this thread launched, ';'-separated,
+ * template arguments included, e.g. "ssd_dt_prep;ssd_a8<mode=0,dump=1,khilo=0,precise=0>".  bench.py puts it next to its HIP-event
+ * time and refuses a PMC traffic file (profiles/ssd_*_traffic.json) recorded for another kernel. */
+const char* omk_ssd_last_kernels(void);
 size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p);
 /* bytes of window_states for these arguments (window_states itself is not looked at); 0 = this forward cannot save them (shape
  * outside the MFMA kernel, gate / out_x requested, fp32 activations): pass none */

@@ -94,7 +94,7 @@ STRUCTS = {s.__name__: s for s in (Sample, CrossEntropy, OmkTensor, AddNormFwd, 
 
 # every symbol include/omk.h declares
 SYMBOLS = [
-    "omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof",
+    "omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof", "omk_ssd_last_kernels",
     "omk_add_norm_fwd", "omk_add_norm_bwd_workspace_bytes", "omk_add_norm_bwd",
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
@@ -109,6 +109,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     """Declare prototypes on a freshly dlopen'ed library and check ABI version + struct sizes."""
     lib.omk_abi_version.restype = C.c_int
     lib.omk_last_error.restype = C.c_char_p
+    lib.omk_ssd_last_kernels.restype = C.c_char_p
     lib.omk_is_emulated.restype = C.c_int
     lib.omk_sizeof.restype = C.c_size_t
     lib.omk_sizeof.argtypes = [C.c_char_p]
@@ -123,7 +124,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
         elif s == "omk_lora_up_bwd_parts":
             fn.restype = C.c_int
             fn.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
-        elif s not in ("omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof"):
+        elif s not in ("omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof", "omk_ssd_last_kernels"):
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_void_p]
     if lib.omk_abi_version() != OMK_ABI_VERSION:

@@ -8,6 +8,20 @@ import torch
 
 ENABLED = False
 _RANGES = {}
+_KERNELS = {}
+
+
+def note_kernels(name: str, lib):
+    """Which kernels the call timed under `name` launched (omk_ssd_last_kernels of the calling thread), last value kept."""
+    if ENABLED:
+        try:
+            _KERNELS[name] = lib.omk_ssd_last_kernels().decode()
+        except Exception:      # a foreign library build without the symbol: the bench then reports no kernel id
+            _KERNELS[name] = None
+
+
+def kernels():
+    return dict(_KERNELS)
 
 
 @contextlib.contextmanager
@@ -26,6 +40,7 @@ def range_(name: str):
 
 def reset():
     _RANGES.clear()
+    _KERNELS.clear()
 
 
 def summary():

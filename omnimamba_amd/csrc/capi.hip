@@ -13,6 +13,21 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+char* kern_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+void kernels_reset() { kern_buf()[0] = 0; }
+void kernels_note(const char* fmt, ...) {
+  char* b = kern_buf();
+  size_t n = strlen(b);
+  if (n + 2 >= 512) return;
+  if (n) b[n++] = ';';
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(b + n, 512 - n, fmt, ap);
+  va_end(ap);
+}
 int finish_launch(const char* what) {
 #ifndef OMK_EMU
   hipError_t e = hipGetLastError();
@@ -29,6 +44,7 @@ int finish_launch(const char* what) {
 extern "C" {
 int omk_abi_version(void) { return OMK_ABI_VERSION; }
 const char* omk_last_error(void) { return omk::err_buf(); }
+const char* omk_ssd_last_kernels(void) { return omk::kern_buf(); }
 size_t omk_sizeof(const char* n) {
 #define OMK_SZ(S) if (strcmp(n, #S) == 0) return sizeof(S)
   if (!n) return 0;

@@ -11,6 +11,10 @@ namespace omk {
 // ---- thread-local error text --------------------------------------------------------------------------
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+// which scan kernels the last omk_ssd_scan_fwd / omk_ssd_scan_bwd of this thread launched (omk_ssd_last_kernels: measurement tools tie a
+// profile to the kernel that was timed)
+void kernels_reset();
+void kernels_note(const char* fmt, ...);
 #define OMK_REQUIRE(cond, ...) \
   do { if (!(cond)) return ::omk::fail(OMK_EINVAL, __VA_ARGS__); } while (0)
 

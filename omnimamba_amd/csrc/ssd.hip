@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void ssd_generic_kernel(GScan a, int TK) {
 }
 
 int ssd_generic_launch(const GScan& g, omk_stream stream) {
+  kernels_note("ssd_generic<mode=%d>", g.mode);
   int TK = 1;
   {   // fp32 forward of few sequences (see the kernel): 8 state elements per thread
     bool f32 = g.U.dt == OMK_F32 && g.K.dt == OMK_F32 && g.Q.dt == OMK_F32 && (!g.Z.p || g.Z.dt == OMK_F32);
@@ -538,6 +539,7 @@ static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdD
   a.B = d.B; a.L = d.L; a.H = d.H; a.dt_dt = dt.dtype; a.bias_dt = dtb.dtype; a.softplus = softplus; a.lo = lo;
   a.hi = hi > 0.f ? hi : INFINITY;
   dim3 block(256);
+  kernels_note("ssd_dt_prep");
   const bool vec = (dt.dtype == OMK_BF16 || dt.dtype == OMK_F16) && a.sh == 1 && (a.sl % 2) == 0 && (a.sb % 2) == 0 && ((uintptr_t)dt.data & 3) == 0 &&
                    (d.H % 2) == 0 && (d.L % 4) == 0 && ((uintptr_t)dtp & 15) == 0 && (!dsoft || ((uintptr_t)dsoft & 15) == 0);
   if (vec) {
@@ -619,6 +621,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (present(p->final_states)) OMK_REQUIRE(p->final_states.dtype == OMK_F32 && p->final_states.ndim == 4, "ssd_scan_fwd: final_states must be f32 (B,H,P,N)");
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p), "ssd_scan_fwd: workspace too small");
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
+  kernels_reset();
   float* dtp = (float*)p->workspace;
   GScan g = {};
   // (tried in round 2: the scan reading the raw (B, L, H) dt itself and applying bias / softplus / clamp in its scalar pass, to
@@ -798,6 +801,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   if (present(p->dfinal_states)) OMK_REQUIRE(p->dfinal_states.dtype == OMK_F32 && p->dfinal_states.ndim == 4, "ssd_scan_bwd: dfinal_states must be f32 (B,H,P,N)");
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_bwd_workspace_bytes(p), "ssd_scan_bwd: workspace too small");
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
+  kernels_reset();
   const bool has_dfin = present(p->dfinal_states);
   const int path = bwd_path(p, d);
   const bool mfma = path != BWD_GENERIC, cp = path == BWD_CP;
@@ -889,9 +893,11 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
     f.dA = (float*)p->dA.data; f.ddtb = (float*)p->ddt_bias.data; f.B = d.B; f.H = d.H; f.L = d.L; f.P = d.P; f.N = d.N;
     if (f.bnd && !f.dfin) {
       dim3 grid((unsigned)(d.B * d.H)), block(1024);
+      kernels_note("ssd_bwd_finish_par");
       OMK_LAUNCH(ssd_bwd_finish_par_kernel, grid, block, 0, stream, f);
     } else {
       dim3 grid((unsigned)(d.B * d.H)), block(64);
+      kernels_note("ssd_bwd_finish");
       OMK_LAUNCH(ssd_bwd_finish_kernel, grid, block, 0, stream, f);
     }
   }

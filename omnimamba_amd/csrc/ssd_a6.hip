@@ -583,6 +583,7 @@ int ssd_a6_state_only(const GScan& g, omk_stream stream) {
   }
   dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
   const size_t smem = sizeof(SmemA6);
+  kernels_note("ssd_a6<state_only>");
   if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<GS_Y, false, true, false, true, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem);
   OMK_LAUNCH((ssd_a6_kernel<GS_Y, false, true, false, true, true>), grid, block, smem, stream, a);
   return OMK_OK;
@@ -597,6 +598,7 @@ int ssd_a6_state_dump(const GScan& g, omk_stream stream) {
   a.nseg = sp.nseg; a.cps = sp.cps;
   dim3 grid((unsigned)(a.B * (a.H / 2) * a.nseg)), block(512);
   const size_t smem = sizeof(SmemA6);
+  kernels_note("ssd_a6<state_dump>");
   if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<GS_Y, false, true, true, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem);
   OMK_LAUNCH((ssd_a6_kernel<GS_Y, false, true, true, false, true>), grid, block, smem, stream, a);
   return OMK_OK;
@@ -618,6 +620,7 @@ int ssd_a6_launch(const GScan& g, omk_stream stream) {
   // context-parallel shards): the carried state is then exact to fp32 accumulation (8 more MFMAs per sub-chunk)
   const bool khilo = (a.flags & (GSF_KHILO | GSF_PRECISE)) || a.fin != nullptr;
 #define OMK_A6K(MODE_, EX_, DF_, DU_, KH_) do { \
+    kernels_note("ssd_a6<mode=%d,ex=%d,dfold=%d,dump=%d,khilo=%d>", (int)MODE_, (int)EX_, (int)DF_, (int)DU_, (int)KH_); \
     if (OMK_SET_MAX_DYN_SMEM((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_a6: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_a6_kernel<MODE_, EX_, DF_, DU_, KH_>), grid, block, smem, stream, a); } while (0)
 #define OMK_A6(MODE_, EX_, DF_, DU_) do { if (khilo && MODE_ == GS_Y) OMK_A6K(MODE_, EX_, DF_, DU_, (MODE_ == GS_Y)); else OMK_A6K(MODE_, EX_, DF_, DU_, false); } while (0)

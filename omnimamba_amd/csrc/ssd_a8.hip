@@ -720,6 +720,7 @@ int ssd_a8_launch(const GScan& g, omk_stream stream) {
   // context-parallel shards) or asks for it (OMK_SSD_KHILO / OMK_SSD_PRECISE)
   const bool khilo = a.mode == GS_Y && ((a.flags & (GSF_KHILO | GSF_PRECISE)) || a.fin != nullptr);
 #define OMK_A8K(MODE_, DU_, KH_, PR_) do { \
+    kernels_note("ssd_a8<mode=%d,dump=%d,khilo=%d,precise=%d>", (int)MODE_, (int)DU_, (int)KH_, (int)PR_); \
     if (OMK_SET_MAX_DYN_SMEM((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), smem)) return fail(OMK_ELAUNCH, "ssd_a8: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), grid, block, smem, stream, a); } while (0)
   if (a.mode == GS_Y) {

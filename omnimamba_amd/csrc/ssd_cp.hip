@@ -534,6 +534,7 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
   const bool al = (((uintptr_t)a.dB | (uintptr_t)a.dC) & 7) == 0 && ((a.dbsb | a.dbsl | a.dbsg | a.dcsb | a.dcsl | a.dcsg) & 3) == 0;
   const char* de = getenv("OMK_CP_DIRECT");
   a.direct = (a.nhs == 1 && a.dB_dt == OMK_BF16 && a.dC_dt == OMK_BF16 && al && !(de && de[0] == '0')) ? 1 : 0;
+  kernels_note("ssd_cp<direct=%d,nhs=%d>", a.direct, a.nhs);
   const size_t smem = sizeof(SmemCp);
   if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
   dim3 grid((unsigned)((int64_t)a.B * a.G * a.nW * a.nhs)), block(512);

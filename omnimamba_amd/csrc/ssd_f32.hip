@@ -184,6 +184,7 @@ int ssd_f32_mfma_launch(const GScan& g, omk_stream stream) {
   if (((uintptr_t)g.K.p & 15) || ((uintptr_t)g.Q.p & 15) || g.K.sb % 4 || g.K.sl % 4 || g.K.sh % 4 || g.Q.sb % 4 || g.Q.sl % 4 || g.Q.sh % 4) return OMK_EUNSUPPORTED;
   if (g.L < 1 || (g.H / g.G) < 1) return OMK_EUNSUPPORTED;
   if (const char* e = getenv("OMK_SSD_F32_MFMA")) if (e[0] == '0') return OMK_EUNSUPPORTED;
+  kernels_note("ssd_f32_mfma");
   dim3 grid((unsigned)((int64_t)g.B * g.H * (g.DU / 16))), block(256);
   if (g.Z.p) OMK_LAUNCH((ssd_f32_mfma_kernel<true>), grid, block, 0, stream, g);
   else OMK_LAUNCH((ssd_f32_mfma_kernel<false>), grid, block, 0, stream, g);

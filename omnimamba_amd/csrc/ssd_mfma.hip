@@ -989,6 +989,7 @@ int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt) {
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<GS_Y, false, true, false>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem);
     OMK_LAUNCH((ssd_mfma_a3_kernel<GS_Y, false, true, false>), sgrid, block, smem, stream, a);
   }
+  kernels_note("ssd_mfma_a3<segment state pass,khilo=%d>;ssd_seg_fold", (int)khilo);
   dim3 fgrid((unsigned)((int64_t)a.B * a.H * (SEG_STATE / 256)));
   OMK_LAUNCH(ssd_seg_fold_kernel, fgrid, block, 0, stream, a);
   return OMK_OK;
@@ -1054,7 +1055,9 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
     if ((int64_t)g.L * ms * 2 >= (int64_t)0xfffff000) return OMK_EUNSUPPORTED;
   }
   if (dry) return OMK_OK;
-  if (ssd_v6_applies(g)) return ssd_v6_launch(g, stream);
+  // PRECISE exists as an instantiation of the specialised-wave kernel; a PRECISE call on another shape (gate / pre-gate copy in the epilogue, D per
+  // (head, column), heads that do not pair up) takes the caller's fall-back chain: the fp32 VALU scan, which rounds nothing
+  if ((g.flags & GSF_PRECISE) && g.mode == GS_Y && !ssd_a8_applies(g)) return OMK_EUNSUPPORTED;
   if (ssd_a6_applies(g)) return ssd_a6_launch(g, stream);
   // one head (x one segment of the sequence) per workgroup, two workgroups per CU
   GScan a = g;
@@ -1063,6 +1066,7 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry) {
   dim3 grid((unsigned)(a.B * a.H * a.nseg)), block(256);
   const size_t smem = sizeof(SmemA3);
 #define OMK_A3K(MODE_, EX_, ST_, DF_, KH_, GRID_) do { \
+    kernels_note("ssd_mfma_a3<mode=%d,ex=%d,state=%d,dfold=%d,khilo=%d>", (int)MODE_, (int)EX_, (int)ST_, (int)DF_, (int)KH_); \
     if (OMK_SET_MAX_DYN_SMEM((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), smem)) return fail(OMK_ELAUNCH, "ssd_mfma: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_mfma_a3_kernel<MODE_, EX_, ST_, DF_, KH_>), GRID_, block, smem, stream, a); } while (0)
   const bool khilo = (g.flags & (GSF_KHILO | GSF_PRECISE)) || OMK_SSD_KHILO_DEFAULT != 0;

@@ -110,9 +110,6 @@ int ssd_mfma_launch(const GScan& g, omk_stream stream, int dry = 0);   // dry = 
 // split sequences (GScan::seg set, class A style descriptor): state-only pass + fold; afterwards slot j - 1 of g.seg is the
 // state at the START of segment j (initial state included).  Shared by the scans whose state this is (y and dC; dx and dB).
 int ssd_mfma_prepare_segments(const GScan& g, omk_stream stream, int* seg_fmt = nullptr);   // *seg_fmt: the order it left the states in
-// the hi + lo ("precise") forward scan (ssd_v6.hip): OMK_SSD_PRECISE=1
-bool ssd_v6_applies(const GScan& g);
-int ssd_v6_launch(const GScan& g, omk_stream stream);
 // the column-slice class A kernel (ssd_a6.hip): state slices in registers, 32-token sub-chunks, intra tiles shared through LDS, one
 // workgroup per head pair (its 16-token predecessor ssd_a5.hip and their experiments: git history, profiles/r04_a5_a6_experiments.txt)
 bool ssd_a6_applies(const GScan& g);

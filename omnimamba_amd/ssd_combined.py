@@ -98,6 +98,7 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
                 p.window_states = K.T(wstates)
         with _prof.range_("ssd_scan_fwd"):
             K.run(lib, "omk_ssd_scan_fwd", p, x)
+        _prof.note_kernels("ssd_scan_fwd", lib)
     elif fin is not None:
         fin.zero_() if initial_states is None else fin.copy_(initial_states)
     if save_window_states:
@@ -146,6 +147,7 @@ def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None
         ws = K.workspace(lib, "omk_ssd_scan_bwd_workspace_bytes", p, x)  # noqa: F841
         with _prof.range_("ssd_scan_bwd"):
             K.run(lib, "omk_ssd_scan_bwd", p, x)
+        _prof.note_kernels("ssd_scan_bwd", lib)
     else:
         for t in (dA, dD, ddtb):
             if t is not None:

@@ -30,6 +30,13 @@ def test_bench_json_contract():
     assert 0.05 < rf["frac"] < 1.0 and (rf["traffic"] is None or rf["traffic"] >= 0.9 * rf["algorithmic_bytes_per_launch"])
     rb = j["roofline_bwd"]
     assert rb["bound"] == "hbm" and rb["algorithmic_bytes_per_launch"] == 8 * 4096 * 25856 and 0.02 < rb["frac"] < 1.0
+    # the PMC files bench.py quotes `traffic` / `mfma_busy` from must have been recorded for the kernels this run timed:
+    # bench.py nulls a stale file's numbers and says so; at HEAD the committed files must match
+    for key, fn in (("roofline", "ssd_fwd_traffic.json"), ("roofline_bwd", "ssd_bwd_traffic.json")):
+        tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        want = tj["with_window_states"]["kernel_ids"] if key == "roofline" else tj["kernel_ids"]
+        assert j[key]["kernel_ids"] == want, (key, j[key]["kernel_ids"], want)
+        assert j[key]["traffic"] is not None and "STALE" not in (j[key]["traffic_source"] or "")
     st = j["scan_target"]                          # the north-star target shape: L = 8192, B = 8 and B = 1
     assert st["B8_L8192"]["algorithmic_bytes"] == 8 * 8192 * 17024 and 0.05 < st["B8_L8192"]["frac_of_hbm_peak"] < 1.0 and st["B1_L8192"]["launch_ms"] > 0
     assert j["sustained"] is None                  # --min-seconds 0
