@@ -298,6 +298,15 @@ typedef struct {
   int32_t force_generic;    /* 1 = use the shape-generic fp32 VALU kernel even when the MFMA kernel applies */
   int32_t flags;            /* ABI 6: OMK_SSD_* bits below, 0 = the default kernels.  Per call -- the library reads no environment
                              * variable that changes which scan kernel runs or what it computes */
+  OmkTensor conv_weight;    /* ABI 6, optional (H * P, width <= 4): K2 fusion of the forward-only path (prefill / inference).  When present,
+                             * x is the PRE-conv input of upstream's causal_conv1d_fn(..., activation="silu") for the x channels of xBC, and
+                             * the scan applies out[t] = silu(bias + sum_k w[k] x[t - width + 1 + k]) (zeros in front of the sequence) while
+                             * it stages x -- same fp32 arithmetic and the same single bf16 rounding as omk_causal_conv1d_fwd, so the result
+                             * equals conv kernel + scan bit for bit.  B / C stay the conv OUTPUT (a 2 G N-channel conv launch of the caller).
+                             * Plain bf16 forward on the specialised-wave kernel only (no z / out_x / window_states / PRECISE, sequence not
+                             * split): otherwise OMK_EUNSUPPORTED and the caller runs conv + scan separately.
+                             * reference: models/stage2/generation.py:195-211 prefill, scripts/inference_mmu.py:137-147 */
+  OmkTensor conv_bias;      /* optional (H * P) */
 } OmkSsdFwd;
 /* OmkSsdFwd::flags / OmkSsdBwd::flags */
 #define OMK_SSD_PRECISE      1  /* forward, bf16 MFMA scan: the carried state meets C as a bf16 hi + lo pair and the state-update operand is

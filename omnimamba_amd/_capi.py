@@ -75,7 +75,8 @@ LoraAdd = _S("OmkLoraAdd", [(n, _t) for n in ("out", "h", "lora_b", "mask")] + [
 LoraUpBwd = _S("OmkLoraUpBwd", [(n, _t) for n in ("dy", "lora_b", "h", "dh", "dlora_b")])
 SsdFwd = _S("OmkSsdFwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "initial_states", "out",
                                             "out_x", "final_states", "window_states")] + _ws
-            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i), ("flags", _i)])
+            + [("dt_min", _f), ("dt_max", _f), ("dt_softplus", _i), ("chunk_size", _i), ("force_generic", _i), ("flags", _i),
+               ("conv_weight", _t), ("conv_bias", _t)])
 # OmkSsdFwd.flags / OmkSsdBwd.flags (include/omk.h)
 SSD_PRECISE, SSD_KHILO, SSD_EVERY_CHUNK, SSD_NO_SPLIT, SSD_COLUMN_SLICE, SSD_SEQUENTIAL_BWD = 1, 2, 4, 8, 16, 32
 SsdBwd = _S("OmkSsdBwd", [(n, _t) for n in ("x", "dt", "A", "Bm", "Cm", "D", "dt_bias", "initial_states", "y", "dout",

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl_kernel(ConvArgs a) {
         for (int i = 0; i < VEC; i++) {
           float acc = bias[i];
 #pragma unroll
-          for (int k = 0; k < W; k++) acc += w[k][i] * win[k][i];
+          for (int k = 0; k < W; k++) acc = fma_f32(w[k][i], win[k][i], acc);
           o[i] = a.silu ? silu_fast(acc) : acc;
         }
         store_vec<T, VEC>(out + (int64_t)(lg + j) * a.osl, o);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl8_kernel(ConvArgs a) {
       for (int i = 0; i < VEC; i++) {
         float acc = bias[i];
 #pragma unroll
-        for (int k = 0; k < W; k++) acc += w[k][i] * win[k][i];
+        for (int k = 0; k < W; k++) acc = fma_f32(w[k][i], win[k][i], acc);
         o4[i] = from_f32<T>(silu_on ? silu_fast(acc) : acc);
       }
       u32x2 pk;
@@ -267,7 +267,7 @@ __global__ void conv1d_fwd_generic_kernel(ConvArgs a, int l_fastest) {
   else { c = (int)(g % a.C); l = (int)((g / a.C) % a.L); b = (int)(g / ((int64_t)a.L * a.C)); }
   const T* x = (const T*)a.x;
   float acc = a.bias ? load_rt(a.bias, c, a.bdt) : 0.f;
-  for (int k = 0; k < a.W; k++) acc += load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt) * conv_in<T>(a, x, b, c, l - (a.W - 1) + k);
+  for (int k = 0; k < a.W; k++) acc = fma_f32(load_rt(a.w, (int64_t)c * a.wsc + k * a.wsk, a.wdt), conv_in<T>(a, x, b, c, l - (a.W - 1) + k), acc);
   if (a.silu) acc = silu_f(acc);
   ((T*)a.out)[(int64_t)b * a.osb + (int64_t)c * a.osc + (int64_t)l * a.osl] = from_f32<T>(acc);
 }
@@ -679,7 +679,7 @@ __global__ void conv1d_update_kernel(ConvUpdArgs a) {
     float xv = load_rt(a.x, (int64_t)b * a.xsb + (int64_t)c * a.xsc + (int64_t)t * a.xsl, a.xdt);
     win[a.W - 1] = xv;
     float acc = bias;
-    for (int k = 0; k < a.W; k++) acc += w[k] * win[k];
+    for (int k = 0; k < a.W; k++) acc = fma_f32(w[k], win[k], acc);
     if (a.silu) acc = silu_f(acc);
     store_rt(a.out, (int64_t)b * a.osb + (int64_t)c * a.osc + (int64_t)t * a.osl, a.xdt, acc);
     for (int k = 0; k + 1 < a.W; k++) win[k] = win[k + 1];

@@ -331,6 +331,10 @@ __device__ __forceinline__ uint64_t clock64_() { return 0; }
 #else
 __device__ __forceinline__ uint64_t clock64_() { return __builtin_readcyclecounter(); }
 #endif
+// a * b + c with ONE rounding, in every build and at every call site: `acc += a * b` under -ffp-contract=fast is fused where the compiler
+// likes it and split where its vectoriser prefers a packed multiply + add (conv1d_fwd_cl8_kernel: tokens 5 .. 7 of every group of eight came
+// out unfused, 1e-5 of the outputs one bf16 ulp away from the other forward kernels).  Kernels whose results must agree bit for bit say fma.
+__device__ __forceinline__ float fma_f32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float sigmoid_fast(float x) { return rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
 // Wave totals of N per-lane values (N a power of two <= 64) with N - 1 + log2(64 / N) shuffles instead of the 6 N

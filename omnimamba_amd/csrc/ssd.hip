@@ -620,6 +620,13 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (present(p->out_x)) OMK_REQUIRE(p->out_x.dtype == p->out.dtype && p->out_x.stride[0] == p->out.stride[0] && p->out_x.stride[1] == p->out.stride[1] && p->out_x.stride[2] == p->out.stride[2], "ssd_scan_fwd: out_x must match out's dtype and strides");
   if (present(p->final_states)) OMK_REQUIRE(p->final_states.dtype == OMK_F32 && p->final_states.ndim == 4, "ssd_scan_fwd: final_states must be f32 (B,H,P,N)");
   OMK_REQUIRE(p->workspace && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p), "ssd_scan_fwd: workspace too small");
+  if (present(p->conv_weight)) {
+    OMK_REQUIRE(p->conv_weight.ndim == 2 && p->conv_weight.shape[0] == (int64_t)d.H * d.P && p->conv_weight.shape[1] >= 1 && p->conv_weight.shape[1] <= 4,
+                "ssd_scan_fwd: conv_weight must be (H * P, width <= 4)");
+    if (present(p->conv_bias)) OMK_REQUIRE(p->conv_bias.ndim == 1 && p->conv_bias.shape[0] == (int64_t)d.H * d.P && p->conv_bias.stride[0] == 1, "ssd_scan_fwd: conv_bias must be dense (H * P)");
+    if (state_only || present(p->z) || present(p->out_x) || present(p->window_states) || (p->flags & OMK_SSD_PRECISE) || p->force_generic || p->x.dtype != OMK_BF16)
+      return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the fused conv exists for the plain bf16 forward only (no gate / pre-gate copy / window states / PRECISE): run omk_causal_conv1d_fwd and the scan separately");
+  }
   if ((int64_t)d.B * d.L * d.H * d.P == 0) return OMK_OK;
   kernels_reset();
   float* dtp = (float*)p->workspace;
@@ -647,6 +654,18 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
 #endif
   g.flags = p->flags & (GSF_PRECISE | GSF_KHILO | GSF_FLUSH | GSF_NO_SPLIT | GSF_COLUMN_SLICE);
   if (ssd_seg_bytes(d.B * d.H, d.L) && !(p->flags & OMK_SSD_NO_SPLIT)) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);
+  if (present(p->conv_weight)) {
+    g.cw = p->conv_weight.data; g.cwsc = p->conv_weight.stride[0]; g.cwsk = p->conv_weight.stride[1]; g.cw_dt = p->conv_weight.dtype; g.cW = (int)p->conv_weight.shape[1];
+    g.cb = p->conv_bias.data; g.cb_dt = p->conv_bias.dtype;
+    // only ssd_a8.hip knows the fused conv: a shape it does not take (heads that do not pair up, D per (head, column), a sequence it would split) is the caller's to run unfused
+    GScan q = g;
+    if (q.seg && ssd_segments(d.B * d.H, d.L).nseg > 1) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: fused conv on a sequence the scan splits into segments (B * H <= 128): run conv + scan separately");
+    g.seg = nullptr;
+    rc = (ssd_mfma_launch(g, nullptr, 1) == OMK_OK && ssd_a8_applies(g)) ? ssd_a8_launch(g, stream) : OMK_EUNSUPPORTED;
+    if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: fused conv on a shape outside the specialised-wave kernel: run conv + scan separately");
+    if (rc) return rc;
+    return finish_launch("ssd_scan_fwd");
+  }
   if (state_only) {
     rc = (p->force_generic || p->x.dtype != OMK_BF16) ? OMK_EUNSUPPORTED : ssd_mfma_state_only(g, stream);
     if (rc == OMK_EUNSUPPORTED) return fail(OMK_EUNSUPPORTED, "ssd_scan_fwd: the state-only pass exists for the MFMA shape only (bf16, headdim 64, d_state 128); run the scan and drop its output");

@@ -47,8 +47,14 @@ static_assert(sizeof(SmemA8) <= 160 * 1024, "one workgroup per CU");
 // PRECISE (OmkSsdFwd::flags & OMK_SSD_PRECISE, forward only): the bf16 copy of the state slice that meets Q^T is a hi + lo pair -- twice the
 // MFMAs of phase 1 and six instead of one VALU operation per packed pair -- and KHILO is on: no operand of the scan is rounded to 8 bits
 // any more, y is within the bare 1e-3 of the fp32 recurrence on every head (tests/test_configs_gpu.py, profiles/r06_precise.txt)
-template <int MODE, bool DUMP, bool KHILO, bool PRECISE = false>
+// CONV (forward only; GScan::cw set -- OmkSsdFwd::conv_weight): U is the PRE-conv x and the staging side applies the causal depthwise conv1d
+// (width <= 4) + SiLU of upstream's causal_conv1d_fn to it on the way into LDS -- the x columns (4096 of the 4352 conv channels of the 1.3B
+// block) never make the round trip through a conv output buffer (K2 fusion, forward-only path: prefill / inference).  The helper waves
+// stage U then: a lane owns FOUR consecutive tokens of eight channels, requests them with their three halo rows (seven 16-byte loads),
+// runs the taps in the conv kernel's own order (bit-identical bf16 operand) and writes four 16-byte rows.
+template <int MODE, bool DUMP, bool KHILO, bool PRECISE = false, bool CONV = false>
 __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
+  constexpr bool CUS = OMK_A8_CU && !CONV;   // the compute waves stage the U tile of their own head
   OMK_DYN_SMEM(smem_raw);
   SmemA8& sm = *reinterpret_cast<SmemA8*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,8 +144,37 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       rda_[S] = buf_ld_f32(Dr, dvo_a, 4u * (uint32_t)tl);
     };
     auto prefetch_kq = [&](auto ps, int tl) { prefetch_k(ps, tl); prefetch_q(ps, tl); prefetch_dt(ps, tl); };
-    auto prefetch_u = [&](auto ps, int tl) {   // (OMK_A8_CU = 0 only)
+    // ---- CONV: the lane's four tokens 4 tg .. 4 tg + 3 (+ three halo rows in front) of the channels 8 seg .. 8 seg + 7 of head hh
+    const int ctg = (ht & 127) >> 3, cseg = ht & 7;
+    u32x4 rc[CONV ? 7 : 1];
+    float cw[CONV ? 8 : 1][4], cb[CONV ? 8 : 1];
+    if (CONV) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int64_t ch = (int64_t)h * 64 + 8 * cseg + e;
+        cb[e] = a.cb ? load_rt(a.cb, ch, a.cb_dt) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cw[e][k] = (k >= 4 - a.cW) ? load_rt(a.cw, ch * a.cwsc + (int64_t)(k - (4 - a.cW)) * a.cwsk, a.cw_dt) : 0.f;   // (taps of a narrower filter: leading zeros)
+      }
+    }
+    auto prefetch_u = [&](auto ps, int tl) {   // (the helpers stage U: OMK_A8_CU = 0, or CONV)
       constexpr int S = decltype(ps)::value;
+      if (CONV) {
+        // rows tl + 4 tg + j - 3, j = 0 .. 6.  The three rows in front of the sequence are zeros: lane offsets stay non-negative (the range
+        // check of a buffer access is made on the unwrapped sum), the first chunk points those rows behind the range instead
+        if (tl >= 3) {
+          const uint32_t sc = 2u * (uint32_t)((tl - 3) * usl);
+#pragma unroll
+          for (int j = 0; j < 7; j++) rc[j] = buf_ld16(Ur, 2u * (uint32_t)((4 * ctg + j) * usl + 8 * cseg), sc);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 7; j++) {
+            const int t = tl + 4 * ctg + j - 3;
+            rc[j] = buf_ld16(Ur, t >= 0 ? 2u * (uint32_t)(t * usl + 8 * cseg) : 0x80000000u, 0u);
+          }
+        }
+        return;
+      }
       const uint32_t su_ = 2u * (uint32_t)(tl * usl);
 #pragma unroll
       for (int r = 0; r < 4; r++) ru[S][r] = buf_ld16(Ur, uvo, su_ + 2u * (uint32_t)((rev ? 16 * (3 - r) : 16 * r) * usl));
@@ -157,6 +192,27 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     };
     auto commit_u = [&](auto ps, int ub) {
       constexpr int S = decltype(ps)::value;
+      if (CONV) {
+        // out[t] = silu(bias + sum_k w[k] x[t - 3 + k]) in fp32, taps in the conv kernel's order (conv1d.hip), rounded to bf16 once: the
+        // operand the unfused path reads back from the conv output buffer, bit for bit
+        u32x4 o[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {      // channel pairs (one 32-bit register of every row)
+          float xl[7], xh[7];
+#pragma unroll
+          for (int j = 0; j < 7; j++) { xl[j] = bf_lo(rc[j][e2]); xh[j] = bf_hi(rc[j][e2]); }
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            float al = cb[2 * e2], ah = cb[2 * e2 + 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { al = fma_f32(cw[2 * e2][k], xl[t + k], al); ah = fma_f32(cw[2 * e2 + 1][k], xh[t + k], ah); }
+            o[t][e2] = pack_bf16x2(silu_fast(al), silu_fast(ah));
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) st16(&sm.U[ub][hh][ux3(4 * ctg + t, 8 * cseg)], o[t]);
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[S][r]);
     };
@@ -302,9 +358,9 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NSET - 1>;
     prefetch_kq(S0{}, chunk_lo(c0));
-    if (!OMK_A8_CU) prefetch_u(S0{}, chunk_lo(c0));
+    if (!CUS) prefetch_u(S0{}, chunk_lo(c0));
     commit_k(S0{}, 0); commit_q(S0{}, 0);
-    if (!OMK_A8_CU) commit_u(S0{}, 0);
+    if (!CUS) commit_u(S0{}, 0);
     if (w == 0) scalars(S0{}, 0, 0, c0);
     prefetch_kq(S0{}, chunk_lo(clipc(c0 + 1)));
     commit_k(S0{}, 1); commit_q(S0{}, 1);
@@ -316,7 +372,7 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     if (w == 1) build_tile(fb, 0, 1);
     prefetch_kq(S0{}, chunk_lo(clipc(c0 + 2)));
     if (NSET == 2) prefetch_kq(S1{}, chunk_lo(clipc(c0 + 3)));
-    if (!OMK_A8_CU) { prefetch_u(S0{}, chunk_lo(clipc(c0 + 1))); if (NSET == 2) prefetch_u(S1{}, chunk_lo(clipc(c0 + 2))); }
+    if (!CUS) { prefetch_u(S0{}, chunk_lo(clipc(c0 + 1))); if (NSET == 2 && !CONV) prefetch_u(S1{}, chunk_lo(clipc(c0 + 2))); }
     block_sync();
     int kb1 = 1, kb2 = 2, kb0 = 0;
     PT8_START();
@@ -347,8 +403,8 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       if (w == 0) { if (!(OMK_A8_VAR & 32)) scalars(ps, kb2, ub0, c + 2); } else if (more && !(OMK_A8_VAR & 16)) build_tile(fb, ub1, 1);
       PT8(3);
       OMK_SCHED_FENCE();
-      if (!(OMK_A8_VAR & 64) && !OMK_A8_CU) commit_u(ps, ub1);
-      if (!(OMK_A8_VAR & 128)) { if (!OMK_A8_CU) prefetch_u(ps, chunk_lo(clipc(c + 1 + NSET))); prefetch_dt(ps, chunk_lo(clipc(c + 2 + NSET))); }
+      if (!(OMK_A8_VAR & 64) && !CUS) commit_u(ps, ub1);
+      if (!(OMK_A8_VAR & 128)) { if (!CUS) prefetch_u(ps, chunk_lo(clipc(c + 1 + (CONV ? 1 : NSET)))); prefetch_dt(ps, chunk_lo(clipc(c + 2 + NSET))); }
       PT8(4);
       block_sync();
       PT8(5);
@@ -456,7 +512,7 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) st16(&sm.U[ub][hh][o_cu + 16 * 64 * r], ru[r]);
   };
-  if (OMK_A8_CU) {
+  if (CUS) {
     prefetch_u(U0{}, chunk_lo(c0));
     commit_u(U0{}, 0);
     prefetch_u(U0{}, chunk_lo(clipc(c0 + 1)));
@@ -662,8 +718,8 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     PT8(1);
     phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
     }
-    if (OMK_A8_CU && !(OMK_A8_VAR & 64)) commit_u(ps, ub0 ^ 1);                                   // U of chunk c + 1
-    if (OMK_A8_CU && !(OMK_A8_VAR & 128)) prefetch_u(ps, chunk_lo(clipc(c + 1 + USET)));
+    if (CUS && !(OMK_A8_VAR & 64)) commit_u(ps, ub0 ^ 1);                                   // U of chunk c + 1
+    if (CUS && !(OMK_A8_VAR & 128)) prefetch_u(ps, chunk_lo(clipc(c + 1 + USET)));
     PT8(2);
     block_sync();   // behind the last request for the buffers of chunk c
     PT8(3);
@@ -710,6 +766,8 @@ int ssd_a8_launch(const GScan& g, omk_stream stream) {
   a.nseg = sp.nseg; a.cps = sp.cps;
   const bool precise = a.mode == GS_Y && (a.flags & GSF_PRECISE);
   if (precise && a.dump) return fail(OMK_EINVAL, "ssd_a8: a PRECISE forward does not save window states");
+  // the fused conv (forward-only path): plain forward of an unsplit sequence
+  if (a.cw && (a.mode != GS_Y || a.dump || precise || a.reverse || a.nseg > 1 || a.cW < 1 || a.cW > 4)) return OMK_EUNSUPPORTED;
   if (a.nseg > 1 && !a.seg_ready) {
     int rc = ssd_mfma_prepare_segments(g, stream);
     if (rc) return rc;
@@ -723,7 +781,12 @@ int ssd_a8_launch(const GScan& g, omk_stream stream) {
     kernels_note("ssd_a8<mode=%d,dump=%d,khilo=%d,precise=%d>", (int)MODE_, (int)DU_, (int)KH_, (int)PR_); \
     if (OMK_SET_MAX_DYN_SMEM((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), smem)) return fail(OMK_ELAUNCH, "ssd_a8: cannot raise dynamic LDS to %zu", smem); \
     OMK_LAUNCH((ssd_a8_kernel<MODE_, DU_, KH_, PR_>), grid, block, smem, stream, a); } while (0)
-  if (a.mode == GS_Y) {
+#define OMK_A8C(KH_) do { \
+    kernels_note("ssd_a8<mode=0,dump=0,khilo=%d,precise=0,conv=1>", (int)KH_); \
+    if (OMK_SET_MAX_DYN_SMEM((ssd_a8_kernel<GS_Y, false, KH_, false, true>), smem)) return fail(OMK_ELAUNCH, "ssd_a8: cannot raise dynamic LDS to %zu", smem); \
+    OMK_LAUNCH((ssd_a8_kernel<GS_Y, false, KH_, false, true>), grid, block, smem, stream, a); } while (0)
+  if (a.cw) { if (khilo) OMK_A8C(true); else OMK_A8C(false); }
+  else if (a.mode == GS_Y) {
     if (precise) OMK_A8K(GS_Y, false, true, true);
     else if (a.dump) { if (khilo) OMK_A8K(GS_Y, true, true, false); else OMK_A8K(GS_Y, true, false, false); }
     else { if (khilo) OMK_A8K(GS_Y, false, true, false); else OMK_A8K(GS_Y, false, false, false); }
@@ -731,6 +794,7 @@ int ssd_a8_launch(const GScan& g, omk_stream stream) {
     if (a.dump) OMK_A8K(GS_DX, true, false, false); else OMK_A8K(GS_DX, false, false, false);
   }
 #undef OMK_A8K
+#undef OMK_A8C
   return OMK_OK;
 }
 

@@ -65,6 +65,9 @@ struct GScan {
   // the raw 16 KB LDS image [u][k] (kx3 swizzle, ssd_tiles.h) the kernel publishes for its own Q . S product.
   uint16_t* dump; int dump_nw;
   int flags;                                                     // GSF_* bits
+  // class A forward on ssd_a8.hip: causal depthwise conv1d (width cW <= 4) + SiLU applied to U while it is staged (U = the PRE-conv x);
+  // weight element (channel c = h * DU + u, tap k) at cw[c * cwsc + k * cwsk], optional bias cb[c]
+  const void* cw; int64_t cwsc, cwsk; int cw_dt, cW; const void* cb; int cb_dt;
   int state_only;                                                // class A (MFMA): no output, only the state pass from the initial state to `fin` (context-parallel shards)
   unsigned long long* prof;                                      // developer only: per-wave phase cycle sums of workgroup 0 (OMK_PROF env)
   int ablate;                                                    // developer only (OMK_PHASE_PROF builds): phases to skip, wrong results

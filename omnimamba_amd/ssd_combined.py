@@ -106,6 +106,73 @@ def ssd_scan_fwd(x, dt, A, B, C, D=None, z=None, dt_bias=None, initial_states=No
     return out, out_x, fin
 
 
+def fused_conv_scan_enabled() -> bool:
+    """OMK_K2_FUSED=0: forward-only passes run conv kernel + scan separately (the fused form: conv1d + SiLU of the x channels inside the
+    scan's staging, OmkSsdFwd.conv_weight)."""
+    return os.environ.get("OMK_K2_FUSED", "1") != "0"
+
+
+def ssd_scan_fwd_fused_conv(xBC, dt, A, conv_weight, conv_bias, nheads, headdim, ngroups, d_state, D=None, dt_bias=None,
+                            dt_softplus=True, dt_limit=(0.0, _INF), return_final_states=False, conv_state_out=None, chunk_size=256):
+    """K2 fusion of the forward-only path (reference reach: models/stage2/generation.py:195-211 prefill,
+    scripts/inference_mmu.py:137-147): xBC (batch, seqlen, d_ssm + 2 G N) is the PRE-conv slice of zxbcdt.  The 2 G N B / C channels go
+    through a small conv launch into a dense buffer; the d_ssm x channels are convolved INSIDE the scan while it stages them
+    (OmkSsdFwd.conv_weight) and never visit a conv output buffer.  conv_state_out (batch, d_ssm + 2 G N, state_len): filled with the
+    last pre-conv inputs like causal_conv1d_fn(..., final_states_out=) does.  Returns (y (batch, seqlen, nheads, headdim), final_states |
+    None), or None when the kernel does not take this call (the caller then runs the separate ops) -- bit-identical results either way."""
+    lib = get_lib()
+    Bsz, L, Ct = xBC.shape
+    H, P, G, N = nheads, headdim, ngroups, d_state
+    d_ssm = H * P
+    if (xBC.dtype != torch.bfloat16 or P != 64 or N != 128 or xBC.stride(-1) != 1 or Ct != d_ssm + 2 * G * N or conv_weight.shape[1] > 4
+            or not fused_conv_scan_enabled() or L == 0 or Bsz == 0):
+        return None
+    # The conv work rides on the scan's workgroups (one per head pair): it pays when they fill the chip -- 256 workgroups at batch 8 of the
+    # 1.3B block: - 38 us per block -- and loses when the scan runs on a fraction of the CUs while the stand-alone conv kernel would use all of
+    # them (batch 4: + 7 us, batch 1: + 5 us; profiles/r06_k2_fusion.txt).  OMK_K2_MIN_WGS: developer override of the threshold.
+    if Bsz * (H // 2) < int(os.environ.get("OMK_K2_MIN_WGS", "256")):
+        return None
+    require_device(lib, xBC, dt, A, conv_weight, conv_bias, D, dt_bias)
+    A = A.float().contiguous()
+    x_pre = xBC[..., :d_ssm].unflatten(-1, (H, P))
+    bc = torch.empty(Bsz, L, 2 * G * N, dtype=xBC.dtype, device=xBC.device)
+    out = torch.empty(Bsz, L, H, P, dtype=xBC.dtype, device=xBC.device)
+    fin = torch.empty(Bsz, H, P, N, dtype=torch.float32, device=xBC.device) if return_final_states else None
+    wx, wbc = conv_weight[:d_ssm], conv_weight[d_ssm:]
+    bx, bbc = (None, None) if conv_bias is None else (conv_bias[:d_ssm].contiguous(), conv_bias[d_ssm:])
+    Bm, Cm = bc[..., :G * N].unflatten(-1, (G, N)), bc[..., G * N:].unflatten(-1, (G, N))
+    p = K.SsdFwd(x=K.T(x_pre), dt=K.T(dt), A=K.T(A), Bm=K.T(Bm), Cm=K.T(Cm), D=K.T(D), z=K.T(None), dt_bias=K.T(dt_bias),
+                 initial_states=K.T(None), out=K.T(out), out_x=K.T(None), final_states=K.T(fin), dt_min=float(dt_limit[0]),
+                 dt_max=float(dt_limit[1]), dt_softplus=int(dt_softplus), chunk_size=int(chunk_size), force_generic=0,
+                 flags=int(current_scan_flags()) & (K.SSD_KHILO | K.SSD_EVERY_CHUNK), conv_weight=K.T(wx), conv_bias=K.T(bx))
+    ws = K.workspace(lib, "omk_ssd_scan_fwd_workspace_bytes", p, xBC)  # noqa: F841
+    # the B / C conv first (the scan reads its output); its epilogue fills the B / C rows of conv_state_out
+    pc = K.Conv1dFwd(x=K.T(xBC[..., d_ssm:].transpose(1, 2)), weight=K.T(wbc), bias=K.T(bbc), initial_states=K.T(None),
+                     out=K.T(bc.transpose(1, 2)), final_states=K.T(None if conv_state_out is None else conv_state_out[:, d_ssm:]), silu=1)
+    fn = lib.omk_ssd_scan_fwd
+    import ctypes as C_
+    if lib.omk_is_emulated():
+        K.run(lib, "omk_causal_conv1d_fwd", pc, xBC)
+        rc = fn(C_.byref(p), None)
+    else:
+        with torch.cuda.device(xBC.device):
+            K.run(lib, "omk_causal_conv1d_fwd", pc, xBC)
+            with _prof.range_("ssd_scan_fwd_fused_conv"):
+                rc = fn(C_.byref(p), K.stream_of(lib, xBC))
+    if rc == -4:      # OMK_EUNSUPPORTED: heads that do not pair up, a sequence the scan splits, strides outside the MFMA kernel
+        return None
+    K.check(lib, rc, "omk_ssd_scan_fwd (fused conv)")
+    if conv_state_out is not None:      # the x rows of the conv state: the last state_len pre-conv inputs (left zero padded)
+        sl = conv_state_out.shape[-1]
+        cs = conv_state_out[:, :d_ssm]
+        if L >= sl:
+            cs.copy_(xBC[:, L - sl:, :d_ssm].transpose(1, 2))
+        else:
+            cs[..., :sl - L].zero_()
+            cs[..., sl - L:].copy_(xBC[:, :, :d_ssm].transpose(1, 2))
+    return out, fin
+
+
 def ssd_scan_bwd(dout, x, dt, A, B, C, D=None, dt_bias=None, initial_states=None, dfinal_states=None,
                  dt_softplus=False, dt_limit=(0.0, _INF), chunk_size=256, need_dinit=False, force_generic=False, y=None,
                  dx_out=None, dB_out=None, dC_out=None, window_states=None, flags=None):
@@ -302,6 +369,23 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         if zxbcdt.stride(-1) != 1:
             zxbcdt = zxbcdt.contiguous()
         z, xBC, dt = torch.split(zxbcdt, [d_ssm, d_ssm + 2 * G * N, H], dim=-1)
+        use_norm = rmsnorm_weight is not None
+        fused = None
+        if not any(ctx.needs_input_grad) and initial_states is None and use_norm and D.dim() == 1:
+            # forward-only (prefill / inference): K2 fusion -- the x channels are convolved inside the scan's staging
+            fused = ssd_scan_fwd_fused_conv(xBC, dt, A, conv1d_weight, conv1d_bias, H, P, G, N, D=D, dt_bias=dt_bias, dt_softplus=True,
+                                            dt_limit=dt_limit, return_final_states=return_final_states, conv_state_out=conv_state_out,
+                                            chunk_size=chunk_size)
+        if fused is not None:
+            y, fin = fused
+            out_n = rmsnorm_fn(y.reshape(Bsz, L, d_ssm), rmsnorm_weight, None, z=z, eps=rmsnorm_eps, group_size=d_ssm // G,
+                               norm_before_gate=norm_before_gate)
+            if outproj_weight is not None:
+                w = outproj_weight if outproj_weight.dtype == out_n.dtype else frozen_cast(outproj_weight, out_n.dtype)
+                out = F.linear(out_n, w, None if outproj_bias is None else outproj_bias.to(out_n.dtype))
+            else:
+                out = out_n
+            return (out, fin) if return_final_states else out
         if conv_state_out is not None:
             # prefill: the conv kernel's epilogue leaves the last `state_len` pre-conv inputs in the
             # cache's conv_state (left zero padded when L < state_len) -- no separate pad / copy pass
@@ -310,7 +394,6 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         else:
             xBC_c = causal_conv1d_fn(xBC.transpose(1, 2), conv1d_weight, conv1d_bias, activation=activation).transpose(1, 2)
         x, Bm, Cm = torch.split(xBC_c, [d_ssm, G * N, G * N], dim=-1)
-        use_norm = rmsnorm_weight is not None
         zz = z.reshape(Bsz, L, H, P) if z.is_contiguous() else z.unflatten(-1, (H, P))
         keep_ws = any(ctx.needs_input_grad) and save_window_states_enabled()
         r = ssd_scan_fwd(x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)), Cm.unflatten(-1, (G, N)), D=D,

@@ -498,3 +498,45 @@ def test_ssd_specialised_wave_kernel_matches_the_column_slice_kernel_bitwise(dev
                 assert rel(g_, r) < 1e-5, (nm, keep_final)
             else:
                 assert torch.equal(r, g_), (nm, keep_final)
+
+
+@pytest.mark.parametrize("L,H,G,W", [(200, 8, 1, 4), (64, 8, 2, 4), (333, 8, 2, 3), (2, 8, 1, 4), (130, 8, 1, 2)])   # (H = 8: zxbcdt rows of a multiple of 16 bytes, like the 8512-wide rows of the model)
+def test_k2_fused_conv_scan_forward_equals_the_separate_ops(dev, monkeypatch, L, H, G, W):
+    """K2 fusion, forward-only path (models/stage2/generation.py:195-211 prefill): under no_grad the fused node
+    hands the PRE-conv x columns to the scan (OmkSsdFwd.conv_weight), which applies conv1d + SiLU while staging them, and only the 2 G N
+    B / C channels take a conv launch.  Same fp32 taps in the same order and one bf16 rounding: output, final state and the conv state
+    left for the decode step must equal the separate ops BIT FOR BIT -- and both must meet the oracle composed from conv + scan + norm."""
+    import omnimamba_amd.ssd_combined as S
+    from omnimamba_amd._lib import get_lib
+    P, N, Bsz = 64, 128, 2
+    d_ssm = H * P
+    Ct = d_ssm + 2 * G * N
+    g = torch.Generator().manual_seed(100 + L)
+    zxbcdt = (torch.randn(Bsz, L, 2 * d_ssm + 2 * G * N + H, generator=g) * 0.8).bfloat16()
+    cw, cb = torch.randn(Ct, W, generator=g) * 0.4, torch.randn(Ct, generator=g) * 0.2
+    dtb, A, D = torch.randn(H, generator=g) * 0.5 - 2.0, -(torch.rand(H, generator=g) * 8 + 0.5), torch.randn(H, generator=g)
+    nw = torch.rand(d_ssm, generator=g) + 0.5
+    d = lambda t: t.to(dev)
+    res = {}
+    monkeypatch.setenv("OMK_K2_MIN_WGS", "1")     # (production takes the fused form only when the scan's workgroups fill the chip)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMK_K2_FUSED", mode)
+        cs = torch.full((Bsz, Ct, 4), 7.0, dtype=torch.bfloat16).to(dev)      # (a state_len of 4 >= width - 1: left zero padded / oldest column first)
+        with torch.no_grad():
+            out, fin = S.mamba_split_conv1d_scan_combined(d(zxbcdt), d(cw), d(cb), d(dtb), d(A), d(D), 256, return_final_states=True,
+                                                          rmsnorm_weight=d(nw), rmsnorm_eps=1e-5, headdim=P, ngroups=G, norm_before_gate=False,
+                                                          conv_state_out=cs)
+        res[mode] = (out.float().cpu(), fin.cpu(), cs.float().cpu(), get_lib().omk_ssd_last_kernels().decode())
+    assert "conv=1" in res["1"][3] and "conv=1" not in res["0"][3], (res["1"][3], res["0"][3])
+    for i, nm in enumerate(["out", "final state", "conv state"]):
+        assert torch.equal(res["1"][i], res["0"][i]), (nm, rel(res["1"][i], res["0"][i]))
+    # against the oracle: conv + SiLU (rounded to bf16 like the conv kernel's output), scan, gated norm
+    z, xBC, dt = torch.split(zxbcdt, [d_ssm, Ct, H], dim=-1)
+    xc = O.causal_conv1d_ref(xBC.transpose(1, 2).float(), cw, cb, activation="silu").transpose(1, 2).bfloat16()
+    x, Bm, Cm = torch.split(xc, [d_ssm, G * N, G * N], dim=-1)
+    y, f0 = O.ssd_ref_sequential(x.unflatten(-1, (H, P)), dt, A, Bm.unflatten(-1, (G, N)), Cm.unflatten(-1, (G, N)), D=D, dt_bias=dtb, dt_softplus=True,
+                                 return_final_states=True)
+    ref = O.rmsnorm_gated_ref(y.flatten(-2).float(), nw, z=z.float(), eps=1e-5, group_size=d_ssm // G, norm_before_gate=False)
+    assert rel(res["1"][0], ref) < 8e-3 and rel(res["1"][1], f0) < 1e-3, (rel(res["1"][0], ref), rel(res["1"][1], f0))
+    want_cs = torch.nn.functional.pad(xBC.transpose(1, 2).float(), (max(4 - L, 0), 0))[..., -4:]
+    assert torch.equal(res["1"][2], want_cs)
