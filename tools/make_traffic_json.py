@@ -47,7 +47,7 @@ def busy(ks):
 method = ("rocprofv3 --pmc in separate passes with --kernel-trace only (tools/pmc_r06.sh); FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section), "
           "WRITE_SIZE as reported; dt' preparation launch included; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
 dtp = pick("ssd_dt_prep")
-plain, train, dx = pick("ssd_a8_kernel<0, false, false, false>"), pick("ssd_a8_kernel<0, true, false, false>"), pick("ssd_a8_kernel<2, true, false, false>")
+plain, train, dx = pick("ssd_a8_kernel<0, false, false, false, false>"), pick("ssd_a8_kernel<0, true, false, false, false>"), pick("ssd_a8_kernel<2, true, false, false, false>")
 cp, fold, fin = pick("ssd_cp_kernel"), pick("ssd_cp_fold_kernel", optional=True), pick("ssd_bwd_finish_par_kernel")   # no fold launch when ssd_cp stores bf16 dB / dC itself
 fwd = {
     "kernel": "ssd_a8_kernel<GS_Y, DUMP=false, KHILO=false> (+ ssd_dt_prep_vec_kernel)", "kernel_ids": ids["fwd"],
