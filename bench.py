@@ -141,6 +141,16 @@ def selscan_cfg1(dev):
             out[f"hip_B{rep * Bsz}_channel_last"] = {"value": round(rep * Bsz * L * Dm / (ms * 1e-3) / 1e6, 1), "unit": "M-elements/s", "launch_ms": round(ms, 4),
                                                      "algorithmic_bytes": nb, "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1),
                                                      "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # forward + backward on the same channel-last views (round 6: selscan_bwd_lanes_kernel walks them as they lie; until then the
+            # backward made L-contiguous copies for the chunked scan)
+            lcl = [t.detach().clone().requires_grad_() for t in cl]
+            gcl = torch.randn_like(got_cl)
+
+            def fb_cl():
+                for t in lcl:
+                    t.grad = None
+                selective_scan_fn(*lcl, True).backward(gcl)
+            out[f"hip_B{rep * Bsz}_channel_last"]["fwd_bwd_ms"] = round(timed(fb_cl, 20, 3), 4)
     return out
 
 

@@ -203,6 +203,10 @@ typedef struct {
   size_t workspace_bytes;
   int32_t delta_softplus;
 } OmkSelScanBwd;
+/* ABI 6: which form omk_selective_scan_bwd takes on these views: 2 = the lanes-are-channels reverse sweep on channel-last (B, L, D) views
+ * as they lie (input-dependent B / C of u's dtype, d_state <= 16, enough sequences to fill the chip), 1 = the chunked scan (L-contiguous rows),
+ * 0 = the per-channel kernel.  The host mirror asks before it decides about L-contiguous copies (omk_selective_scan_fwd_form's twin). */
+int omk_selective_scan_bwd_form(const OmkSelScanBwd* p);
 size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p);
 int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream);   /* L-contiguous rows, variable B / C, L >= 64, 8 | channels
                                                                              per group: d_state <= 64; other layouts: d_state <= 16 */

@@ -100,7 +100,7 @@ SYMBOLS = [
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
     "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
-    "omk_selective_scan_fwd", "omk_selective_scan_fwd_form", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
+    "omk_selective_scan_fwd", "omk_selective_scan_fwd_form", "omk_selective_scan_bwd_form", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd_window_states_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",
     "omk_cross_entropy", "omk_lora_up_bwd_parts", "omk_sample",
 ]
@@ -119,7 +119,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
         if s.endswith("_workspace_bytes") or s.endswith("_window_states_bytes"):
             fn.restype = C.c_size_t
             fn.argtypes = [C.c_void_p]
-        elif s == "omk_selective_scan_fwd_form":
+        elif s in ("omk_selective_scan_fwd_form", "omk_selective_scan_bwd_form"):
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p]
         elif s == "omk_lora_up_bwd_parts":

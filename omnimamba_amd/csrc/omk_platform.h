@@ -366,6 +366,58 @@ template <int N> __device__ __forceinline__ void wave_multi_sum(float (&v)[N]) {
   WaveMultiSum<N, 32>::run(v, lane_id());
 }
 
+// The same totals for 32 values WITHOUT the LDS crossbar: behind __shfl_xor every halving step was a ds_bpermute with its own
+// s_waitcnt (32 round trips per call: ~3 k cycles in selscan_bwd_lanes_kernel).  Steps 32 and 16 are register swaps between lane halves
+// (v_permlane32_swap / v_permlane16_swap: the pair of values a lane keeps / sends IS the swap), steps 8 .. 1 DPP row operations folded into
+// the add.  On return v[0] of lane L is the total of the value with index L >> 1 (as wave_multi_sum<32>).
+__device__ __forceinline__ void wave_sum32(float (&v)[32]) {
+#ifdef OMK_EMU
+  wave_multi_sum<32>(v);
+#else
+  const int lane = lane_id();
+  // (the two halves of the builtin's result are taken apart through the inline asm below: written as r[0] + r[1] the compiler added the first
+  // result to itself -- tools/probe/wave_sum32_probe.hip)
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    float x = v[i], y = v[i + 16];
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    v[i] = x + y;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float x = v[i], y = v[i + 8];
+    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    v[i] = x + y;
+  }
+#define OMK_DPP_MOV(x, ctrl, bank) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, bank, false))
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+      v[i] = keep + OMK_DPP_MOV(send, 0x128, 0xf);                       // row_ror:8 = lane ^ 8 inside a row of 16
+    }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+      const int lo = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x104, 0xf, 0x5, false);     // row_shl:4 -> banks 0, 2 read lane + 4
+      const int x4 = __builtin_amdgcn_update_dpp(lo, __builtin_bit_cast(int, send), 0x114, 0xf, 0xa, false);    // row_shr:4 -> banks 1, 3 read lane - 4
+      v[i] = keep + __builtin_bit_cast(float, x4);
+    }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+    const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + OMK_DPP_MOV(send, 0x4e, 0xf);                          // quad_perm [2, 3, 0, 1]
+  }
+  v[0] += OMK_DPP_MOV(v[0], 0xb1, 0xf);                                  // quad_perm [1, 0, 3, 2]
+#undef OMK_DPP_MOV
+#endif
+}
+
 __device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }

@@ -21,6 +21,7 @@ struct SsArgs {
   const void* u; const void* delta; const void* A; const void* Bm; const void* Cm; const void* D; const void* z; const void* dbias;
   void* out; float* last;
   float* ckpt; int TLB, nTB;   // optional: state at the start of every TLB-token tile, (B, D, nTB, N) f32 (backward)
+  int ckpt_cl;                 // the checkpoints as (B, nTB, N, D) instead: adjacent lanes = adjacent channels (the lanes = channels backward)
   int64_t usb, usd, usl, dsb, dsd, dsl, zsb, zsd, zsl, osb, osd, osl;
   int64_t Asd, Asn, Bsb, Bsg, Bsn, Bsl, Csb, Csg, Csn, Csl;   // for constant B/C: Bsg = stride over d, Bsn over n
   int B, Dm, L, N, G, DT, softplus, Bvar, Cvar, adt, bdt, cdt, ddt, dbdt;
@@ -633,10 +634,17 @@ __global__ __launch_bounds__(64) void selscan_fwd_lanes_kernel(SsArgs a) {
   };
   auto checkpoint = [&](int l0) {   // state in front of token l0 (a multiple of a.TLB): what the chunked backward restarts from
     if (a.ckpt && live && (l0 % a.TLB) == 0) {
-      float* cp = a.ckpt + (((int64_t)b * a.Dm + d) * a.nTB + l0 / a.TLB) * a.N;
+      if (a.ckpt_cl) {
+        float* cp = a.ckpt + (((int64_t)b * a.nTB + l0 / a.TLB) * a.N) * a.Dm + d;
 #pragma unroll
-      for (int n = 0; n < 16; n++)
-        if (n < a.N) cp[n] = x2[n >> 1][n & 1];
+        for (int n = 0; n < 16; n++)
+          if (n < a.N) cp[(int64_t)n * a.Dm] = x2[n >> 1][n & 1];
+      } else {
+        float* cp = a.ckpt + (((int64_t)b * a.Dm + d) * a.nTB + l0 / a.TLB) * a.N;
+#pragma unroll
+        for (int n = 0; n < 16; n++)
+          if (n < a.N) cp[n] = x2[n >> 1][n & 1];
+      }
     }
   };
 
@@ -818,6 +826,7 @@ struct SsBwdArgs {
   int64_t dBsb, dBsg, dBsn, dBsl, dCsb, dCsg, dCsn, dCsl;   // variable: (B, G, N, L); constant: dBsg = stride over d, dBsn over n
   int NB, nOct;   // chunked form: state indices per LDS block, channel tiles per workgroup
   int dbg;        // developer ablation bits (OMK_SELSCAN_BWD_DBG): 2 no flush atomics, 4 no n loop
+  uint32_t xg, xdu, xdd, xdz;   // lanes = channels form: bytes one batch element of dout / du / ddelta / dz spans (buffer ranges)
 };
 
 template <class T>
@@ -1202,6 +1211,250 @@ __global__ __launch_bounds__(1024) void selscan_bwd_chunked_kernel(SsBwdArgs q) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// backward for MANY sequences on CHANNEL-LAST storage: lanes = channels, one reverse sweep (round 6; the forward's twin,
+// selscan_fwd_lanes_kernel).  The module keeps (B, L, D) activations as the in_proj GEMM leaves them
+// (/root/reference/models/stage2/mixer_seq_simple.py:16,197-205 builds the mixer; mamba_simple.py here); until now their backward made
+// L-contiguous copies for the chunked scan (3.3 ms forward + backward at batch 64) or took the per-channel kernel above (33 ms).
+//   one wave = 64 adjacent channels of one (batch, group); a lane owns its channel's d_state <= 16 adjoint states G, its dA row and the
+//   running sums of dD / d(delta_bias), and walks the sequence backwards in tiles of 16 tokens (= the checkpoint spacing SSB_TL of pass 1,
+//   which is the forward lanes kernel without output, checkpoints stored (B, tile, n, D): a lane reads ITS element of a 256-byte row);
+//   a tile is two sub-tiles of 8 tokens: the forward recurrence is re-run from the checkpoint -- 8 tokens to reach the second sub-tile,
+//   then each sub-tile once more with p_t = a_t x_{t-1} parked in wave-private LDS (16 float4 rows x 8 tokens x 64 lanes = 32 KB; four
+//   workgroups of one wave per CU) -- and the adjoint step of a token reads p_t back: 1.5 forward steps + one adjoint step per token;
+//   B_t / C_t are broadcasts out of a wave-private LDS tile like in the forward; dB_t / dC_t (sums over the channels of the group) leave
+//   the wave through a 32-value butterfly (wave_sum32: lane-half swaps + DPP, no LDS) and one float atomic per value and token.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SBL_T = SSB_TL, SBL_S = 8;
+static_assert(SBL_T == 2 * SBL_S && SBL_T == SCL_TB, "a tile = two sub-tiles = one block of the forward lanes kernel");
+
+template <class T>
+__global__ __launch_bounds__(64) void selscan_bwd_lanes_kernel(SsBwdArgs q) {
+  const SsArgs& a = q.f;
+  __shared__ __attribute__((aligned(16))) float sB[SBL_T * SCL_SB];
+  __shared__ __attribute__((aligned(16))) float sC[SBL_T * SCL_SB];
+  __shared__ __attribute__((aligned(16))) f32x4 sP[SBL_S * 4 * 64];
+  __shared__ float sRed[SBL_S * 32];
+  __shared__ float sDl[SBL_T * 64];   // delta (softplus applied) of the tile's tokens, [token][lane]
+  constexpr uint32_t ES = sizeof(T);
+  constexpr float LN2 = 0.6931471805599453f;
+  const int lane = threadIdx.x;
+  const int dpg = a.Dm / a.G, tpg = (dpg + 63) / 64;
+  const int tg = blockIdx.x % tpg, g = (blockIdx.x / tpg) % a.G, b = blockIdx.x / (tpg * a.G);
+  const int d0 = g * dpg + tg * 64;
+  const int nd = (dpg - tg * 64) < 64 ? (dpg - tg * 64) : 64;
+  const bool live = lane < nd;
+  const int d = d0 + (live ? lane : 0);
+  float A2[16], G[16], dAa[16];
+#pragma unroll
+  for (int n = 0; n < 16; n++) {
+    A2[n] = n < a.N ? load_rt(a.A, (int64_t)d * a.Asd + (int64_t)n * a.Asn, a.adt) * LOG2E : 0.f;
+    G[n] = 0.f; dAa[n] = 0.f;
+  }
+  const float Dv = a.D ? load_rt(a.D, d, a.ddt) : 0.f;
+  const float db = a.dbias ? load_rt(a.dbias, d, a.dbdt) : 0.f;
+  const bool hasz = a.z != nullptr;
+  float dDa = 0.f, dba = 0.f;
+  const BufRes Ur = make_buf((const T*)a.u + (int64_t)b * a.usb, a.xu), Dr = make_buf((const T*)a.delta + (int64_t)b * a.dsb, a.xd);
+  const BufRes Zr = make_buf(hasz ? (const T*)a.z + (int64_t)b * a.zsb : nullptr, hasz ? a.xz : 0u);
+  const BufRes Gr = make_buf((const T*)q.dout + (int64_t)b * q.gsb, q.xg);
+  const BufRes DUr = make_buf((T*)q.du + (int64_t)b * q.dusb, q.xdu), DDr = make_buf((T*)q.ddelta + (int64_t)b * q.ddsb, q.xdd);
+  const BufRes DZr = make_buf(hasz ? (T*)q.dz + (int64_t)b * q.dzsb : nullptr, hasz ? q.xdz : 0u);
+  const BufRes Br = make_buf((const T*)a.Bm + (int64_t)b * a.Bsb + (int64_t)g * a.Bsg, a.xB);
+  const BufRes Cr = make_buf((const T*)a.Cm + (int64_t)b * a.Csb + (int64_t)g * a.Csg, a.xC);
+  const uint32_t lch = (uint32_t)(d0 + lane);
+  const uint32_t uvo = live ? ES * lch * (uint32_t)a.usd : SCL_OOR, dvo = live ? ES * lch * (uint32_t)a.dsd : SCL_OOR;
+  const uint32_t zvo = (live && hasz) ? ES * lch * (uint32_t)a.zsd : SCL_OOR, gvo = live ? ES * lch * (uint32_t)q.gsd : SCL_OOR;
+  const uint32_t duvo = live ? ES * lch * (uint32_t)q.dusd : SCL_OOR, ddvo = live ? ES * lch * (uint32_t)q.ddsd : SCL_OOR;
+  const uint32_t dzvo = (live && hasz) ? ES * lch * (uint32_t)q.dzsd : SCL_OOR;
+  // B / C rows of a tile: 16 tokens x 16 states = four elements per lane and array (the forward's scheme)
+  const int r4 = lane >> 4, t16 = lane & 15;
+  const bool bl = a.Bsl == 1, cl = a.Csl == 1;
+  const uint32_t bvo = ES * (bl ? (uint32_t)r4 * (uint32_t)a.Bsn + (uint32_t)t16 * (uint32_t)a.Bsl : (uint32_t)t16 * (uint32_t)a.Bsn + (uint32_t)r4 * (uint32_t)a.Bsl);
+  const uint32_t cvo = ES * (cl ? (uint32_t)r4 * (uint32_t)a.Csn + (uint32_t)t16 * (uint32_t)a.Csl : (uint32_t)t16 * (uint32_t)a.Csn + (uint32_t)r4 * (uint32_t)a.Csl);
+  const uint32_t bks = ES * 4u * (uint32_t)(bl ? a.Bsn : a.Bsl), cks = ES * 4u * (uint32_t)(cl ? a.Csn : a.Csl);
+  const int blo = bl ? t16 * SCL_SB + r4 : r4 * SCL_SB + t16, bls = bl ? 4 : 4 * SCL_SB;
+  const int clo = cl ? t16 * SCL_SB + r4 : r4 * SCL_SB + t16, cls = cl ? 4 : 4 * SCL_SB;
+  float* dBb = q.dB + (int64_t)b * q.dBsb + (int64_t)g * q.dBsg;
+  float* dCb = q.dC + (int64_t)b * q.dCsb + (int64_t)g * q.dCsg;
+  const int nT = (a.L + SBL_T - 1) / SBL_T;
+
+  const uint32_t usl_ = ES * (uint32_t)a.usl, dsl_ = ES * (uint32_t)a.dsl, zsl_ = hasz ? ES * (uint32_t)a.zsl : 0u, gsl_ = ES * (uint32_t)q.gsl;
+  auto softplus_of = [&](uint32_t raw, int t) -> float {   // delta of token t (zero behind the end of the sequence: the identity step)
+    float v = raw_to_f32<T>(raw) + db;
+    if (a.softplus) v = v > 20.f ? v : LN2 * log2_fast(1.f + exp2_fast(v * LOG2E));
+    return t < a.L ? v : 0.f;
+  };
+  // The token loops are REAL loops (one token per iteration, the 16 states unrolled inside): unrolled over a sub-tile the compiler kept the
+  // rows and inputs of all eight tokens alive at once -- 512 registers + 378 spilled, 6.6 k cycles per token.  A token's inputs are
+  // requested one iteration ahead (they hit L2: the tile's rows were touched by the sweep before).
+  // (two tokens per iteration on two sets of input registers, each refilled right behind its use: with one set the loop-carried value is a
+  // register copy at the back edge, and the copy a wait for the load just issued)
+  // ---- forward steps of tokens l0 + k0 .. + 7 from state h; PARK: p_t = a_t x_{t-1} into LDS for the adjoint steps
+  auto sweep = [&](float (&h)[16], int l0, int k0, auto park_c) {
+    constexpr bool PARK = decltype(park_c)::value;
+    auto step = [&](int k, uint32_t cu) OMK_ALWAYS_INLINE_LAMBDA {
+      const float dlt = sDl[(k0 + k) * 64 + lane], du_ = dlt * raw_to_f32<T>(cu);
+      const f32x4* rb = reinterpret_cast<const f32x4*>(&sB[(k0 + k) * SCL_SB]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4 b4 = rb[j];
+        f32x4 pv;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int n = 4 * j + e;
+          const float pn = exp2_fast(dlt * A2[n]) * h[n];
+          pv[e] = pn;
+          h[n] = fmaf(du_, b4[e], pn);
+        }
+        if (PARK) sP[(k * 4 + j) * 64 + lane] = pv;
+      }
+    };
+    const uint32_t t0 = (uint32_t)(l0 + k0);
+    uint32_t ua = buf_ld_raw<T>(Ur, uvo, usl_ * t0), ub = buf_ld_raw<T>(Ur, uvo, usl_ * (t0 + 1u));
+#pragma unroll 1
+    for (int k = 0; k < SBL_S; k += 2) {
+      step(k, ua);
+      OMK_SCHED_FENCE();
+      ua = buf_ld_raw<T>(Ur, uvo, usl_ * (t0 + (uint32_t)k + 2u));       // (behind the end of the batch element's range: zeros)
+      step(k + 1, ub);
+      OMK_SCHED_FENCE();
+      ub = buf_ld_raw<T>(Ur, uvo, usl_ * (t0 + (uint32_t)k + 3u));
+    }
+  };
+  // ---- adjoint steps of tokens l0 + k0 + 7 .. l0 + k0 (p_t of each from LDS); the dB / dC rows of the sub-tile collect in LDS and leave
+  // as four atomic instructions behind the loop (one atomic per token inside it made every iteration wait for the atomic's round trip:
+  // the load counter returns in order)
+  auto adjoint = [&](int l0, int k0) {
+    auto step = [&](int kk, uint32_t cu, uint32_t cz, uint32_t cg) OMK_ALWAYS_INLINE_LAMBDA {
+      const int k = k0 + kk, t = l0 + k;
+      const float go = raw_to_f32<T>(cg), dlt = sDl[k * 64 + lane], u_ = raw_to_f32<T>(cu);
+      const float zv = raw_to_f32<T>(cz), sg = sigmoid_fast(zv);
+      const float dy = hasz ? go * zv * sg : go;
+      dDa = fmaf(dy, u_, dDa);
+      float sbg = 0.f, sgap = 0.f, ych = 0.f;
+      float red[32];
+      const float dlu = dlt * u_;
+      const f32x4* rb = reinterpret_cast<const f32x4*>(&sB[k * SCL_SB]);
+      const f32x4* rc = reinterpret_cast<const f32x4*>(&sC[k * SCL_SB]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4 pv = sP[(kk * 4 + j) * 64 + lane], b4 = rb[j], c4 = rc[j];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int n = 4 * j + e;
+          const float gn = fmaf(c4[e], dy, G[n]);              // g_t
+          sbg = fmaf(b4[e], gn, sbg);
+          const float gp = gn * pv[e];
+          sgap = fmaf(gp, A2[n], sgap);
+          dAa[n] = fmaf(gp, dlt, dAa[n]);
+          const float xn = fmaf(dlu, b4[e], pv[e]);             // x_t[n]
+          ych = fmaf(c4[e], xn, ych);
+          red[n] = gn * dlu;                                    // dB_t[n] of this channel
+          red[16 + n] = dy * xn;                                // dC_t[n]
+          G[n] = exp2_fast(dlt * A2[n]) * gn;                   // a_t g_t: what token t - 1 adds its C dy to
+        }
+      }
+      if (hasz) buf_st_t<T>(DZr, go * fmaf(Dv, u_, ych) * sg * (1.f + zv * (1.f - sg)), dzvo, ES * (uint32_t)t * (uint32_t)q.dzsl);
+      buf_st_t<T>(DUr, fmaf(dlt, sbg, Dv * dy), duvo, ES * (uint32_t)t * (uint32_t)q.dusl);
+      float ddr = fmaf(sgap, LN2, u_ * sbg);
+      if (a.softplus) ddr *= 1.f - exp2_fast(-dlt * LOG2E);     // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      ddr = t < a.L ? ddr : 0.f;
+      dba += ddr;
+      buf_st_t<T>(DDr, ddr, ddvo, ES * (uint32_t)t * (uint32_t)q.ddsl);
+      if (!live) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) red[i] = 0.f;
+      }
+      wave_sum32(red);               // lane L: total of value L >> 1
+      if ((lane & 1) == 0) sRed[kk * 32 + (lane >> 1)] = red[0];
+    };
+    const int tl = l0 + k0 + SBL_S - 1;
+    auto ld3 = [&](int t, uint32_t& ru, uint32_t& rz, uint32_t& rg) OMK_ALWAYS_INLINE_LAMBDA {
+      const uint32_t tt = (uint32_t)(t > 0 ? t : 0);
+      ru = buf_ld_raw<T>(Ur, uvo, usl_ * tt); rz = buf_ld_raw<T>(Zr, zvo, zsl_ * tt); rg = buf_ld_raw<T>(Gr, gvo, gsl_ * tt);
+    };
+    uint32_t ua, za, ga, ub, zb, gb;
+    ld3(tl, ua, za, ga);
+    ld3(tl - 1, ub, zb, gb);
+#pragma unroll 1
+    for (int kk = SBL_S - 1; kk >= 0; kk -= 2) {
+      step(kk, ua, za, ga);
+      OMK_SCHED_FENCE();
+      ld3(l0 + k0 + kk - 2, ua, za, ga);
+      step(kk - 1, ub, zb, gb);
+      OMK_SCHED_FENCE();
+      ld3(l0 + k0 + kk - 3, ub, zb, gb);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int idx = lane + 64 * r, kk = idx >> 5, j = idx & 31, n = j & 15, t = l0 + k0 + kk;
+      if (t < a.L && n < a.N) {
+        const float v = sRed[idx];
+        if (j < 16) atomic_add_f32(dBb + (int64_t)n * q.dBsn + (int64_t)t * q.dBsl, v);
+        else atomic_add_f32(dCb + (int64_t)n * q.dCsn + (int64_t)t * q.dCsl, v);
+      }
+    }
+  };
+
+  for (int ti = nT - 1; ti >= 0; ti--) {
+    const int l0 = ti * SBL_T;
+    // ---- B / C rows of the tile into the wave-private LDS tile, the checkpoint in front of the tile
+    uint32_t pb[4], pc[4];
+    {
+      const uint32_t sb0 = ES * (uint32_t)l0 * (uint32_t)a.Bsl, sc0 = ES * (uint32_t)l0 * (uint32_t)a.Csl;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        pb[k] = buf_ld_raw<T>(Br, bvo, sb0 + (uint32_t)k * bks);
+        pc[k] = buf_ld_raw<T>(Cr, cvo, sc0 + (uint32_t)k * cks);
+      }
+    }
+    float hs[16], h[16];
+    {
+      const float* cp = a.ckpt + (((int64_t)b * a.nTB + ti) * a.N) * a.Dm + d;
+#pragma unroll
+      for (int n = 0; n < 16; n++) hs[n] = (n < a.N && live) ? cp[(int64_t)n * a.Dm] : 0.f;
+    }
+    // delta of the tile's 16 tokens: sixteen loads in flight, sixteen independent softplus chains, parked in LDS -- inside a token step the
+    // chain (load -> exp -> log -> sixteen exps) was 300 - 400 cycles of latency nothing else in a one-wave-per-SIMD kernel covers
+    uint32_t rdl[SBL_T];
+#pragma unroll
+    for (int k = 0; k < SBL_T; k++) rdl[k] = buf_ld_raw<T>(Dr, dvo, dsl_ * (uint32_t)(l0 + k));
+    wave_lds_sync();   // the previous tile's broadcast reads before the new rows
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool okb = (bl ? r4 + 4 * k : t16) < a.N, okc = (cl ? r4 + 4 * k : t16) < a.N;
+      sB[blo + k * bls] = okb ? raw_to_f32<T>(pb[k]) : 0.f;
+      sC[clo + k * cls] = okc ? raw_to_f32<T>(pc[k]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < SBL_T; k++) sDl[k * 64 + lane] = softplus_of(rdl[k], l0 + k);
+    wave_lds_sync();
+    // second sub-tile first: the first one's forward steps lead to its start state
+#pragma unroll
+    for (int n = 0; n < 16; n++) h[n] = hs[n];
+    sweep(h, l0, 0, std::false_type{});
+    sweep(h, l0, SBL_S, std::true_type{});
+    wave_lds_sync();
+    adjoint(l0, SBL_S);
+    wave_lds_sync();
+#pragma unroll
+    for (int n = 0; n < 16; n++) h[n] = hs[n];
+    sweep(h, l0, 0, std::true_type{});
+    wave_lds_sync();
+    adjoint(l0, 0);
+  }
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < 16; n++)
+      if (n < a.N) atomic_add_f32(q.dA + (int64_t)d * a.N + n, dAa[n]);
+    if (q.dD) atomic_add_f32(q.dD + d, dDa);
+    if (q.ddb) atomic_add_f32(q.ddb + d, dba);
+  }
+}
+
 }  // namespace omk
 
 using namespace omk;
@@ -1232,6 +1485,15 @@ static int ss_fill(SsArgs& a, const OmkTensor& u, const OmkTensor& delta, const 
   else { a.Csg = Cm.stride[0]; a.Csn = Cm.stride[1]; }
   a.softplus = softplus; a.adt = A.dtype; a.bdt = Bm.dtype; a.cdt = Cm.dtype; a.ddt = D.dtype; a.dbdt = dbias.dtype;
   return OMK_OK;
+}
+
+// OmkSelScan{Fwd,Bwd}::pass_states comes in two forms: (B, D, ceil(L / 512), N) -- the state in front of every 512-token pass, for the chunked
+// backward -- and (B, ceil(L / 16), N, D) -- in front of every 16-token tile with the channels innermost, for the lanes = channels backward
+static bool ss_tile_states(const OmkTensor& t, int B, int Dm, int L, int N) {
+  if (!present(t) || t.ndim != 4 || t.dtype != OMK_F32 || !is_dense(t)) return false;
+  const int nT = (L + SBL_T - 1) / SBL_T, nP = (L + SSR_TP - 1) / SSR_TP;
+  if (t.shape[0] == B && t.shape[1] == Dm && t.shape[2] == nP && t.shape[3] == N) return false;   // the chunked form
+  return t.shape[0] == B && t.shape[1] == nT && t.shape[2] == N && t.shape[3] == Dm;
 }
 
 // The lanes = channels sweep (selscan_fwd_lanes_kernel) takes the call when it applies and the batch fills the chip by itself:
@@ -1327,7 +1589,10 @@ extern "C" int omk_selective_scan_fwd(const OmkSelScanFwd* p, omk_stream stream)
   a.out = p->out.data; a.last = (float*)p->last_state.data;
   a.osb = p->out.stride[0]; a.osd = p->out.stride[1]; a.osl = p->out.stride[2];
   if ((int64_t)a.B * a.Dm * a.L == 0) return OMK_OK;
-  if (present(p->pass_states)) {
+  if (ss_tile_states(p->pass_states, a.B, a.Dm, a.L, a.N)) {
+    a.ckpt = (float*)p->pass_states.data; a.TLB = SBL_T; a.nTB = (a.L + SBL_T - 1) / SBL_T; a.ckpt_cl = 1;
+    if (ss_lanes_form(a, p->u.dtype) != 2) return fail(OMK_EUNSUPPORTED, "selective_scan_fwd: tile states (B, ceil(L / 16), N, D) belong to the lanes = channels form (channel-last views, d_state <= 16)");
+  } else if (present(p->pass_states)) {
     const int nP = (a.L + SSR_TP - 1) / SSR_TP;
     OMK_REQUIRE(p->pass_states.dtype == OMK_F32 && is_dense(p->pass_states) && numel(p->pass_states) == (int64_t)a.B * a.Dm * nP * a.N,
                 "selective_scan_fwd: pass_states must be contiguous f32 (B, D, ceil(L / 512), N)");
@@ -1352,6 +1617,43 @@ extern "C" int omk_selective_scan_fwd_form(const OmkSelScanFwd* p) {
   const bool lcontig = a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && a.osl == 1 && (!a.Bvar || a.Bsl == 1) && (!a.Cvar || a.Csl == 1) &&
                        a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
   return lcontig ? 1 : 0;
+}
+
+// channel-last views of everything, input-dependent B / C of u's dtype, d_state <= 16, and as many waves as the forward's lanes form asks
+// for: fills the buffer ranges of both kernels.  q.f and the gradient strides must be filled.
+static bool ss_bwd_lanes_applies(SsBwdArgs& q, const OmkSelScanBwd* p, int udt) {
+  SsArgs& a = q.f;
+  if ((present(p->pass_states) && !ss_tile_states(p->pass_states, a.B, a.Dm, a.L, a.N)) || !a.Bvar || !a.Cvar || a.N > 16 || a.bdt != udt || a.cdt != udt) return false;
+  const bool z = a.z != nullptr;
+  if (!(a.usd == 1 && a.dsd == 1 && (!z || (a.zsd == 1 && q.dzsd == 1)) && q.gsd == 1 && q.dusd == 1 && q.ddsd == 1)) return false;
+  if (a.Dm == 1) return false;   // (a single channel is both layouts: the chunked form takes it)
+  SsArgs probe = a;              // the forward's criteria (spans, number of waves, OMK_SELSCAN_LANES) on an output laid out like u
+  probe.out = const_cast<void*>(a.u); probe.osb = a.usb; probe.osd = a.usd; probe.osl = a.usl; probe.ckpt = nullptr;
+  if (ss_lanes_form(probe, udt) != 2) return false;
+  a.xu = probe.xu; a.xd = probe.xd; a.xz = probe.xz; a.xB = probe.xB; a.xC = probe.xC; a.xo = 0u;
+  const int64_t es = (int64_t)dtype_size(udt), lim = (int64_t)1 << 31;
+  auto ext = [&](int64_t sd, int64_t sl) -> int64_t { return (sd < 0 || sl < 0) ? lim : es * (((int64_t)a.Dm - 1) * sd + ((int64_t)a.L - 1) * sl + 1); };
+  const int64_t eg = ext(q.gsd, q.gsl), eu = ext(q.dusd, q.dusl), ed = ext(q.ddsd, q.ddsl), ez = z ? ext(q.dzsd, q.dzsl) : 0;
+  if (eg >= lim || eu >= lim || ed >= lim || ez >= lim) return false;
+  q.xg = (uint32_t)eg; q.xdu = (uint32_t)eu; q.xdd = (uint32_t)ed; q.xdz = (uint32_t)ez;
+  return true;
+}
+
+// 2: omk_selective_scan_bwd would run the lanes = channels reverse sweep on these (channel-last) views as they lie; 0 / 1: it wants the
+// L-contiguous rows of the chunked form (1) or falls to the per-channel kernel (0) -- the host mirror decides about copies with it
+extern "C" int omk_selective_scan_bwd_form(const OmkSelScanBwd* p) {
+  if (!p || !present(p->dout) || !present(p->du) || !present(p->ddelta)) return fail(OMK_EINVAL, "selective_scan_bwd_form: dout, du, ddelta required");
+  SsBwdArgs q = {};
+  int rc = ss_fill(q.f, p->u, p->delta, p->A, p->Bm, p->Cm, p->D, p->z, p->delta_bias, p->delta_softplus, "selective_scan_bwd_form");
+  if (rc) return rc;
+  if (p->dout.ndim != 3 || p->du.ndim != 3 || p->ddelta.ndim != 3) return 0;
+  q.gsd = p->dout.stride[1]; q.gsl = p->dout.stride[2]; q.dusd = p->du.stride[1]; q.dusl = p->du.stride[2];
+  q.ddsd = p->ddelta.stride[1]; q.ddsl = p->ddelta.stride[2];
+  if (present(p->dz)) { q.dzsd = p->dz.stride[1]; q.dzsl = p->dz.stride[2]; }
+  if (ss_bwd_lanes_applies(q, p, p->u.dtype)) return 2;
+  const SsArgs& a = q.f;
+  const bool lc = a.Bvar && a.Cvar && a.usl == 1 && a.dsl == 1 && (!a.z || a.zsl == 1) && q.gsl == 1 && a.Bsl == 1 && a.Csl == 1 && a.L >= 64;
+  return lc ? 1 : 0;
 }
 
 extern "C" size_t omk_selective_scan_bwd_workspace_bytes(const OmkSelScanBwd* p) {
@@ -1389,11 +1691,24 @@ extern "C" int omk_selective_scan_bwd(const OmkSelScanBwd* p, omk_stream stream)
   if (a.Cvar) { q.dCsb = p->dC.stride[0]; q.dCsg = p->dC.stride[1]; q.dCsn = p->dC.stride[2]; q.dCsl = p->dC.stride[3]; }
   else { q.dCsg = p->dC.stride[0]; q.dCsn = p->dC.stride[1]; }
   const int dpg = a.Dm / a.G;
+  // ---- channel-last storage with enough sequences to fill the chip: the lanes = channels reverse sweep (selscan_bwd_lanes_kernel)
+  if (ss_bwd_lanes_applies(q, p, udt)) {
+    a.ckpt = (float*)p->workspace; a.TLB = SBL_T; a.nTB = (a.L + SBL_T - 1) / SBL_T; a.ckpt_cl = 1;
+    dim3 grid((unsigned)((int64_t)a.B * a.G * ((dpg + 63) / 64))), block(64);
+    if (present(p->pass_states)) a.ckpt = (float*)p->pass_states.data;   // (the training forward left them: no pass 1)
+    else {   // pass 1: the forward sweep once more, no output, the state in front of every 16-token tile as (B, tile, n, D)
+      SsArgs f = a;
+      f.out = nullptr; f.xo = 0u; f.last = nullptr; f.z = nullptr; f.xz = 0u; f.D = nullptr;
+      OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_fwd_lanes_kernel<T, false>), grid, block, 0, stream, f));
+    }
+    OMK_DISPATCH_DTYPE(udt, T, OMK_LAUNCH((selscan_bwd_lanes_kernel<T>), grid, block, 0, stream, q));
+    return finish_launch("selective_scan_bwd");
+  }
   // ---- L-contiguous storage, input-dependent B and C of u's dtype: the chunked associative scan in both directions
   const bool chunked = a.Bvar && a.Cvar && a.usl == 1 && a.dsl == 1 && (!a.z || (a.zsl == 1 && q.dzsl == 1)) && q.gsl == 1 && q.dusl == 1 &&
                        q.ddsl == 1 && a.Bsl == 1 && a.Csl == 1 && a.bdt == udt && a.cdt == udt && a.adt == OMK_F32 && dpg % 8 == 0 &&
                        a.L >= 64 && !getenv("OMK_SELSCAN_SEQ");
-  OMK_REQUIRE(!present(p->pass_states) || chunked, "selective_scan_bwd: pass_states belong to the chunked form (L-contiguous rows, variable B / C, L >= 64)");
+  OMK_REQUIRE(!present(p->pass_states) || chunked, "selective_scan_bwd: pass_states belong to the chunked form (L-contiguous rows, variable B / C, L >= 64) or, as tile states, to the lanes = channels form");
   if (chunked) {
     a.TLB = SSR_TP; a.nTB = (a.L + SSR_TP - 1) / SSR_TP;
     if (present(p->pass_states)) {

@@ -40,6 +40,7 @@ class SelectiveScanFn(torch.autograd.Function):
                                  delta_softplus=int(delta_softplus))
             if lib.omk_selective_scan_fwd_form(_C.byref(probe)) == 2:
                 out = o
+        took_lanes = out is not None
         if out is None and L >= 64:
             # the chunked associative scan wants L-contiguous rows (lanes = time): one copy pass here costs far less than the per-channel
             # sequential kernel
@@ -54,7 +55,12 @@ class SelectiveScanFn(torch.autograd.Function):
         # a backward will follow and the chunked form applies: keep the state in front of every 512-token pass (B D L / 512 N floats) --
         # the backward then needs no second forward pass
         ps = None
-        if (L >= 64 and any(ctx.needs_input_grad) and B4.dim() == 4 and C4.dim() == 4 and B4.dtype == u.dtype and C4.dtype == u.dtype and
+        lanes_fwd = took_lanes and B4.dim() == 4 and C4.dim() == 4 and A.shape[1] <= 16
+        if lanes_fwd and any(ctx.needs_input_grad) and u.numel() > 0 and not os.environ.get("OMK_SELSCAN_NO_PASS_STATES"):
+            # the lanes-are-channels forward took channel-last views: so will the backward, from the state in front of every 16-token tile
+            # (B, L / 16, N, D floats, channels innermost) -- without the tensor the backward runs the forward sweep once more to get them
+            ps = torch.empty(Bsz, (L + 15) // 16, A.shape[1], Dm, dtype=torch.float32, device=u.device)
+        if (ps is None and not lanes_fwd and L >= 64 and any(ctx.needs_input_grad) and B4.dim() == 4 and C4.dim() == 4 and B4.dtype == u.dtype and C4.dtype == u.dtype and
                 (Dm // B4.shape[1]) % 8 == 0 and (out.stride(1) == 1 or all(t is None or t.stride(-1) == 1 for t in (u, delta, z, B4, C4))) and
                 not os.environ.get("OMK_SELSCAN_SEQ") and not os.environ.get("OMK_SELSCAN_NO_PASS_STATES")):
             # = the conditions of the chunked backward (selscan.hip); without the tensor the backward runs a state-only forward pass first
@@ -79,15 +85,37 @@ class SelectiveScanFn(torch.autograd.Function):
         lib = get_lib()
         u, delta, A, B4, C4, D, z, delta_bias, ps = ctx.saved_tensors
         dout = dout.to(u.dtype)
-        if u.shape[-1] >= 64:
+        lanes = False
+        tile_ps = ps is not None and ps.shape[-1] == u.shape[1] and ps.shape[1] == (u.shape[2] + 15) // 16
+        if u.stride(1) == 1 and u.shape[1] > 1 and u.numel() > 0 and (ps is None or tile_ps) and os.environ.get("OMK_SELSCAN_BWD_LANES", "1") != "0":   # (=0: developer A/B against the copies + chunked scan)
+            # channel-last views (what the Mamba-1 module holds): with enough sequences the lanes-are-channels reverse sweep reads and
+            # writes them as they lie (omk_selective_scan_bwd_form == 2, selscan.hip: selscan_bwd_lanes_kernel) -- no L-contiguous copies
+            Bsz, Dm, L = u.shape
+            cl = lambda t: t if t.stride(1) == 1 else t.transpose(1, 2).contiguous().transpose(1, 2)
+            delta_c, dout_c, z_c = cl(delta), cl(dout), None if z is None else cl(z)
+            du_c = torch.empty(Bsz, L, Dm, dtype=u.dtype, device=u.device).transpose(1, 2)
+            dd_c = torch.empty(Bsz, L, Dm, dtype=u.dtype, device=u.device).transpose(1, 2)
+            dz_c = None if z is None else torch.empty(Bsz, L, Dm, dtype=u.dtype, device=u.device).transpose(1, 2)
+            probe = K.SelScanBwd(u=K.T(u), delta=K.T(delta_c), A=K.T(A.float() if A.dtype != torch.float32 else A), Bm=K.T(B4), Cm=K.T(C4),
+                                 D=K.T(D), z=K.T(z_c), delta_bias=K.T(delta_bias), dout=K.T(dout_c), du=K.T(du_c), ddelta=K.T(dd_c),
+                                 dA=K.T(None), dB=K.T(None), dC=K.T(None), dD=K.T(None), dz=K.T(dz_c), ddelta_bias=K.T(None),
+                                 pass_states=K.T(ps), delta_softplus=int(ctx.delta_softplus))
+            if lib.omk_selective_scan_bwd_form(_C.byref(probe)) == 2:
+                lanes, delta, dout, z = True, delta_c, dout_c, z_c
+        if not lanes and ps is not None and tile_ps:
+            ps = None          # (tile states are of no use to the other forms)
+        if not lanes and u.shape[-1] >= 64:
             # (the forward may have read channel-last views as they lay: the chunked backward wants rows along L)
             u, delta, dout = (t if t.stride(-1) == 1 else t.contiguous() for t in (u, delta, dout))
             z = z if z is None or z.stride(-1) == 1 else z.contiguous()
             B4 = B4 if B4.dim() != 4 or B4.stride(-1) == 1 else B4.contiguous()
             C4 = C4 if C4.dim() != 4 or C4.stride(-1) == 1 else C4.contiguous()
         Af = A.float() if A.dtype != torch.float32 else A
-        du, ddelta = torch.empty_like(u), torch.empty_like(delta)
-        dz = None if z is None else torch.empty_like(z)
+        if lanes:
+            du, ddelta, dz = du_c, dd_c, dz_c
+        else:
+            du, ddelta = torch.empty_like(u), torch.empty_like(delta)
+            dz = None if z is None else torch.empty_like(z)
         # the fp32 accumulators (the kernel adds into them) as slices of ONE zeroed buffer: one fill launch instead of five
         shapes = [A.shape, B4.shape, C4.shape, None if D is None else D.shape, None if delta_bias is None else delta_bias.shape]
         sizes = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]

@@ -197,3 +197,47 @@ def test_selective_scan_bwd_delta_underflow(dev):
         if a is not None:
             assert torch.isfinite(a.grad).all(), name
             assert rel(a.grad, b.grad) < 2e-4, (name, rel(a.grad, b.grad))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bc_layout", ["nl", "ln"])
+@pytest.mark.parametrize("Dm,L,N,G,with_z,softplus", [(70, 45, 16, 1, True, True), (12, 33, 8, 2, False, True), (130, 100, 5, 1, True, False),
+                                                      (64, 16, 16, 1, True, True), (96, 200, 16, 2, True, True)])
+def test_selective_scan_bwd_lanes_are_channels(dev, monkeypatch, dtype, bc_layout, Dm, L, N, G, with_z, softplus):
+    """Round 6: the backward on CHANNEL-LAST views as they lie (selscan_bwd_lanes_kernel: a lane owns a channel and walks the sequence
+    backwards in 16-token tiles, forward states re-run from the checkpoints of a forward pass, dB / dC through a wave butterfly + float
+    atomics) -- forced onto small shapes: ragged channel tiles (70 = 64 + 6, groups of 6 / 48), ragged last tile, odd d_state, B / C with either
+    of (state, token) contiguous, with and without gate / softplus.  Every gradient against autograd of the fp64 recurrence, and the
+    gradient tensors of u / delta / z come back channel-last (no L-contiguous copies anywhere)."""
+    from omnimamba_amd.selective_scan import selective_scan_fn
+    monkeypatch.setenv("OMK_SELSCAN_LANES", "1")
+    torch.manual_seed(5)
+    Bsz = 3
+    mk = lambda scale=1.0, rand=False: ((torch.rand(Bsz, L, Dm) if rand else torch.randn(Bsz, L, Dm)) * scale).to(dtype)
+    u, delta, z = mk(), mk(0.5, True), mk()
+    Bm, Cm = torch.randn(Bsz, G, L, N).to(dtype), torch.randn(Bsz, G, L, N).to(dtype)
+    A, D, db = -(torch.rand(Dm, N) + 0.1), torch.randn(Dm), torch.randn(Dm) * 0.1
+    gy = torch.randn(Bsz, L, Dm).to(dtype)
+
+    def leaves(device, f64):
+        cv = (lambda t: t.detach().double()) if f64 else (lambda t: t.detach().clone())
+        return [cv(t).to(device).requires_grad_() for t in (u, delta, A, Bm, Cm, D, z, db)]
+
+    lv = leaves(dev, False)
+    ud, dd, zd = lv[0].transpose(1, 2), lv[1].transpose(1, 2), lv[6].transpose(1, 2)        # channel-last views (B, D, L) of (B, L, D) storage
+    Bd = lv[3].transpose(2, 3) if bc_layout == "nl" else lv[3].transpose(2, 3).contiguous()   # (B, G, N, L): token or state contiguous
+    Cd = lv[4].transpose(2, 3) if bc_layout == "nl" else lv[4].transpose(2, 3).contiguous()
+    out = selective_scan_fn(ud, dd, lv[2], Bd, Cd, lv[5], zd if with_z else None, lv[7], softplus)
+    assert out.stride(1) == 1
+    out.backward(gy.to(dev).transpose(1, 2))
+    r = leaves("cpu", True)
+    o0 = O.selective_scan_ref(r[0].transpose(1, 2), r[1].transpose(1, 2), r[2], r[3].transpose(2, 3), r[4].transpose(2, 3), r[5],
+                              r[6].transpose(1, 2) if with_z else None, r[7], softplus)
+    o0.backward(gy.double().transpose(1, 2))
+    tol = 2e-4 if dtype == torch.float32 else 1.2e-2
+    for nm, a_, b_ in zip(["u", "delta", "A", "B", "C", "D", "z", "delta_bias"], lv, r):
+        if nm == "z" and not with_z:
+            continue
+        e = rel(a_.grad, b_.grad)
+        assert e < (tol if nm not in ("A", "delta_bias", "D") or dtype == torch.float32 else 3e-2), (nm, e)
+    assert lv[0].grad.is_contiguous() and lv[1].grad.is_contiguous()      # (B, L, D) gradients written in place: channel-last all the way
