@@ -739,7 +739,7 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
       else OMK_LAUNCH((conv1d_fwd_cl_kernel<T_, VEC_, TL_, 2, TG_>), grid, block, 0, stream, a); } while (0)
     const char* tle = getenv("OMK_CONV_FWD_TL");   // developer A/B of the tokens per thread (bf16)
     const int tl = (tle && *tle) ? atoi(tle) : (a.L >= 1024 ? 64 : 32);   // 64: -4 % on the 1.3B slice (halo rows), 128: worse again
-    static const bool cl8 = !(getenv("OMK_CONV_FWD_CL8") && getenv("OMK_CONV_FWD_CL8")[0] == '0');
+    const bool cl8 = !(getenv("OMK_CONV_FWD_CL8") && getenv("OMK_CONV_FWD_CL8")[0] == '0');
     const int64_t farf = (int64_t)a.L * 2 * (a.xsl > a.osl ? a.xsl : a.osl);
     const char* vce = getenv("OMK_CONV_FWD_VEC");   // developer A/B: "8" = 16 bytes per lane, 4 tokens in flight
     if (p->x.dtype == OMK_BF16 && vce && vce[0] == '8' && a.C % 8 == 0) {
@@ -825,7 +825,7 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
 #undef CONV_BWD_X
     } else {
       // the scalar-position kernel (conv1d_bwd_cl4_kernel) when every row offset fits 31 bits (OMK_CONV_BWD_CL4=0: the round-3 kernel)
-      static const bool cl4 = !(getenv("OMK_CONV_BWD_CL4") && getenv("OMK_CONV_BWD_CL4")[0] == '0');
+      const bool cl4 = !(getenv("OMK_CONV_BWD_CL4") && getenv("OMK_CONV_BWD_CL4")[0] == '0');
       const int64_t far = (int64_t)a.L * 2 * (a.xsl > a.dosl ? (a.xsl > a.dxsl ? a.xsl : a.dxsl) : (a.dosl > a.dxsl ? a.dosl : a.dxsl));
       if (cl4 && far < ((int64_t)1 << 31) && a.xsc == 1 && a.dosc == 1 && a.dxsc == 1) {
         const int CVB = (a.C / 2 + 63) / 64, NT4 = (a.L + 4 * TL - 1) / (4 * TL);

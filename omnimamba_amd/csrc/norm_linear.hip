@@ -1065,24 +1065,28 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       const int nb = a.B <= 2 ? 2 : (a.B <= 4 ? 4 : 8);
       const int vecw = wdt == OMK_F32 ? 4 : 8, steps_row = a.In / (64 * vecw), rw = 16 / steps_row;
       const size_t bsmem = (size_t)nb * a.In * (wdt == OMK_F32 ? 4 : 2) + (size_t)(NL_THREADS / 64) * nb * (9 + 64) * 4;
-      if (bsmem > 150 * 1024) return fail(OMK_EUNSUPPORTED, "norm_linear: %d sequences x %d features do not fit the LDS", a.B, a.In);
+      // (these two limits belong to the VECTOR form below; the matrix-pipe form walks its tiles persistently and sizes its own LDS -- the
+      // checks are applied behind its dispatch: advisor finding, round 5)
+      const bool vec_lds_ok = bsmem <= 150 * 1024;
       const int wg_per_cu = bsmem <= 76 * 1024 ? 2 : 1;
       const int maxw = wg_per_cu * cu_count() * (NL_THREADS / 64);
       const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
       const int nw_ = (a.Out + rw * k - 1) / (rw * k);
       a.nbatch = k;
-      if (k * rw > 64) return fail(OMK_EUNSUPPORTED, "norm_linear: %d output rows are too many for the batched kernel", a.Out);
+      const bool vec_rows_ok = k * rw <= 64;
       dim3 bgrid((unsigned)((nw_ + NL_THREADS / 64 - 1) / (NL_THREADS / 64))), bblock(NL_THREADS);
       const bool gate = present(p->z);
       if (gate && present(p->residual)) return fail(OMK_EUNSUPPORTED, "norm_linear: residual and gate together are served by the batch-1 kernel only");
       // 16-bit weights: the matrix-pipe form, a workgroup per tile of 16 rows (OMK_NL_MFMA=0: the vector form, for the A/B)
-      static const bool use_mfma = !(getenv("OMK_NL_MFMA") && atoi(getenv("OMK_NL_MFMA")) == 0);
+      const bool use_mfma = !(getenv("OMK_NL_MFMA") && atoi(getenv("OMK_NL_MFMA")) == 0);   // (developer switches are read per call, all of them)
       // B rows of the LoRA read as 16-byte loads
-      const bool lora_rows16 = a.R == 0 || (a.R == 8 && (a.lbs * (wdt == OMK_F32 ? 4 : 2)) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.lb) & 15) == 0);
+      // (both matrices: load_lora reads the A rows as 16-byte vectors too -- advisor finding, round 5)
+      const bool lora_rows16 = a.R == 0 || (a.R == 8 && (a.lbs * (wdt == OMK_F32 ? 4 : 2)) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.lb) & 15) == 0 &&
+                                            (a.las * (wdt == OMK_F32 ? 4 : 2)) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.la) & 15) == 0);
       // fp32 weights (four v_mfma_f32_16x16x4_f32 per 16-byte vector): only where it was measured ahead of the vector form -- eight sequences
       // with LoRA, rows of up to 2048 features: 29.7 against 31.5 us for the 1.3B in_proj; behind it at two sequences (28.8 / 19.5 us) and
       // without LoRA (23.9 / 19.7 us) -- profiles/r05_decode_projections.txt.  (4096 features: 32 loads per lane and tile, no room for two tiles.)
-      static const bool mfma_f32 = !(getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 0);
+      const bool mfma_f32 = !(getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 0);
       const bool f32_ok = wdt == OMK_F32 && nq <= 2 && mfma_f32 && ((nb == 8 && a.R > 0) || (getenv("OMK_NL_MFMA_F32") && atoi(getenv("OMK_NL_MFMA_F32")) == 2));
       if (use_mfma && lora_rows16 && (wdt == OMK_BF16 || f32_ok)) {
         // tiles of 8 rows when there are fewer 16-row tiles than workgroups (out_proj of the 1.3B model: 11.1 -> 10.1 us at eight sequences,
@@ -1115,6 +1119,8 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
 #undef NLM_G
         return finish_launch("norm_linear");
       }
+      if (!vec_lds_ok) return fail(OMK_EUNSUPPORTED, "norm_linear: %d sequences x %d features do not fit the LDS", a.B, a.In);
+      if (!vec_rows_ok) return fail(OMK_EUNSUPPORTED, "norm_linear: %d output rows are too many for the batched kernel", a.Out);
 #define NLB_G(TW_, TR_, NQ_, RM_, NB_, G_) do { \
         if (OMK_SET_MAX_DYN_SMEM((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bsmem)) return fail(OMK_ELAUNCH, "norm_linear: cannot raise dynamic LDS to %zu", bsmem); \
         OMK_LAUNCH((norm_linear_batched_kernel<TW_, TR_, NQ_, RM_, NB_, G_>), bgrid, bblock, bsmem, stream, a); } while (0)
@@ -1137,7 +1143,7 @@ extern "C" int omk_norm_linear(const OmkNormLinear* p, omk_stream stream) {
       const int vecw = wdt == OMK_F32 ? 4 : 8;
       const int steps_row = a.In / (64 * vecw), rw = 16 / steps_row;   // rows per batch (16 loads of 16 bytes per lane)
       // waves: every wave takes k full batches of rw rows (k as small as two workgroups per CU allow)
-      static const int wpc = getenv("OMK_NLF_WPC") ? atoi(getenv("OMK_NLF_WPC")) : 2;   // workgroups per CU the grid is sized for
+      const int wpc = getenv("OMK_NLF_WPC") ? atoi(getenv("OMK_NLF_WPC")) : 2;   // workgroups per CU the grid is sized for
       const int maxw = (wpc > 0 ? wpc : 2) * cu_count() * (NL_THREADS / 64);
       const int k = (a.Out + rw * maxw - 1) / (rw * maxw);
       const int nw_ = (a.Out + rw * k - 1) / (rw * k);

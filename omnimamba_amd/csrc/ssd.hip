@@ -544,7 +544,7 @@ static void launch_dt_prep(const OmkTensor& dt, const OmkTensor& dtb, const SsdD
                    (d.H % 2) == 0 && (d.L % 4) == 0 && ((uintptr_t)dtp & 15) == 0 && (!dsoft || ((uintptr_t)dsoft & 15) == 0);
   if (vec) {
     // 32-token tiles: 7.6 us per launch against 9.7 us with 64 (twice the blocks in flight; the (B, H, L) rows still leave as full 128-byte lines)
-    static const int tok = getenv("OMK_DT_PREP_TOK") ? atoi(getenv("OMK_DT_PREP_TOK")) : 32;
+    const int tok = getenv("OMK_DT_PREP_TOK") ? atoi(getenv("OMK_DT_PREP_TOK")) : 32;
     if (tok == 32) {
       dim3 grid((unsigned)((int64_t)d.B * ((d.L + 31) / 32) * ((d.H + 63) / 64)));
       if (dt.dtype == OMK_BF16) OMK_LAUNCH((ssd_dt_prep_vec_kernel<bf16_t, 32>), grid, block, 0, stream, a);
@@ -691,7 +691,7 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
 // (ssd_cp.hip) behind the dx scan
 enum { BWD_GENERIC = 0, BWD_MFMA = 1, BWD_CP = 2 };
 struct BwdWs { float *dtp, *dsoft, *e, *wsum, *dB32, *dC32, *sfin, *part, *ckpt, *bnd, *seg, *segf, *pB, *pC; uint16_t *Sf, *Sg; int nhs; size_t total; };
-static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, int path) {
+static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N, bool need_sfin, int path, bool cp_direct = false) {
   BwdWs w = {}; size_t off = 0; char* c = (char*)base;
   auto take = [&](size_t bytes) { float* r = (float*)(c + off); off += align256(bytes); return r; };
   const size_t bhl = (size_t)B * H * L * 4, blgn = (size_t)B * L * G * N * 4;
@@ -708,7 +708,8 @@ static BwdWs bwd_ws_layout(void* base, int B, int L, int H, int P, int G, int N,
     w.Sf = (uint16_t*)take((size_t)B * H * nW * 16384);
     w.Sg = (uint16_t*)take((size_t)B * H * nW * 16384);
     w.nhs = ssd_cp_heads_split(B, L, H, G);
-    w.pB = take((size_t)w.nhs * blgn); w.pC = take((size_t)w.nhs * blgn);
+    // (fp32 partials of the head subsets: not reserved when the kernel stores dB / dC itself -- 2 x 16 MiB at B 8, L 4096; advisor finding, round 5)
+    if (!cp_direct) { w.pB = take((size_t)w.nhs * blgn); w.pC = take((size_t)w.nhs * blgn); }
   }
   // split sequences: start states of the segments -- adjoint state (dx and dB scans) and forward state (dC scan)
   w.seg = mfma && ssd_seg_bytes(B * H, L) ? take(ssd_seg_bytes(B * H, L)) : nullptr;
@@ -797,10 +798,19 @@ static int bwd_path(const OmkSsdBwd* p, const SsdDims& d) {
   return bwd_cp_applies(p, d) ? BWD_CP : BWD_MFMA;
 }
 
+static bool bwd_cp_direct(const OmkSsdBwd* p, const SsdDims& d) {
+  CpArgs c = {};
+  c.dB = p->dB.data; c.dbsb = p->dB.stride[0]; c.dbsl = p->dB.stride[1]; c.dbsg = p->dB.stride[2]; c.dB_dt = p->dB.dtype;
+  c.dC = p->dC.data; c.dcsb = p->dC.stride[0]; c.dcsl = p->dC.stride[1]; c.dcsg = p->dC.stride[2]; c.dC_dt = p->dC.dtype;
+  c.nhs = ssd_cp_heads_split(d.B, d.L, d.H, d.G);
+  return ssd_cp_direct(c);
+}
+
 extern "C" size_t omk_ssd_scan_bwd_workspace_bytes(const OmkSsdBwd* p) {
   if (!p) return 0;
   SsdDims d = {(int)p->x.shape[0], (int)p->x.shape[1], (int)p->x.shape[2], (int)p->x.shape[3], (int)p->Bm.shape[2], (int)p->Bm.shape[3]};
-  return bwd_ws_layout(nullptr, d.B, d.L, d.H, d.P, d.G, d.N, present(p->dfinal_states), bwd_path(p, d)).total;
+  const int path = bwd_path(p, d);
+  return bwd_ws_layout(nullptr, d.B, d.L, d.H, d.P, d.G, d.N, present(p->dfinal_states), path, path == BWD_CP && bwd_cp_direct(p, d)).total;
 }
 
 extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
@@ -824,7 +834,7 @@ extern "C" int omk_ssd_scan_bwd(const OmkSsdBwd* p, omk_stream stream) {
   const bool has_dfin = present(p->dfinal_states);
   const int path = bwd_path(p, d);
   const bool mfma = path != BWD_GENERIC, cp = path == BWD_CP;
-  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, path);
+  BwdWs w = bwd_ws_layout(p->workspace, d.B, d.L, d.H, d.P, d.G, d.N, has_dfin, path, cp && bwd_cp_direct(p, d));
   const int64_t bhl = (int64_t)d.B * d.H * d.L, blgn = (int64_t)d.B * d.L * d.G * d.N;
   if (!mfma) { launch_zero(w.e, bhl, stream); launch_zero(w.wsum, bhl, stream); launch_zero(w.dB32, blgn, stream); launch_zero(w.dC32, blgn, stream); }
   launch_dt_prep(p->dt, p->dt_bias, d, w.dtp, w.dsoft, p->dt_softplus, p->dt_min, p->dt_max, stream, (float*)p->dA.data, d.H,

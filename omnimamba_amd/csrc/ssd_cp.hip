@@ -527,13 +527,18 @@ int ssd_cp_heads_split(int B, int L, int H, int G) {
   return nhs;
 }
 
+// one head subset, bf16 gradients on 8-byte aligned rows: the kernel stores dB / dC itself (no fp32 partials, no fold launch)
+bool ssd_cp_direct(const CpArgs& a) {
+  const bool al = (((uintptr_t)a.dB | (uintptr_t)a.dC) & 7) == 0 && ((a.dbsb | a.dbsl | a.dbsg | a.dcsb | a.dcsl | a.dcsg) & 3) == 0;
+  const char* de = getenv("OMK_CP_DIRECT");
+  return a.nhs == 1 && a.dB_dt == OMK_BF16 && a.dC_dt == OMK_BF16 && al && !(de && de[0] == '0');
+}
+
 int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
   CpArgs a = a0;
   if (const char* e = getenv("OMK_CP_ABLATE")) a.ablate = atoi(e);
   // 8-byte stores of four bf16: rows and group blocks of dB / dC 8-byte aligned (OMK_CP_DIRECT=0: the partial buffers + fold launch)
-  const bool al = (((uintptr_t)a.dB | (uintptr_t)a.dC) & 7) == 0 && ((a.dbsb | a.dbsl | a.dbsg | a.dcsb | a.dcsl | a.dcsg) & 3) == 0;
-  const char* de = getenv("OMK_CP_DIRECT");
-  a.direct = (a.nhs == 1 && a.dB_dt == OMK_BF16 && a.dC_dt == OMK_BF16 && al && !(de && de[0] == '0')) ? 1 : 0;
+  a.direct = ssd_cp_direct(a) ? 1 : 0;
   kernels_note("ssd_cp<direct=%d,nhs=%d>", a.direct, a.nhs);
   const size_t smem = sizeof(SmemCp);
   if (OMK_SET_MAX_DYN_SMEM(ssd_cp_kernel, smem)) return fail(OMK_ELAUNCH, "ssd_cp: cannot raise dynamic LDS to %zu", smem);
@@ -560,7 +565,7 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
     }
   }
 #endif
-  if (a.direct) return OMK_OK;   // (written by the kernel itself)   // (written by the kernel itself)
+  if (a.direct) return OMK_OK;   // (written by the kernel itself)
   const int64_t total = (int64_t)a.B * a.L * a.G * 16;
   dim3 fgrid((unsigned)((total + 255) / 256), 2u), fblock(256);
   const FoldOne fC = {(const float*)a.pC, a.dC, a.dcsb, a.dcsl, a.dcsg, a.dC_dt}, fB = {(const float*)a.pB, a.dB, a.dbsb, a.dbsl, a.dbsg, a.dB_dt};

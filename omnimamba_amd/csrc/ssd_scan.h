@@ -143,6 +143,7 @@ struct CpArgs {
   unsigned long long* prof;   // developer only (OMK_PHASE_PROF builds, OMK_CP_PROF=1): per-wave phase cycle sums of workgroup 0
 };
 int ssd_cp_heads_split(int B, int L, int H, int G);
+bool ssd_cp_direct(const CpArgs& a);   // the kernel writes dB / dC itself (the fp32 partial buffers pB / pC are not needed then)
 int ssd_cp_launch(const CpArgs& a, omk_stream stream);
 int ssd_reduce_partials(const float* part, void* out, int64_t osb, int64_t osl, int64_t osg, int out_dt, int B, int L, int G, int H, omk_stream stream);
 
