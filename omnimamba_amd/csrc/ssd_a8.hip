@@ -718,6 +718,17 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
     PT8(1);
     phase1(fr, false, false, dump_nb, fc, kb0, ub0, 1);
     }
+    if ((OMK_A8_VAR & 1024) && (OMK_A8_VAR & 4096)) {   // (ablation 1024 + 4096: the memory skeleton -- every load, commit and output store of a chunk, no arithmetic)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          if (OMK_A8_VAR & 8192) {   // (the same bytes as FULL 128-byte lines: wave w takes the rows with bit 3 == w, eight rows x 128 bytes per instruction)
+            const int row = 32 * jj + 16 * s2 + 8 * w + (lane >> 3);
+            buf_st16(Or, u32x4{0u, 0u, 0u, 0u}, 2u * (uint32_t)(rowtok(row) * osl + 8 * (lane & 7)), so);
+          } else buf_st16(Or, u32x4{0u, 0u, 0u, 0u}, ovo[jj][s2], so);
+        }
+    }
     if (CUS && !(OMK_A8_VAR & 64)) commit_u(ps, ub0 ^ 1);                                   // U of chunk c + 1
     if (CUS && !(OMK_A8_VAR & 128)) prefetch_u(ps, chunk_lo(clipc(c + 1 + USET)));
     PT8(2);
