@@ -723,6 +723,11 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
       for (int jj = 0; jj < 2; jj++)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
+          if (OMK_A8_VAR & 16384) {  // (... as 256-byte pieces, both heads of the pair: four rows x 256 bytes per instruction, wave 2 hh + w takes rows with bits 3:2 == its index)
+            const int row = 32 * jj + 16 * s2 + 4 * (2 * hh + w) + (lane >> 4);
+            const BufRes Or2 = make_buf((uint16_t*)a.out + (int64_t)b * a.osb + (int64_t)(2 * hp) * a.osh, (uint32_t)((int64_t)a.L * osl * 2));
+            buf_st16(Or2, u32x4{0u, 0u, 0u, 0u}, 2u * (uint32_t)(rowtok(row) * osl + 8 * (lane & 15)), so);
+          } else
           if (OMK_A8_VAR & 8192) {   // (the same bytes as FULL 128-byte lines: wave w takes the rows with bit 3 == w, eight rows x 128 bytes per instruction)
             const int row = 32 * jj + 16 * s2 + 8 * w + (lane >> 3);
             buf_st16(Or, u32x4{0u, 0u, 0u, 0u}, 2u * (uint32_t)(rowtok(row) * osl + 8 * (lane & 7)), so);

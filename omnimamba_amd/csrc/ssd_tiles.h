@@ -33,7 +33,7 @@ __device__ __forceinline__ BufRes make_buf(const void* p, uint32_t nbytes) {
 }
 __device__ __forceinline__ u32x4 buf_ld16(const BufRes& b, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;   // (the UNWRAPPED sum: a kernel must not count on 32-bit wrap-around of lane + scalar offset)
   if (o >= b.nbytes) return u32x4{0u, 0u, 0u, 0u};
   return *reinterpret_cast<const u32x4*>(b.base + o);
 #else
@@ -42,7 +42,7 @@ __device__ __forceinline__ u32x4 buf_ld16(const BufRes& b, uint32_t voff, uint32
 }
 __device__ __forceinline__ float buf_ld_f32(const BufRes& b, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;   // (the UNWRAPPED sum: a kernel must not count on 32-bit wrap-around of lane + scalar offset)
   if (o >= b.nbytes) return 0.f;
   return *reinterpret_cast<const float*>(b.base + o);
 #else
@@ -51,7 +51,7 @@ __device__ __forceinline__ float buf_ld_f32(const BufRes& b, uint32_t voff, uint
 }
 __device__ __forceinline__ void buf_st_f32(const BufRes& b, float v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;
   if (o < b.nbytes) *reinterpret_cast<float*>(const_cast<char*>(b.base) + o) = v;
 #else
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b.r, (int)voff, (int)soff, 0);
@@ -60,7 +60,7 @@ __device__ __forceinline__ void buf_st_f32(const BufRes& b, float v, uint32_t vo
 // 16-bit elements (bf16 / f16 storage): the raw bits
 __device__ __forceinline__ uint16_t buf_ld_u16(const BufRes& b, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;   // (the UNWRAPPED sum: a kernel must not count on 32-bit wrap-around of lane + scalar offset)
   if (o >= b.nbytes) return 0;
   return *reinterpret_cast<const uint16_t*>(b.base + o);
 #else
@@ -69,7 +69,7 @@ __device__ __forceinline__ uint16_t buf_ld_u16(const BufRes& b, uint32_t voff, u
 }
 __device__ __forceinline__ void buf_st_u16(const BufRes& b, uint16_t v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;
   if (o < b.nbytes) *reinterpret_cast<uint16_t*>(const_cast<char*>(b.base) + o) = v;
 #else
   __builtin_amdgcn_raw_buffer_store_b16(v, b.r, (int)voff, (int)soff, 0);
@@ -101,7 +101,7 @@ template <> __device__ __forceinline__ void buf_st_t<f16_t>(const BufRes& b, flo
 }
 __device__ __forceinline__ u32x2 buf_ld8(const BufRes& b, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;   // (the UNWRAPPED sum: a kernel must not count on 32-bit wrap-around of lane + scalar offset)
   if (o >= b.nbytes) return u32x2{0u, 0u};
   return *reinterpret_cast<const u32x2*>(b.base + o);
 #else
@@ -110,7 +110,7 @@ __device__ __forceinline__ u32x2 buf_ld8(const BufRes& b, uint32_t voff, uint32_
 }
 __device__ __forceinline__ void buf_st8(const BufRes& b, u32x2 v, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;
   if (o < b.nbytes) *reinterpret_cast<u32x2*>(const_cast<char*>(b.base) + o) = v;
 #else
   __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
@@ -131,7 +131,7 @@ __device__ __forceinline__ void buf_st16(const BufRes& b, u32x4 v, uint32_t voff
 // barrier for the other waves).  Rows behind the end of the buffer arrive as zeros.
 __device__ __forceinline__ void buf_ld16_lds(const BufRes& b, void* lds_base, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;
   u32x4 v = {0u, 0u, 0u, 0u};
   if (o < b.nbytes) v = *reinterpret_cast<const u32x4*>(b.base + o);
   *reinterpret_cast<u32x4*>((char*)lds_base + 16 * lane_id()) = v;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void buf_ld16_lds(const BufRes& b, void* lds_base, ui
 }
 __device__ __forceinline__ void buf_ld4_lds(const BufRes& b, void* lds_base, uint32_t voff, uint32_t soff) {
 #ifdef OMK_EMU
-  const uint32_t o = voff + soff;
+  const uint64_t o = (uint64_t)voff + soff;
   uint32_t v = 0u;
   if (o < b.nbytes) v = *reinterpret_cast<const uint32_t*>(b.base + o);
   *reinterpret_cast<uint32_t*>((char*)lds_base + 4 * lane_id()) = v;
