@@ -143,7 +143,7 @@ __device__ __forceinline__ float conv_in(const ConvArgs& a, const T* x, int b, i
 #ifndef TGF
 #define TGF 8   // tokens requested per group
 #endif
-template <class T, int TL, int W, int TG>
+template <class T, int TL, int W, int TG, bool WF>
 __global__ __launch_bounds__(256) void conv1d_fwd_cl8_kernel(ConvArgs a) {
   constexpr int VEC = 4;
   static_assert(sizeof(T) == 2, "four 16-bit channels = 8 bytes per lane");
@@ -156,7 +156,48 @@ __global__ __launch_bounds__(256) void conv1d_fwd_cl8_kernel(ConvArgs a) {
   if (l0 >= a.L) return;                                           // (scalar: the whole wave)
   const T* x = (const T*)a.x + (int64_t)b * a.xsb + c0;
   float w[W][VEC], bias[VEC], win[W][VEC];
-  {
+  if constexpr (WF) {
+    // SHORT strips need a short prologue (WF: fp32 (C, W) weight rows, contiguous and 16-byte aligned, fp32 bias or none -- checked by the
+    // launcher): the lane's VEC x W taps are VEC x W consecutive floats = W 16-byte requests, the bias one more, the W - 1 halo rows three
+    // 8-byte requests behind ONE scalar test -- against 16 + 4 + 12 run-time-dtype element requests in the general prologue below, which
+    // costs a 16-token strip more than its tokens (profiles/r06_stream_kernels.txt).
+    f32x4 wq[W], bq = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* wp = reinterpret_cast<const f32x4*>((const float*)a.w + (int64_t)c0 * W);
+#pragma unroll
+    for (int q = 0; q < W; q++) wq[q] = wp[q];
+    if (a.bias) bq = *reinterpret_cast<const f32x4*>((const float*)a.bias + c0);
+    const bool interior = l0 >= W - 1;                                // (scalar)
+    vec_t<T, VEC> qx[W];
+    if (interior) {
+#pragma unroll
+      for (int s = 1; s < W; s++) qx[s] = *reinterpret_cast<const vec_t<T, VEC>*>(x + (int64_t)(l0 - W + s) * a.xsl);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      bias[i] = bq[i];
+      win[0][i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < W; k++) w[k][i] = wq[(i * W + k) / 4][(i * W + k) % 4];
+    }
+    if (interior) {
+#pragma unroll
+      for (int s = 1; s < W; s++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) win[s][i] = to_f32(qx[s].e[i]);
+    } else {   // the first strip of a sequence: initial states or zeros, earlier tokens of the strip's own sequence
+#pragma unroll
+      for (int s = 1; s < W; s++) {
+        const int l = l0 - W + s;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          float v = 0.f;
+          if (l >= 0) v = to_f32(x[(int64_t)l * a.xsl + i]);
+          else if (a.init && W - 1 + l >= 0) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(W - 1 + l) * a.isl, a.idt);
+          win[s][i] = v;
+        }
+      }
+    }
+  } else {
     RawElem qb[VEC], qw[W][VEC], qi[W][VEC];
     vec_t<T, VEC> qx[W];
 #pragma unroll
@@ -437,41 +478,85 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl_kernel(ConvArgs a) {
 //   * rows move through buffer resources: the lane part of an address is one constant VGPR (idle lanes of the last channel block point
 //     behind the range: their loads read zeros and their stores are dropped), the row part the instruction's scalar offset;
 //   * the token step exists twice: the seven interior groups of a 64-token tile take a copy without any test -- the window shifts are
-//     register renames there.
+//     register renames there;
+//   * (round 6) the lane's two channels are one packed fp32 pair (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and contiguous fp32 weights take a
+//     prologue of 16-byte requests (WF): 207 -> 185 us at the cfg 2 slice (profiles/r06_stream_kernels.txt).
 // ---------------------------------------------------------------------------------------------------------
 #ifndef TGX
-#define TGX 4   // tokens requested per group: 4 = 102 registers, four waves per SIMD (8: 142 registers, three waves; 298 - 307 against 306 - 314 us)
+#define TGX 4   // tokens requested per group (round 6, packed pairs: 4 / 8 / 16 = 76 / 94 / 142 registers, 193.8 / 189.6 / 194.2 us -- no difference)
 #endif
-template <class T, int TL, int W, int TG>
-__global__ __launch_bounds__(256) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // (142 registers, three waves per SIMD; bounded to 128 it spills 14 and runs 353 us against 315)
+template <class T, int TL, int W, int TG, int NS, bool WF>   // NS strips of TL tokens per workgroup (one wave each): NS TL tokens per set of dw / db atomics
+__global__ __launch_bounds__(64 * NS) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // (74 - 76 registers with the packed pairs of round 6; 102 before)
   constexpr int VEC = 2;
   static_assert(sizeof(T) == 2, "two 16-bit channels = one dword per lane");
-  __shared__ float sred[4][64][VEC * (W + 1)];
-  const int CV = a.C / VEC, NT4 = (a.L + 4 * TL - 1) / (4 * TL), CVB = (CV + 63) / 64;
+  __shared__ float sred[NS][64][VEC * (W + 1)];
+  const int CV = a.C / VEC, NT4 = (a.L + NS * TL - 1) / (NS * TL), CVB = (CV + 63) / 64;
   const int cvb = blockIdx.x % CVB, t4 = (blockIdx.x / CVB) % NT4, b = blockIdx.x / (CVB * NT4);
   const int cvl = threadIdx.x & 63, strip = uniform_i(threadIdx.x >> 6);
   const int cv = cvb * 64 + cvl;
   const bool cvok = cv < CV;
-  const int c0 = (cvok ? cv : 0) * VEC, l0 = (t4 * 4 + strip) * TL;
+  const int c0 = (cvok ? cv : 0) * VEC, l0 = (t4 * NS + strip) * TL;
   const T* x = (const T*)a.x;
-  float w[W][VEC], bias[VEC], dwacc[W][VEC], dbacc[VEC];
+  // the lane's two channels are ONE packed fp32 pair everywhere below: taps, window, sums -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do
+  // both channels per instruction (the scalar form is VALU bound: ~ 45 vector + 4 transcendental instructions per token, ~ 25 + 4 packed)
+  f32x2 w[W], bias, dwacc[W], dbacc;
+  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;   // (scalar; idle lanes walk along on zeros)
+  f32x2 xw[W], dp[W];
+#pragma unroll
+  for (int s = 0; s < W; s++) { xw[s] = f32x2{0.f, 0.f}; dp[s] = f32x2{0.f, 0.f}; dwacc[s] = f32x2{0.f, 0.f}; }
+  dbacc = f32x2{0.f, 0.f};
+  if constexpr (WF) {
+    // the short prologue of the forward kernel (fp32 (C, W) weight rows, contiguous and 16-byte aligned; fp32 bias or none): the lane's 2 W taps are
+    // 2 W consecutive floats, the halo rows three dword requests behind one scalar test
+    const float* wp = (const float*)a.w + (int64_t)c0 * W;
+    float wf[VEC * W];
+    if constexpr ((VEC * W) % 4 == 0) {
+#pragma unroll
+      for (int q = 0; q < VEC * W / 4; q++) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(wp)[q];
+#pragma unroll
+        for (int e = 0; e < 4; e++) wf[4 * q + e] = v[e];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC * W / 2; q++) {
+        const f32x2 v = reinterpret_cast<const f32x2*>(wp)[q];
+        wf[2 * q] = v[0]; wf[2 * q + 1] = v[1];
+      }
+    }
+    bias = a.bias ? *reinterpret_cast<const f32x2*>((const float*)a.bias + c0) : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < W; kk++) w[kk] = f32x2{wf[kk], wf[W + kk]};
+    if (l0 >= W - 1 && l0 < a.L) {                                      // (scalar)
+      uint32_t qx[W];
+#pragma unroll
+      for (int s = 1; s < W; s++) qx[s] = *reinterpret_cast<const uint32_t*>(x + (int64_t)b * a.xsb + c0 + (int64_t)(l0 - W + s) * a.xsl);
+#pragma unroll
+      for (int s = 1; s < W; s++) {
+        if constexpr (std::is_same<T, bf16_t>::value) xw[s] = f32x2{__builtin_bit_cast(float, qx[s] << 16), __builtin_bit_cast(float, qx[s] & 0xffff0000u)};
+        else xw[s] = f32x2{to_f32(__builtin_bit_cast(T, (uint16_t)qx[s])), to_f32(__builtin_bit_cast(T, (uint16_t)(qx[s] >> 16)))};
+      }
+    } else {
+#pragma unroll
+      for (int s = 1; s < W; s++) {
+        const int l = l0 - W + s;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          float v = 0.f;
+          if (l >= 0) v = to_f32(x[(int64_t)b * a.xsb + (int64_t)(c0 + i) * a.xsc + (int64_t)(l < a.L ? l : a.L - 1) * a.xsl]);
+          else if (a.init && a.W - 1 + l >= 0) v = load_rt(a.init, (int64_t)b * a.isb + (int64_t)(c0 + i) * a.isc + (int64_t)(a.W - 1 + l) * a.isl, a.idt);
+          xw[s][i] = v;
+        }
+      }
+    }
+  } else {
   RawElem qb[VEC], qw[W][VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
     qb[i] = raw_rt_flat(a.bias ? a.bias : a.w, a.bias ? c0 + i : 0, a.bias ? a.bdt : a.wdt);
-    dbacc[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < W; k++) {
-      qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
-      dwacc[k][i] = 0.f;
-    }
+    for (int k = 0; k < W; k++) qw[k][i] = raw_rt_flat(a.w, (int64_t)(c0 + i) * a.wsc + k * a.wsk, a.wdt);
   }
-  const int lend = (l0 + TL < a.L) ? l0 + TL : a.L;   // (scalar; idle lanes walk along on zeros)
-  float xw[W][VEC], dp[W][VEC];
-#pragma unroll
-  for (int s = 0; s < W; s++)
-#pragma unroll
-    for (int i = 0; i < VEC; i++) { xw[s][i] = 0.f; dp[s][i] = 0.f; }
   {
     T qx[W][VEC];
     RawElem qi[W][VEC];
@@ -499,6 +584,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // 
       for (int i = 0; i < VEC; i++) xw[s][i] = l >= 0 ? to_f32(qx[s][i]) : (ini ? cvt_rt_flat(qi[s][i], a.idt) : 0.f);
     }
   }
+  }
   const int pend = lend + W - 1;
   // rows of this batch element as buffers; lane part of every address: the channel pair (idle lanes: behind the range)
   const uint32_t vch = cvok ? 2u * (uint32_t)c0 : 0x7ffffff0u;
@@ -507,50 +593,46 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // 
   const BufRes dr = make_buf((T*)a.dx + (int64_t)b * a.dxsb, (uint32_t)(((int64_t)(a.L - 1) * a.dxsl + a.C) * 2));
   const uint32_t xrow = 2u * (uint32_t)a.xsl, grow = 2u * (uint32_t)a.dosl, drow = 2u * (uint32_t)a.dxsl;
   const bool silu_on = a.silu != 0;
-  auto un2 = [](uint32_t r, float (&o)[VEC]) {
+  auto un2 = [](uint32_t r) -> f32x2 {
+    f32x2 o;
     if constexpr (std::is_same<T, bf16_t>::value) { o[0] = __builtin_bit_cast(float, r << 16); o[1] = __builtin_bit_cast(float, r & 0xffff0000u); }
     else { o[0] = to_f32(__builtin_bit_cast(T, (uint16_t)r)); o[1] = to_f32(__builtin_bit_cast(T, (uint16_t)(r >> 16))); }
+    return o;
+  };
+  auto silu_grad2 = [](f32x2 pre) -> f32x2 {   // silu_grad of both channels: the two exp2 / rcp are the only unpacked steps
+    const f32x2 t = pre * (-LOG2E);
+    const f32x2 e = {exp2_fast(t[0]), exp2_fast(t[1])};
+    const f32x2 q = e + 1.f;
+    const f32x2 sg = {rcp_fast(q[0]), rcp_fast(q[1])};
+    return sg * (1.f + pre * (1.f - sg));
   };
   auto token = [&](auto fast_c, uint32_t rx_, uint32_t rg_, int p) {   // p: scalar
     constexpr bool FAST = decltype(fast_c)::value;
     if (FAST || p < pend) {
 #pragma unroll
-      for (int s = 0; s + 1 < W; s++)
-#pragma unroll
-        for (int i = 0; i < VEC; i++) { xw[s][i] = xw[s + 1][i]; dp[s][i] = dp[s + 1][i]; }
+      for (int s = 0; s + 1 < W; s++) { xw[s] = xw[s + 1]; dp[s] = dp[s + 1]; }
       const bool inside = FAST ? true : p < a.L;
-      float go[VEC], xn[VEC];
-      un2(rx_, xn);
-      un2(rg_, go);
+      f32x2 d = un2(rg_), xn = un2(rx_);
+      if (!inside) { d = f32x2{0.f, 0.f}; xn = f32x2{0.f, 0.f}; }
+      xw[W - 1] = xn;
+      if (silu_on) {
+        f32x2 pre = bias;
 #pragma unroll
-      for (int i = 0; i < VEC; i++) { xw[W - 1][i] = inside ? xn[i] : 0.f; go[i] = inside ? go[i] : 0.f; }
+        for (int k = 0; k < W; k++) pre = fma_f32x2(w[k], xw[k], pre);
+        d *= silu_grad2(pre);
+      }
+      dp[W - 1] = d;
+      if (FAST || p < lend) {   // dw/db: each position is counted by exactly one tile (behind the sequence d is zero)
+        dbacc += d;
 #pragma unroll
-      for (int i = 0; i < VEC; i++) {
-        float d = go[i];
-        if (silu_on) {
-          float pre = bias[i];
-#pragma unroll
-          for (int k = 0; k < W; k++) pre += w[k][i] * xw[k][i];
-          d *= silu_grad(pre);
-        }
-        dp[W - 1][i] = d;
-        if (FAST || p < lend) {   // dw/db: each position is counted by exactly one tile (behind the sequence d is zero)
-          dbacc[i] += d;
-#pragma unroll
-          for (int k = 0; k < W; k++) dwacc[k][i] += d * xw[k][i];
-        }
+        for (int k = 0; k < W; k++) dwacc[k] = fma_f32x2(d, xw[k], dwacc[k]);
       }
       const int lo = p - (W - 1);
       if (FAST || (lo >= l0 && lo < lend)) {
-        float o[VEC];
+        f32x2 acc = w[0] * dp[W - 1];
 #pragma unroll
-        for (int i = 0; i < VEC; i++) {
-          float acc = 0.f;
-#pragma unroll
-          for (int k = 0; k < W; k++) acc += w[k][i] * dp[W - 1 - k][i];
-          o[i] = acc;
-        }
-        T o2[VEC] = {from_f32<T>(o[0]), from_f32<T>(o[1])};
+        for (int k = 1; k < W; k++) acc = fma_f32x2(w[k], dp[W - 1 - k], acc);
+        T o2[VEC] = {from_f32<T>(acc[0]), from_f32<T>(acc[1])};
         const uint32_t pk = (uint32_t)__builtin_bit_cast(uint16_t, o2[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o2[1]) << 16);
         buf_st_f32(dr, __builtin_bit_cast(float, pk), vch, drow * (uint32_t)lo);
       }
@@ -586,7 +668,9 @@ __global__ __launch_bounds__(256) void conv1d_bwd_cl4_kernel(ConvArgs a) {   // 
 #pragma unroll
       for (int k = 0; k <= W; k++) {
         const int j = i * (W + 1) + k;
-        const float v = sred[0][cvl][j] + sred[1][cvl][j] + sred[2][cvl][j] + sred[3][cvl][j];
+        float v = sred[0][cvl][j];
+#pragma unroll
+        for (int q = 1; q < NS; q++) v += sred[q][cvl][j];
         if (k < W) atomic_add_f32(a.dw + (int64_t)(c0 + i) * W + k, v);
         else if (a.db) atomic_add_f32(a.db + c0 + i, v);
       }
@@ -748,13 +832,23 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
     if (cl8 && !(tle && *tle) && !(vce && *vce) && (p->x.dtype == OMK_BF16 || p->x.dtype == OMK_F16) && a.L >= 256 && a.C % 4 == 0 && farf < ((int64_t)1 << 31) &&
         a.xsc == 1 && a.osc == 1) {
       // scalar token positions (conv1d_fwd_cl8_kernel); OMK_CONV_FWD_CL8=0: the per-thread tiles of rounds 1 - 4
-      constexpr int TLF = 64;
-      const int CVB = (a.C / 4 + 63) / 64, NT4 = (a.L + 4 * TLF - 1) / (4 * TLF);
+      // strips of 16 tokens: the shorter a wave lives the better these streams run (tools/probe/conv_probe.hip: 128 / 64 / 32 / 16 tokens
+      // per strip = 4.73 / 5.06 / 5.17 / 5.45 TB/s, three halo rows per strip included) -- once the prologue is a handful of 16-byte
+      // requests (WF); the general prologue keeps 64
+      const char* wfe = getenv("OMK_CONV_CL8_WF");   // developer A/B: "0" = the general prologue
+      const bool wf = !(wfe && *wfe == '0') && p->weight.dtype == OMK_F32 && a.wsk == 1 && a.wsc == a.W && ((uintptr_t)p->weight.data & 15) == 0 &&
+                      (!present(p->bias) || (p->bias.dtype == OMK_F32 && ((uintptr_t)p->bias.data & 15) == 0));
+      int tlf = wf ? 16 : 64;
+      if (const char* e = getenv("OMK_CONV_CL8_TL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) tlf = v; }   // developer A/B
+      const int CVB = (a.C / 4 + 63) / 64, NT4 = (a.L + 4 * tlf - 1) / (4 * tlf);
       dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB)), block(256);
-#define CONV_FWD_8(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 4, TGF>), grid, block, 0, stream, a); \
-        else if (a.W == 3) OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 3, TGF>), grid, block, 0, stream, a); \
-        else OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TLF, 2, TGF>), grid, block, 0, stream, a); } while (0)
+#define CONV_FWD_8F(T_, TL_, W_) do { if (wf) OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TL_, W_, TGF, true>), grid, block, 0, stream, a); \
+        else OMK_LAUNCH((conv1d_fwd_cl8_kernel<T_, TL_, W_, TGF, false>), grid, block, 0, stream, a); } while (0)
+#define CONV_FWD_8W(T_, TL_) do { if (a.W == 4) CONV_FWD_8F(T_, TL_, 4); else if (a.W == 3) CONV_FWD_8F(T_, TL_, 3); else CONV_FWD_8F(T_, TL_, 2); } while (0)
+#define CONV_FWD_8(T_) do { if (tlf == 64) CONV_FWD_8W(T_, 64); else if (tlf == 32) CONV_FWD_8W(T_, 32); else CONV_FWD_8W(T_, 16); } while (0)
       if (p->x.dtype == OMK_BF16) CONV_FWD_8(bf16_t); else CONV_FWD_8(f16_t);
+#undef CONV_FWD_8F
+#undef CONV_FWD_8W
 #undef CONV_FWD_8
     } else
     if (p->x.dtype == OMK_BF16) {
@@ -828,12 +922,17 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
       const bool cl4 = !(getenv("OMK_CONV_BWD_CL4") && getenv("OMK_CONV_BWD_CL4")[0] == '0');
       const int64_t far = (int64_t)a.L * 2 * (a.xsl > a.dosl ? (a.xsl > a.dxsl ? a.xsl : a.dxsl) : (a.dosl > a.dxsl ? a.dosl : a.dxsl));
       if (cl4 && far < ((int64_t)1 << 31) && a.xsc == 1 && a.dosc == 1 && a.dxsc == 1) {
-        const int CVB = (a.C / 2 + 63) / 64, NT4 = (a.L + 4 * TL - 1) / (4 * TL);
-        dim3 grid((unsigned)((int64_t)a.B * NT4 * CVB));
-#define CONV_BWD_4(T_) do { if (a.W == 4) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 4, TGX>), grid, block, 0, stream, a); \
-          else if (a.W == 3) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 3, TGX>), grid, block, 0, stream, a); \
-          else OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, 2, TGX>), grid, block, 0, stream, a); } while (0)
+        // (measured and not kept, profiles/r06_stream_kernels.txt: 8 / 16 strips per workgroup, 32- and 16-token strips, 8 / 16 tokens requested
+        // per group -- 189 ... 194 us all, 16 waves per workgroup 220 ... 262)
+        const bool wf = p->weight.dtype == OMK_F32 && a.wsk == 1 && a.wsc == a.W && ((uintptr_t)p->weight.data & 15) == 0 &&
+                        (!present(p->bias) || (p->bias.dtype == OMK_F32 && ((uintptr_t)p->bias.data & 7) == 0));
+        const int CVB = (a.C / 2 + 63) / 64, NTS = (a.L + 4 * TL - 1) / (4 * TL);
+        dim3 grid((unsigned)((int64_t)a.B * NTS * CVB)), blk(256);
+#define CONV_BWD_4G(T_, W_) do { if (wf) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, W_, TGX, 4, true>), grid, blk, 0, stream, a); \
+          else OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, W_, TGX, 4, false>), grid, blk, 0, stream, a); } while (0)
+#define CONV_BWD_4(T_) do { if (a.W == 4) CONV_BWD_4G(T_, 4); else if (a.W == 3) CONV_BWD_4G(T_, 3); else CONV_BWD_4G(T_, 2); } while (0)
         if (p->x.dtype == OMK_BF16) CONV_BWD_4(bf16_t); else CONV_BWD_4(f16_t);
+#undef CONV_BWD_4G
 #undef CONV_BWD_4
       } else if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 8); else CONV_BWD_V(f16_t, 2, 8);
     }

@@ -337,11 +337,29 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
   }
 }
 
+// VEC weights of a lane as fp32: 16-byte requests when the row is fp32 / 16-bit and aligned (WVEC, checked by the launcher) -- a one-shot
+// workgroup pays this prologue per row, the per-element run-time-dtype loads (sixteen scalar-branch round trips) cost it its gain
+template <int VEC, bool WVEC>
+__device__ __forceinline__ void load_w_row(const void* w, int i0, int wdt, float (&o)[VEC]) {
+  if constexpr (WVEC) {
+    static_assert(VEC == 8, "two 16-byte fp32 groups or one 16-bit group");
+    if (wdt == OMK_F32) {
+      const f32x4 v0 = reinterpret_cast<const f32x4*>((const float*)w + i0)[0], v1 = reinterpret_cast<const f32x4*>((const float*)w + i0)[1];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o[i] = v0[i]; o[4 + i] = v1[i]; }
+    } else if (wdt == OMK_BF16) load_vec<bf16_t, VEC>((const bf16_t*)w + i0, o);
+    else load_vec<f16_t, VEC>((const f16_t*)w + i0, o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) o[i] = load_rt(w, i0 + i, wdt);
+  }
+}
+
 // The reference's mode only (OmniMamba / Mamba-2: gate z present, norm_before_gate = 0, no bias, one segment per block row): the rows of a
 // block are software pipelined -- the 16-byte loads of the NEXT row are in flight while this row is reduced and stored (a persistent
 // block otherwise has one row of loads outstanding per wave: the general kernel runs at 4.5 TB/s where a plain element-wise kernel with
 // the same three streams reaches 6.1) -- and nothing the mode does not need stays in registers (bias, the gate after its use).
-template <class TX, int VEC, int NCHUNK, int WPR>
+template <class TX, int VEC, int NCHUNK, int WPR, bool WVEC>
 __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_lean_kernel(NormArgs a) {
   NORM_ROWMAP();
   const TX* x = (const TX*)a.x;
@@ -354,9 +372,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_lean_kernel(NormA
   const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
   float wreg[NCHUNK][VEC];
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c++)
-#pragma unroll
-    for (int i = 0; i < VEC; i++) wreg[c][i] = load_rt(a.w, g0 + NORM_COL(c) + i, a.wdt);
+  for (int c = 0; c < NCHUNK; c++) load_w_row<VEC, WVEC>(a.w, g0 + NORM_COL(c), a.wdt, wreg[c]);
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   vec_t<TX, VEC> rx[NCHUNK], rz[NCHUNK];
   auto issue = [&](int64_t it) {
@@ -624,7 +640,7 @@ static int norm_blocks(int64_t rows, int ngroups, const VecPlan& pl) {
   const int rpb = NORM_WAVES / pl.wpr;
   int64_t per_group = (rows + rpb - 1) / rpb;
   int64_t cap = NORM_MAX_BLOCKS / ngroups;
-  if (const char* e = getenv("OMK_NORM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= 8192) cap = v / ngroups; }   // developer A/B
+  if (const char* e = getenv("OMK_NORM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) cap = v / ngroups; }   // developer A/B
   if (cap < 1) cap = 1;
   if (per_group > cap) per_group = cap;
   if (per_group < 1) per_group = 1;
@@ -760,9 +776,22 @@ extern "C" int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream) {
                     p->x.dtype == OMK_BF16 && !getenv("OMK_NORM_NO_LEAN");
   if (lean) {
     if (const char* e = getenv("OMK_NORM_ABL")) a.rms |= atoi(e) & 62;
-    if (plan.wpr == 1) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 4, 1>), grid, block, 0, stream, a);
-    else if (plan.nchunk == 2) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 2, 4>), grid, block, 0, stream, a);
-    else OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, 4, 4>), grid, block, 0, stream, a);
+    // SHORT-LIVED workgroups: two block rows each.  tools/probe/stream3_probe.hip (profiles/r06_stream_kernels.txt): the same three streams run
+    // at 5.7 TB/s from workgroups that live for one or two rows and at 5.1 - 5.3 from 1024 - 2048 persistent ones, whatever their row map
+    // (strided, contiguous ranges, an atomic queue) -- the rate falls steadily with the rows a workgroup walks.  The weight row is requested
+    // in 16-byte pieces so that the per-workgroup prologue stays small.
+    const bool wvec = ((uintptr_t)p->weight.data & 15) == 0 && (p->weight.ndim < 1 || p->weight.stride[p->weight.ndim - 1] == 1);
+    const int rpb = NORM_WAVES / plan.wpr;
+    int64_t per_group = (rows + rpb - 1) / rpb;
+    if (per_group > 2048) per_group = (per_group + 1) / 2;
+    if (const char* e = getenv("OMK_NORM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20) && v / a.ngroups < per_group) per_group = v / a.ngroups; }   // developer A/B
+    const dim3 lgrid((unsigned)(per_group * a.ngroups));
+#define OMK_LEAN_FWD(NC_, WPR_) do { if (wvec) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, NC_, WPR_, true>), lgrid, block, 0, stream, a); \
+      else OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, NC_, WPR_, false>), lgrid, block, 0, stream, a); } while (0)
+    if (plan.wpr == 1) OMK_LEAN_FWD(4, 1);
+    else if (plan.nchunk == 2) OMK_LEAN_FWD(2, 4);
+    else OMK_LEAN_FWD(4, 4);
+#undef OMK_LEAN_FWD
     return finish_launch("norm_gated_fwd");
   }
   OMK_DISPATCH_DTYPE(p->x.dtype, TX, OMK_PLAN_SWITCH(plan, OMK_LAUNCH((norm_gated_fwd_kernel<TX, VEC, NCHUNK, WPR>), grid, block, 0, stream, a)));
@@ -807,6 +836,8 @@ extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
   const bool lean = present(p->z) && present(p->dz) && !p->norm_before_gate && plan.vec == 8 && gsz == (int64_t)plan.wpr * plan.nchunk * 64 * 8 &&
                     p->x.dtype == OMK_BF16 && !getenv("OMK_NORM_NO_LEAN");
   if (lean) {
+    // (measured and not kept, profiles/r06_stream_kernels.txt: the next row's requests in a second staging set -- 150 registers, three waves per
+    // SIMD: 300 us against 290; the five streams with trivial arithmetic take 244 us on the same box, one-shot or persistent alike)
     if (plan.wpr == 1) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 1>), grid, block, 0, stream, a);
     else if (plan.nchunk == 2) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 2, 4>), grid, block, 0, stream, a);
     else OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 4>), grid, block, 0, stream, a);

@@ -335,6 +335,8 @@ __device__ __forceinline__ uint64_t clock64_() { return __builtin_readcyclecount
 // likes it and split where its vectoriser prefers a packed multiply + add (conv1d_fwd_cl8_kernel: tokens 5 .. 7 of every group of eight came
 // out unfused, 1e-5 of the outputs one bf16 ulp away from the other forward kernels).  Kernels whose results must agree bit for bit say fma.
 __device__ __forceinline__ float fma_f32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// the same on a pair of fp32 values: one v_pk_fma_f32
+__device__ __forceinline__ f32x2 fma_f32x2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float sigmoid_fast(float x) { return rcp_fast(1.f + exp2_fast(-x * LOG2E)); }
 // Wave totals of N per-lane values (N a power of two <= 64) with N - 1 + log2(64 / N) shuffles instead of the 6 N

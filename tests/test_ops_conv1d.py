@@ -46,6 +46,41 @@ def test_conv1d_fwd_bwd(dev, dtype, W, layout, C, L):
             assert rel(ir.grad, idd.grad) < gtol
 
 
+@pytest.mark.parametrize("W", [2, 3, 4])
+def test_conv1d_long_strips_both_prologues_agree(dev, W):
+    """The scalar-position kernels of long channel-last rows take a short prologue for contiguous fp32 (C, W) weights (16-byte requests, strips of
+    16 tokens in the forward) and the general run-time-dtype prologue for everything else: the same op with the same weights as a strided view and
+    as bf16-representable values in a bf16 tensor must give the same bits (forward, final states) and the same gradients."""
+    from omnimamba_amd.causal_conv1d import causal_conv1d_fn
+    torch.manual_seed(1)
+    B, C, L = 2, 12, 600
+    base = torch.randn(B, L, C + 4).bfloat16().to(dev)
+    w = torch.randn(C, W).bfloat16().float().to(dev)                 # bf16-representable values
+    b = torch.randn(C).bfloat16().float().to(dev)
+    init = torch.randn(B, C, W - 1).bfloat16().to(dev)
+    wide = torch.zeros(C, 2 * W, device=dev); wide[:, ::2] = w
+    variants = {"fp32 contiguous": (w, b), "fp32 strided view": (wide[:, ::2], b), "bf16": (w.bfloat16(), b.bfloat16())}
+    res = {}
+    for name, (wv, bv) in variants.items():
+        x = base[:, :, 4:].transpose(1, 2).detach().requires_grad_()
+        wr, br = wv.detach().requires_grad_(), bv.detach().requires_grad_()
+        ir = init.detach().requires_grad_()
+        out, fin = causal_conv1d_fn(x, wr, br, initial_states=ir, return_final_states=True, activation="silu")
+        g = torch.ones_like(out) * 0.5
+        out.backward(g)
+        res[name] = (out.detach().float().cpu(), fin.float().cpu(), x.grad.float().cpu(), wr.grad.float().cpu(), br.grad.float().cpu(), ir.grad.float().cpu())
+    ref = res["fp32 contiguous"]
+    for name in ("fp32 strided view", "bf16"):
+        got = res[name]
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), name                    # forward: bit for bit
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[5], ref[5]), name                    # dx, dinit: the same arithmetic
+        for i in (3, 4):                                                                             # dw, db: atomics, order free (bf16: rounded)
+            tol = 1e-2 if name == "bf16" else 1e-5
+            assert rel(got[i], ref[i].double()) < tol, (name, i)
+    o0 = O.causal_conv1d_ref(base[:, :, 4:].transpose(1, 2).cpu(), w.cpu(), b.cpu(), initial_states=init.cpu(), activation="silu")
+    assert rel(ref[0], o0) < 6e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv1d_update(dev, dtype):
     from omnimamba_amd.causal_conv1d import causal_conv1d_update
