@@ -538,6 +538,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_kernel(NormBwdArg
 // inputs stay in their 16-byte staging registers until their last use, three fp32 arrays cross the reduction.
 template <class TX, int VEC, int NCHUNK, int WPR>
 __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_lean_kernel(NormBwdArgs a) {
+  static_assert(std::is_same<TX, bf16_t>::value && VEC == 8, "packed bf16 pairs: a 16-byte staging register = four element pairs");
   NORM_ROWMAP();
   const TX* x = (const TX*)a.x;
   const TX* z = (const TX*)a.z;
@@ -551,65 +552,72 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_lean_kernel(NormB
   const int64_t bi = blockIdx.x / a.ngroups, nbg = gridDim.x / a.ngroups;
   // (the weight row lives in LDS, read per row: sixteen registers that decide between three and four waves per SIMD)
   __shared__ __attribute__((aligned(16))) float wsh[WPR * NCHUNK * 64 * VEC];
-  float dwacc[NCHUNK][VEC];
+  // Every element pair of a 32-bit input word is ONE packed fp32 pair from its conversion to the v_cvt_pk_bf16_f32 of the outputs (round 6):
+  // v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do both elements per instruction -- only the two exp2 and the two rcp of a pair stay scalar.
+  f32x2 dwacc[NCHUNK][4];
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c++)
+  for (int c = 0; c < NCHUNK; c++) {
 #pragma unroll
-    for (int i = 0; i < VEC; i++) { dwacc[c][i] = 0.f; if (wrow == 0) wsh[NORM_COL(c) + i] = load_rt(a.w, g0 + NORM_COL(c) + i, a.wdt); }
+    for (int e = 0; e < 4; e++) dwacc[c][e] = f32x2{0.f, 0.f};
+    if (wrow == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; i++) wsh[NORM_COL(c) + i] = load_rt(a.w, g0 + NORM_COL(c) + i, a.wdt);
+    }
+  }
   block_sync();
+  auto unpk = [](uint32_t w) -> f32x2 { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; };
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   for (int64_t it = bi; it < niter; it += nbg) {
     const int64_t rraw = it * RPB + wrow;
     const bool rlive = rraw < a.rows;
     const int64_t row = rlive ? rraw : a.rows - 1;
-    vec_t<TX, VEC> rx[NCHUNK], rz[NCHUNK], rd[NCHUNK];
+    u32x4 rx[NCHUNK], rz[NCHUNK], rd[NCHUNK];
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      rx[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(x + row * a.xs + g0 + NORM_COL(c));
-      rd[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(dy + row * a.dys + g0 + NORM_COL(c));
-      rz[c] = *reinterpret_cast<const vec_t<TX, VEC>*>(z + row * a.zs + g0 + NORM_COL(c));
+      rx[c] = *reinterpret_cast<const u32x4*>(x + row * a.xs + g0 + NORM_COL(c));
+      rd[c] = *reinterpret_cast<const u32x4*>(dy + row * a.dys + g0 + NORM_COL(c));
+      rz[c] = *reinterpret_cast<const u32x4*>(z + row * a.zs + g0 + NORM_COL(c));
     }
-    float gv[NCHUNK][VEC], wdy[NCHUNK][VEC], sig[NCHUNK][VEC];
-    float s2 = 0.f, t2 = 0.f;
+    f32x2 gv[NCHUNK][4], wdy[NCHUNK][4], sig[NCHUNK][4];
+    f32x2 s2v = {0.f, 0.f}, t2v = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
-      for (int i = 0; i < VEC; i++) {
-        const float zf = to_f32(rz[c].e[i]);
-        sig[c][i] = sigmoid_fast(zf);
-        const float wv = wsh[NORM_COL(c) + i];
-        gv[c][i] = to_f32(rx[c].e[i]) * (zf * sig[c][i]);      // x silu(z): what the norm sees
-        wdy[c][i] = rlive ? to_f32(rd[c].e[i]) * wv : 0.f;
-        s2 += gv[c][i] * gv[c][i];
-        t2 += gv[c][i] * wdy[c][i];
+      for (int e = 0; e < 4; e++) {
+        const f32x2 zf = unpk(rz[c][e]);
+        const f32x2 t = zf * (-LOG2E);
+        const f32x2 q = f32x2{exp2_fast(t[0]), exp2_fast(t[1])} + 1.f;
+        sig[c][e] = f32x2{rcp_fast(q[0]), rcp_fast(q[1])};
+        const f32x2 wv = *reinterpret_cast<const f32x2*>(&wsh[NORM_COL(c) + 2 * e]);
+        gv[c][e] = unpk(rx[c][e]) * (zf * sig[c][e]);           // x silu(z): what the norm sees
+        wdy[c][e] = rlive ? unpk(rd[c][e]) * wv : f32x2{0.f, 0.f};
+        s2v = fma_f32x2(gv[c][e], gv[c][e], s2v);
+        t2v = fma_f32x2(gv[c][e], wdy[c][e], t2v);
       }
+    float s2 = s2v[0] + s2v[1], t2 = t2v[0] + t2v[1];
     row_sum2<WPR>(s2, t2, red, wave, rpar);
     const float rstd = rsqrtf(s2 * inv_n + a.eps);
     const float c1 = rstd * t2 * inv_n;
     // (the staging registers made opaque: the second pass converts the packed inputs again instead of keeping 48 fp32 copies alive)
 #pragma unroll
-    for (int c = 0; c < NCHUNK; c++) {
-      static_assert(sizeof(vec_t<TX, VEC>) == 16, "16-byte staging registers");
-      u32x4 qx = __builtin_bit_cast(u32x4, rx[c]), qz = __builtin_bit_cast(u32x4, rz[c]), qd = __builtin_bit_cast(u32x4, rd[c]);
+    for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) { OMK_OPAQUE(qx[e]); OMK_OPAQUE(qz[e]); OMK_OPAQUE(qd[e]); }
-      rx[c] = __builtin_bit_cast(vec_t<TX, VEC>, qx); rz[c] = __builtin_bit_cast(vec_t<TX, VEC>, qz); rd[c] = __builtin_bit_cast(vec_t<TX, VEC>, qd);
-    }
+      for (int e = 0; e < 4; e++) { OMK_OPAQUE(rx[c][e]); OMK_OPAQUE(rz[c][e]); OMK_OPAQUE(rd[c][e]); }
     if (rlive) {
 #pragma unroll
       for (int c = 0; c < NCHUNK; c++) {
-        float ox[VEC], oz[VEC];
+        u32x4 ox, oz;
 #pragma unroll
-        for (int i = 0; i < VEC; i++) {
-          const float xhat = gv[c][i] * rstd;
-          dwacc[c][i] += to_f32(rd[c].e[i]) * xhat;
-          const float dg = (wdy[c][i] - xhat * c1) * rstd;     // grad wrt the normalised input x silu(z)
-          const float zf = to_f32(rz[c].e[i]), sg = sig[c][i], ds = dg * sg;
-          ox[i] = ds * zf;
-          oz[i] = ds * to_f32(rx[c].e[i]) * (1.f + zf * (1.f - sg));
+        for (int e = 0; e < 4; e++) {
+          const f32x2 xhat = gv[c][e] * rstd, zf = unpk(rz[c][e]), sg = sig[c][e];
+          dwacc[c][e] = fma_f32x2(unpk(rd[c][e]), xhat, dwacc[c][e]);
+          const f32x2 ds = (wdy[c][e] - xhat * c1) * rstd * sg;     // grad wrt the normalised input x silu(z), times the sigmoid
+          const f32x2 vx = ds * zf, vz = ds * unpk(rx[c][e]) * (1.f + zf * (1.f - sg));
+          ox[e] = pack_bf16x2(vx[0], vx[1]);
+          oz[e] = pack_bf16x2(vz[0], vz[1]);
         }
-        st<TX, VEC>(dx + rraw * a.dxs + g0 + NORM_COL(c), ox);
-        st<TX, VEC>(dz + rraw * a.dzs + g0 + NORM_COL(c), oz);
+        *reinterpret_cast<u32x4*>(dx + rraw * a.dxs + g0 + NORM_COL(c)) = ox;
+        *reinterpret_cast<u32x4*>(dz + rraw * a.dzs + g0 + NORM_COL(c)) = oz;
       }
     }
   }
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_lean_kernel(NormB
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++)
 #pragma unroll
-      for (int i = 0; i < VEC; i++) a.dw_part[part * a.cols + g0 + NORM_COL(c) + i] = dwacc[c][i];
+      for (int e = 0; e < 4; e++) *reinterpret_cast<f32x2*>(&a.dw_part[part * a.cols + g0 + NORM_COL(c) + 2 * e]) = dwacc[c][e];
   }
 }
 
