@@ -582,7 +582,11 @@ using namespace omk;
 extern "C" size_t omk_ssd_scan_fwd_workspace_bytes(const OmkSsdFwd* p) {
   if (!p) return 0;
   // dt' + developer profiling slots + the segment states of a split sequence (ssd_scan.h)
-  return align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024 + ssd_seg_bytes((int)(p->x.shape[0] * p->x.shape[2]), (int)p->x.shape[1]);
+  size_t n = align256((size_t)p->x.shape[0] * p->x.shape[1] * p->x.shape[2] * 4) + 1024 + ssd_seg_bytes((int)(p->x.shape[0] * p->x.shape[2]), (int)p->x.shape[1]);
+#ifdef OMK_PHASE_PROF
+  n += 64 * 1024;   // developer build: first / last wall clock of every workgroup (ssd_a8.hip PT8_END), at the END of the workspace
+#endif
+  return n;
 }
 
 // Can this forward leave its window states behind, and how large are they?  The class-A MFMA kernel of the plain scan only (bf16,
@@ -651,6 +655,8 @@ extern "C" int omk_ssd_scan_fwd(const OmkSsdFwd* p, omk_stream stream) {
   if (getenv("OMK_PROF") && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p)) g.prof = (unsigned long long*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4));
 #ifdef OMK_PHASE_PROF
   if (const char* e = getenv("OMK_ABLATE")) g.ablate = atoi(e);
+  if (getenv("OMK_PROF_WG") && p->workspace_bytes >= omk_ssd_scan_fwd_workspace_bytes(p))   // the per-workgroup clocks instead of the phase sums: slots behind everything else
+    { g.prof = (unsigned long long*)((char*)p->workspace + omk_ssd_scan_fwd_workspace_bytes(p) - 64 * 1024); g.ablate |= 1 << 20; }
 #endif
   g.flags = p->flags & (GSF_PRECISE | GSF_KHILO | GSF_FLUSH | GSF_NO_SPLIT | GSF_COLUMN_SLICE);
   if (ssd_seg_bytes(d.B * d.H, d.L) && !(p->flags & OMK_SSD_NO_SPLIT)) g.seg = (float*)((char*)p->workspace + align256((size_t)d.B * d.H * d.L * 4) + 1024);

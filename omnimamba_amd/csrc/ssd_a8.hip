@@ -80,10 +80,16 @@ __global__ __launch_bounds__(512) void ssd_a8_kernel(GScan a) {
   uint64_t pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const bool prof = a.prof != nullptr && blockIdx.x == 0;
 #define PT8(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
-#define PT8_END() do { if (prof) { pt[10] = clock64_() - t_core0; \
+  // (every workgroup also leaves the 100 MHz wall clock of its first and last instruction + its XCC_ID behind the per-wave slots: when do the
+  // workgroups of one launch finish -- the launch lasts as long as its slowest one)
+#define PT8_END() do { if (a.prof != nullptr && (a.ablate & (1 << 20)) && lane == 0 && (wave == 0 || wave == 4)) { \
+      a.prof[128 + 4 * blockIdx.x + (wave >> 2) * 2] = t_wall0; \
+      a.prof[128 + 4 * blockIdx.x + (wave >> 2) * 2 + 1] = __builtin_readsteadycounter() | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 60); } \
+    if (prof) { pt[10] = clock64_() - t_core0; \
     pt[11] = (__builtin_readsteadycounter() - t_ref0) | ((uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 40); \
     if (lane == 0) for (int i = 0; i < 12; i++) a.prof[wave * 12 + i] = pt[i]; } } while (0)
   uint64_t tprev = 0, t_core0 = 0, t_ref0 = 0;
+  const uint64_t t_wall0 = __builtin_readsteadycounter();
 #define PT8_START() do { if (prof) { tprev = clock64_(); t_core0 = tprev; t_ref0 = __builtin_readsteadycounter(); } } while (0)
 #else
 #define PT8(i) do { } while (0)

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
   uint64_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool prof = a.prof != nullptr && blockIdx.x == 0;
   uint64_t tprev = prof ? clock64_() : 0;
+  const uint64_t t_wall0 = __builtin_readsteadycounter();   // (every workgroup: 100 MHz wall clock of its first / last instruction + XCC_ID, slots behind the phase sums)
 #define PTC(i) do { if (prof) { uint64_t n_ = clock64_(); pt[i] += n_ - tprev; tprev = n_; } } while (0)
 #else
 #define PTC(i) do { } while (0)
@@ -468,6 +469,12 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
           *reinterpret_cast<u32x2*>(dBp + n) = u32x2{pack_bf16x2(dBt[j][4 * q], dBt[j][4 * q + 1]), pack_bf16x2(dBt[j][4 * q + 2], dBt[j][4 * q + 3])};
         }
     }
+#ifdef OMK_PHASE_PROF
+    if (a.prof != nullptr && threadIdx.x == 0) {
+      a.prof[64 + 2 * blockIdx.x] = t_wall0;
+      a.prof[64 + 2 * blockIdx.x + 1] = __builtin_readsteadycounter() | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 60);
+    }
+#endif
     return;
   }
   // ---- fp32 partials of this head subset: [hs][b][t][g][n]
@@ -482,6 +489,12 @@ __global__ __launch_bounds__(512) void ssd_cp_kernel(CpArgs a) {
         *reinterpret_cast<f32x4*>(a.pB + row + n) = f32x4{dBt[j][4 * q], dBt[j][4 * q + 1], dBt[j][4 * q + 2], dBt[j][4 * q + 3]};
       }
   }
+#ifdef OMK_PHASE_PROF
+  if (a.prof != nullptr && threadIdx.x == 0) {
+    a.prof[64 + 2 * blockIdx.x] = t_wall0;
+    a.prof[64 + 2 * blockIdx.x + 1] = __builtin_readsteadycounter() | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 60);
+  }
+#endif
 }
 
 // out[b][t][g][n] = sum over the head subsets of part[hs][b][t][g][n], in the gradient's dtype; one thread = 8 consecutive n.
@@ -546,7 +559,7 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
 #ifdef OMK_PHASE_PROF
   static unsigned long long* dprof = nullptr;
   const bool want = getenv("OMK_CP_PROF") != nullptr;
-  if (want && !dprof) (void)hipMalloc((void**)&dprof, 64 * sizeof(unsigned long long));
+  if (want && !dprof) (void)hipMalloc((void**)&dprof, (64 + 2 * 8192) * sizeof(unsigned long long));
   a.prof = want ? dprof : nullptr;
 #endif
   OMK_LAUNCH(ssd_cp_kernel, grid, block, smem, stream, a);
@@ -563,6 +576,24 @@ int ssd_cp_launch(const CpArgs& a0, omk_stream stream) {
       for (int i = 0; i < 8; i++) { fprintf(stderr, "%10llu", hp[w * 8 + i] / hps); tot += hp[w * 8 + i]; }
       fprintf(stderr, "%10llu\n", tot / hps);
     }
+    // when did the workgroups finish?  (the launch lasts as long as its slowest one)
+    const int nwg = (int)grid.x < 8192 ? (int)grid.x : 8192;
+    unsigned long long* st = (unsigned long long*)malloc((size_t)nwg * 16);
+    (void)hipMemcpy(st, dprof + 64, (size_t)nwg * 16, hipMemcpyDeviceToHost);
+    const unsigned long long mask = (1ull << 60) - 1;
+    unsigned long long t0 = ~0ull, t1 = 0; double busy = 0, fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nwg; i++) t0 = st[2 * i] < t0 ? st[2 * i] : t0;
+    double emin = 1e30;
+    for (int i = 0; i < nwg; i++) {
+      const unsigned long long e = st[2 * i + 1] & mask; const int xc = (int)(st[2 * i + 1] >> 60) & 7;
+      t1 = e > t1 ? e : t1; busy += (double)(e - st[2 * i]);
+      const double ef = (double)(e - t0) * 0.01; emin = ef < emin ? ef : emin; fx[xc] += ef; nx[xc]++; mx[xc] = ef > mx[xc] ? ef : mx[xc];
+    }
+    fprintf(stderr, "ssd_cp workgroups: %d, finish min %.1f max %.1f us, mean busy %.1f us = %.2f of the launch; per XCC mean / max finish:", nwg, emin, (double)(t1 - t0) * 0.01,
+            busy / nwg * 0.01, busy / nwg / (double)(t1 - t0));
+    for (int xc = 0; xc < 8; xc++) if (nx[xc]) fprintf(stderr, "  %d: %.0f / %.0f", xc, fx[xc] / nx[xc], mx[xc]);
+    fprintf(stderr, "\n");
+    free(st);
   }
 #endif
   if (a.direct) return OMK_OK;   // (written by the kernel itself)

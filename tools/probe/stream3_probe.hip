@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int COLS = 4096, ZROW = 8512, VPR = COLS / 8;   // 512 16-byte vectors per row
@@ -41,7 +42,7 @@ __device__ __forceinline__ u32x4 scale8(const float (&g)[8], float r, const floa
   return o;
 }
 
-struct A { const uint16_t* x; const uint16_t* z; uint16_t* y; const float* w; int64_t rows; int nt; };
+struct A { const uint16_t* x; const uint16_t* z; uint16_t* y; const float* w; int64_t rows; int nt; unsigned long long* stamp; int perm; };
 
 // (0) element-wise, one shot: UNR 16-byte vectors per lane and stream, a workgroup = 256 * UNR consecutive vectors; no reduction
 template <int UNR>
@@ -88,8 +89,11 @@ __global__ __launch_bounds__(256) void wg_row_kernel(A a) {
     }
   };
   int par = 0;
-  issue(blockIdx.x);
-  for (int64_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  const unsigned long long t_begin = a.stamp ? wall_clock64() : 0;
+  // perm: workgroup b takes row index (b / 8) + (b % 8) (G / 8) -- an XCD (= b % 8) then owns a contiguous eighth of every G rows instead of every 8th row
+  const int64_t first = a.perm ? (int64_t)(blockIdx.x >> 3) + (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) : blockIdx.x;
+  issue(first);
+  for (int64_t row = first; row < a.rows; row += gridDim.x) {
     float g[2][8]; float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; c++) s += gate8(rx[c], rz[c], g[c]);
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(256) void wg_row_kernel(A a) {
     }
     if (ONE) break;
   }
+  if (a.stamp && threadIdx.x == 0) { a.stamp[2 * blockIdx.x] = t_begin; a.stamp[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
 // (4) the persistent workgroup-per-row kernel with other row maps: MAP 0 strided without prefetch, 1 a contiguous range of K rows per
@@ -452,6 +457,26 @@ int main(int argc, char** argv) {
     for (int g : {1024, 2048}) {
       char nm[96]; snprintf(nm, sizeof nm, "wave pair per row, persistent x %d, norm", g);
       report(nm, time_us([&] { pair_row_kernel<false><<<dim3(g), 256>>>(a); }));
+    }
+  }
+  {   // when do the workgroups of the persistent kernel start and finish?  (100 MHz wall clock)
+    for (int pass = 0; pass < 4; pass++) {
+      const int g = (pass & 1) ? 2048 : 1024;
+      unsigned long long* st; hipMalloc(&st, (size_t)g * 16);
+      A b = a; b.stamp = st; b.nt = 0; b.perm = pass >> 1;
+      if (b.perm) printf("(rows permuted: an XCD owns a contiguous eighth of every G rows)\n");
+      wg_row_kernel<false, true><<<dim3(g), 256>>>(b); hipDeviceSynchronize();
+      wg_row_kernel<false, true><<<dim3(g), 256>>>(b); hipDeviceSynchronize();
+      std::vector<unsigned long long> h(2 * g); hipMemcpy(h.data(), st, (size_t)g * 16, hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull; for (int i = 0; i < g; i++) t0 = h[2 * i] < t0 ? h[2 * i] : t0;
+      std::vector<double> b0(g), e0(g);
+      for (int i = 0; i < g; i++) { b0[i] = (h[2 * i] - t0) * 0.01; e0[i] = (h[2 * i + 1] - t0) * 0.01; }
+      std::vector<double> bs = b0, es = e0; std::sort(bs.begin(), bs.end()); std::sort(es.begin(), es.end());
+      printf("persistent x %d: workgroup start  min %.1f  median %.1f  max %.1f us | finish  min %.1f  5%% %.1f  median %.1f  95%% %.1f  max %.1f us\n", g,
+             bs[0], bs[g / 2], bs[g - 1], es[0], es[g / 20], es[g / 2], es[g - g / 20 - 1], es[g - 1]);
+      // by XCD (workgroup id mod 8): median finish
+      for (int xcd = 0; xcd < 8; xcd++) { std::vector<double> v; for (int i = xcd; i < g; i += 8) v.push_back(e0[i]); std::sort(v.begin(), v.end()); printf("   xcd %d: finish median %.1f max %.1f\n", xcd, v[v.size() / 2], v.back()); }
+      hipFree(st);
     }
   }
   {
