@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OMK_ABI_VERSION 6
+#define OMK_ABI_VERSION 7
 #define OMK_MAX_DIMS 5
 
 typedef enum { OMK_OK = 0, OMK_EINVAL = -1, OMK_EARCH = -2, OMK_ELAUNCH = -3, OMK_EUNSUPPORTED = -4 } omk_status;
@@ -383,16 +383,19 @@ int omk_cross_entropy(const OmkCrossEntropy* p, omk_stream stream);
  * (argmax) and the top_k > 0 branch (top-k -> / temperature -> top-p filter of :64-76 -> multinomial), for 1 <= top_k <= 64.
  * One uniform per row from Philox4x32-10 keyed by (seed, row, *step_counter + offset): the reference draws with
  * torch.multinomial, so the ids agree in distribution (and exactly for top_k == 1), not stream for stream.  step_counter is a
- * device int64 the caller advances (inside its captured graph), NULL = 0.  top_k == 0 with top_p <= 0 or >= 1 is the plain
- * multinomial of softmax(logits / temperature) over the whole vocabulary (:114-119 with an inactive filter: the default
- * arguments of t2i_generate); a top-p cut or min_p over the whole vocabulary stays on the host library (OMK_EINVAL here).     */
+ * device int64 the caller advances (inside its captured graph), NULL = 0.  top_k == 0 is the whole-vocabulary branch (:107-119):
+ * the plain multinomial of softmax(logits / temperature) (the default arguments of t2i_generate), behind the reference's top-p cut
+ * when 0 < top_p < 1 (ascending cumulative probability <= 1 - top_p is cut, ties at the boundary in index order) or, ABI 7, behind its
+ * min_p filter when min_p > 0 (a raw logit below min_p x the largest softmax(logits) probability is cut -- the reference's own
+ * comparison, :43; top_p is ignored then, as there; a row with nothing left returns its arg max where the reference raises).      */
 typedef struct {
   OmkTensor logits;        /* (batch, vocab) f32 / bf16 / f16, unit last stride */
   OmkTensor out_ids;       /* out (batch) int64, dense (dtype field ignored) */
   const void* step_counter; /* optional device int64 */
   uint64_t seed, offset;
-  int32_t top_k;           /* 0 (whole vocabulary, no top-p cut) or 1 .. 64 */
+  int32_t top_k;           /* 0 (whole vocabulary) or 1 .. 64 */
   float top_p, temperature;
+  float min_p;             /* ABI 7 (occupies the former tail padding): 0 = off; > 0 only with top_k == 0 */
 } OmkSample;
 int omk_sample(const OmkSample* p, omk_stream stream);
 

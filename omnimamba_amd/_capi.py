@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-OMK_ABI_VERSION = 6
+OMK_ABI_VERSION = 7
 OMK_MAX_DIMS = 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.uint8: 3, torch.bool: 3}   # 3 = OMK_U8: masks only
 
@@ -88,7 +88,7 @@ CrossEntropy = _S("OmkCrossEntropy", [("logits", _t), ("labels", C.c_void_p), ("
                                       ("ignore_index", _i64), ("write_grad", _i)])
 
 Sample = _S("OmkSample", [("logits", _t), ("out_ids", _t), ("step_counter", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
-                          ("top_k", _i), ("top_p", _f), ("temperature", _f)])
+                          ("top_k", _i), ("top_p", _f), ("temperature", _f), ("min_p", _f)])
 
 STRUCTS = {s.__name__: s for s in (Sample, CrossEntropy, OmkTensor, AddNormFwd, AddNormBwd, NormGatedFwd, NormGatedBwd, Conv1dFwd, Conv1dBwd,
                                    Conv1dUpdate, StateUpdate, SelScanFwd, SelScanBwd, NormLinear, LoraAdd, LoraUpBwd, SsdFwd, SsdBwd)}

@@ -78,8 +78,9 @@ def sample(logits, top_k=1, top_p=0.0, min_p=0.0, temperature=1.0):
         assert top_p <= 1.0, "top-p should be in (0, 1]."
     kk = min(top_k, logits.size(-1)) if top_k > 0 else 0
     if logits.is_cuda and SMP.applies(logits, kk, min_p=min_p if top_k <= 0 else 0.0, top_p=top_p):
-        # 1 < top_k <= 64, or the whole vocabulary without a top-p / min-p cut (t2i_generate's default arguments: top_k 0, top_p 1.0)
-        return SMP.sample_device(logits, top_k=kk, top_p=top_p, temperature=temperature, seed=torch.initial_seed(), offset=_stream_base())
+        # 1 < top_k <= 64, or the whole-vocabulary branch (t2i_generate's default arguments: top_k 0, top_p 1.0; its top-p cut; its min_p filter)
+        return SMP.sample_device(logits, top_k=kk, top_p=top_p, temperature=temperature, seed=torch.initial_seed(), offset=_stream_base(),
+                                 min_p=min_p if top_k <= 0 else 0.0)
     if top_k > 0:
         top_k = min(top_k, logits.size(-1))
         vals, idx = torch.topk(logits, top_k, dim=-1)
@@ -185,7 +186,7 @@ class GreedyLoopGraph:
     when top_k == 1 and there is no EOS test (the T2I path: exactly num_tokens codes, omnimamba.py:321)."""
 
     def __init__(self, model, inference_params, batch_size, max_seqlen, n_steps, task, n_warmups=2, top_k=1, top_p=0.0, temperature=1.0,
-                 seed=0):
+                 seed=0, min_p=0.0):
         dev = next(iter(model.parameters())).device
         self.ip = inference_params
         self.draw = torch.zeros((), dtype=torch.int64, device=dev)      # Philox stream position, advanced inside the graph
@@ -204,7 +205,7 @@ class GreedyLoopGraph:
             if top_k == 1:
                 nxt = lg.argmax(dim=-1, keepdim=True)
             else:   # top-k / temperature / top-p / draw as ONE launch that reads its stream position from device memory
-                nxt = SMP.sample_device(lg, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, step_counter=self.draw).unsqueeze(1)
+                nxt = SMP.sample_device(lg, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, step_counter=self.draw, min_p=min_p).unsqueeze(1)
                 self.draw.add_(1)
             self.tokens.scatter_(1, self.slot.clamp(max=self.tokens.shape[1] - 1), nxt)
             self.input_ids.copy_(nxt)
@@ -291,9 +292,9 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     graph = None
     if hasattr(model, "prepare_decode"):
         model.prepare_decode(task)      # per-token-id tables of the embedding MLPs, built outside any graph capture
-    if (device_loop and cg and (1 <= top_k <= SMP.MAX_TOP_K or (top_k == 0 and (top_p <= 0.0 or top_p >= 1.0))) and min_p == 0.0 and eos_token_id is None and teacher_outputs is None
+    if (device_loop and cg and (1 <= top_k <= SMP.MAX_TOP_K or (top_k == 0 and 0.0 <= min_p < 1.0)) and eos_token_id is None and teacher_outputs is None
             and vocab_size is None and trace is None and scores is None):
-        return _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k, top_p, temperature)
+        return _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k, top_p, temperature, min_p=min_p if top_k == 0 else 0.0)
     if cg:
         # the reference's cache rule (generation.py:308-369): one set of state tensors and one graph memory pool, thrown away
         # only when the device / dtype changes or a LARGER batch or max_seqlen arrives; captured steps are kept per
@@ -393,7 +394,7 @@ def decode(input_ids, input_embeddings, model, max_length, top_k=1, top_p=0.0, m
     return seqs
 
 
-def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k=1, top_p=0.0, temperature=1.0):
+def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, top_k=1, top_p=0.0, temperature=1.0, min_p=0.0):
     """Prefill (eager, fills the caches), then max_length - P - 1 replays of GreedyLoopGraph."""
     batch_size, seqlen_pr = input_ids.shape[0], input_embeddings.shape[1]   # (the embedding sequence is the prompt: see decode)
     dev = input_embeddings.device
@@ -404,14 +405,14 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
         raise IndexError(f"decode: max_length {max_length} runs past the {task} position table of {n_pos} rows")
     cache = getattr(model, "_decoding_cache", None)
     seed = torch.initial_seed()
-    key = ("device_loop", batch_size, max_length, n_steps, task, top_k, top_p, temperature, seed if top_k != 1 else 0)
+    key = ("device_loop", batch_size, max_length, n_steps, task, top_k, top_p, temperature, min_p, seed if top_k != 1 else 0)
     if cache is None or cache.get("kind") != "device_loop" or cache.get("key") != key:
         dtype = next(iter(model.parameters())).dtype
         ip = InferenceParams(max_seqlen=max_length, max_batch_size=batch_size, seqlen_offset=seqlen_pr,
                              key_value_memory_dict=model.allocate_inference_cache(batch_size, max_length, dtype),
                              lengths_per_sample=torch.full((batch_size,), seqlen_pr, dtype=torch.int32, device=dev))
         cache = {"kind": "device_loop", "key": key, "ip": ip,
-                 "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed)}
+                 "graph": GreedyLoopGraph(model, ip, batch_size, max_length, n_steps, task, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, min_p=min_p)}
         if _prefill_graph_ok(seqlen_pr):
             ip.reset(max_length, batch_size)
             cache["prefill"] = PrefillGraph(model, ip, batch_size, seqlen_pr, input_embeddings.shape[-1], task, input_embeddings.dtype)
@@ -426,7 +427,7 @@ def _decode_device_loop(input_ids, input_embeddings, model, max_length, task, to
         lg0 = (out.t2i_logits if task == "t2i" else out.mmu_logits).squeeze(1)
     base = 0 if top_k == 1 else _stream_base()   # this call's stretch of the Philox stream: base, base + 1, ... (one position per token)
     first = (lg0.argmax(dim=-1, keepdim=True) if top_k == 1 else
-             SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=base).unsqueeze(1))
+             SMP.sample_device(lg0, top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, offset=base, min_p=min_p).unsqueeze(1))
     ip.seqlen_offset = seqlen_pr
     seqs = torch.cat([input_ids, first], dim=1)
     if n_steps > 0:

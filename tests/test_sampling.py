@@ -83,7 +83,7 @@ def test_topk_topp_distribution_matches_reference(dev, top_k, top_p, temp):
 def test_full_vocabulary_multinomial_matches_reference(dev, temp, top_p):
     """top_k == 0 with top_p outside (0, 1) -- the default arguments of the reference's t2i_generate (omnimamba.py:311) -- is the plain
     multinomial of softmax(logits / T) over the whole vocabulary (generation.py:114-119): chi-square of 8192 / 2048 draws against those
-    probabilities, -inf logits never drawn, reproducible per (seed, counter); a top-p cut over the whole vocabulary is refused."""
+    probabilities, -inf logits never drawn, reproducible per (seed, counter)."""
     from omnimamba_amd.sampling import applies, sample_device
     g = torch.Generator().manual_seed(5)
     V = 16384 if dev.type == "cuda" else 1500
@@ -92,7 +92,7 @@ def test_full_vocabulary_multinomial_matches_reference(dev, temp, top_p):
     p_ref = torch.softmax(row.double() / temp, -1)
     nrow, nlaunch = (512, 16) if dev.type == "cuda" else (64, 32)
     logits = row[None].repeat(nrow, 1).contiguous().to(dev)
-    assert applies(logits, 0, top_p=top_p) and not applies(logits, 0, top_p=0.5) and not applies(logits, 0, min_p=0.1, top_p=top_p)
+    assert applies(logits, 0, top_p=top_p) and applies(logits, 0, top_p=0.5) and applies(logits, 0, min_p=0.1, top_p=top_p) and not applies(logits, 0, min_p=1.5)
     counter = torch.zeros((), dtype=torch.int64, device=dev)
     counts = torch.zeros(V, dtype=torch.float64)
     for i in range(nlaunch):
@@ -113,8 +113,90 @@ def test_full_vocabulary_multinomial_matches_reference(dev, temp, top_p):
     a = sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=77, step_counter=counter)
     b = sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=77, step_counter=counter)
     assert torch.equal(a, b) and not torch.equal(a, sample_device(logits, top_k=0, top_p=top_p, temperature=temp, seed=78, step_counter=counter))
-    with pytest.raises(RuntimeError):
-        sample_device(logits, top_k=0, top_p=0.5)
+
+
+def _ref_full_filtered(row, top_p, min_p, temp):
+    """The reference's whole-vocabulary branch (generation.py:107-119) as probabilities over the vocabulary + the mask of removed tokens."""
+    row = row.float()
+    if min_p > 0.0:
+        thr = torch.softmax(row, -1).max() * min_p          # a probability ... compared with the raw logits (:43, :110-111)
+        removed = row < thr
+        work = row.masked_fill(removed, float("-inf")) / temp
+    else:
+        work = row / temp
+        sv, si = torch.sort(work, descending=False, stable=True)
+        rem_sorted = sv.softmax(-1).cumsum(-1) <= (1 - top_p)
+        removed = torch.zeros_like(rem_sorted).scatter(0, si, rem_sorted)
+        work = work.masked_fill(removed, float("-inf"))
+    return torch.softmax(work.double(), -1), removed
+
+
+@pytest.mark.parametrize("top_p,min_p,temp", [(0.9, 0.0, 1.0), (0.5, 0.0, 0.7), (0.05, 0.0, 1.3), (0.0, 0.02, 1.0), (0.3, 0.2, 0.8)])
+def test_full_vocabulary_top_p_and_min_p_filters_match_reference(dev, top_p, min_p, temp):
+    """top_k == 0 behind the reference's two filters of that branch (generation.py:107-119), on the device since round 6: the top-p cut over
+    ALL tokens (ascending cumulative probability <= 1 - top_p is cut) and min_p (a raw logit under min_p x the largest probability is cut; top_p
+    is ignored then).  No draw may land on a token the reference removes (the one token at the boundary of the cumulative sum excepted: the
+    reference adds fp32 probabilities in sorted order, the kernel 2^-40 fixed-point masses), and 4096+ draws follow its probabilities."""
+    from omnimamba_amd.sampling import applies, sample_device
+    g = torch.Generator().manual_seed(11)
+    V = 16384 if dev.type == "cuda" else 1200
+    row = torch.randn(V, generator=g) * 2.5 + 1.0
+    row[::11] = float("-inf")
+    p_ref, removed = _ref_full_filtered(row, top_p, min_p, temp)
+    nrow, nlaunch = (512, 16) if dev.type == "cuda" else (64, 20)
+    logits = row[None].repeat(nrow, 1).contiguous().to(dev)
+    assert applies(logits, 0, top_p=top_p, min_p=min_p)
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    counts = torch.zeros(V, dtype=torch.float64)
+    for i in range(nlaunch):
+        counter.fill_(i)
+        counts += torch.bincount(sample_device(logits, top_k=0, top_p=top_p, min_p=min_p, temperature=temp, seed=21, step_counter=counter).cpu(), minlength=V).double()
+    n = nrow * nlaunch
+    assert counts.sum() == n
+    wrong = torch.nonzero((counts > 0) & removed).flatten()
+    if min_p > 0.0:
+        assert wrong.numel() == 0
+    else:   # at most the largest removed token (the boundary of the cumulative sum)
+        finite_removed = torch.where(removed & torch.isfinite(row), row, torch.full_like(row, float("-inf")))
+        assert wrong.numel() <= 1 and (wrong.numel() == 0 or row[wrong[0]] == finite_removed.max())
+    exp = p_ref * n
+    big = exp >= 5
+    chi = (((counts[big] - exp[big]) ** 2) / exp[big]).sum().item()
+    dof = int(big.sum().item()) - 1
+    e, o = exp[~big].sum().item(), counts[~big].sum().item()
+    if e > 0:
+        chi += (o - e) ** 2 / e
+        dof += 1
+    assert chi < dof + 5 * math.sqrt(2 * max(dof, 1)) + 5, (chi, dof)
+    counter.fill_(3)
+    a = sample_device(logits, top_k=0, top_p=top_p, min_p=min_p, temperature=temp, seed=21, step_counter=counter)
+    assert torch.equal(a, sample_device(logits, top_k=0, top_p=top_p, min_p=min_p, temperature=temp, seed=21, step_counter=counter))
+
+
+def test_full_vocabulary_top_p_ties_and_empty_min_p(dev):
+    """Equal logits at the boundary of the top-p cut are removed in index order (what a stable ascending sort does); a tiny top_p leaves the
+    arg max alone; min_p with every logit under the threshold (all-negative logits: the reference's multinomial raises on the NaN row) gives the
+    arg max."""
+    from omnimamba_amd.sampling import sample_device
+    V = 700
+    row = torch.full((V,), -3.0)
+    row[100:140] = 1.0          # forty equal tokens hold most of the mass: the cut ends inside them
+    row[5] = 2.0
+    p_ref, removed = _ref_full_filtered(row, 0.6, 0.0, 1.0)
+    kept_ties = [i for i in range(100, 140) if not removed[i]]
+    assert 0 < len(kept_ties) < 40 and kept_ties == list(range(140 - len(kept_ties), 140))      # the reference cuts the lowest indices
+    logits = row[None].repeat(64, 1).contiguous().to(dev)
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    seen = set()
+    for i in range(24):
+        counter.fill_(i)
+        seen |= set(sample_device(logits, top_k=0, top_p=0.6, seed=9, step_counter=counter).cpu().tolist())
+    assert seen <= set(kept_ties) | {5} and len(seen & set(kept_ties)) >= len(kept_ties) - 2, (sorted(seen), kept_ties)
+    ids = sample_device(logits, top_k=0, top_p=1e-6, seed=9)
+    assert (ids.cpu() == 5).all()
+    neg = (-torch.rand(3, V) - 0.5).to(dev)
+    ids = sample_device(neg, top_k=0, min_p=0.5, seed=1)
+    assert torch.equal(ids.cpu(), neg.cpu().argmax(-1))
 
 
 def test_ties_at_the_threshold_take_the_lowest_indices(dev):
