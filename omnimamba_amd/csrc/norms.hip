@@ -64,6 +64,7 @@ struct NormArgs {
   void* y; void* ro; float* rstd; float* mean;
   int64_t xs, rs, ys, ros, zs;      // row strides (elements)
   int64_t rows; int cols; int ngroups; int wdt, bdt; float eps; int rms; int norm_before_gate;
+  int wvec;                         // weight (and bias) rows can be requested in 16-byte pieces and every lane's columns exist (launcher)
 };
 struct NormBwdArgs {
   const void* dy; const void* dro; const void* xsum; const void* w; const float* rstd; const float* mean;
@@ -73,6 +74,24 @@ struct NormBwdArgs {
   int64_t dys, dros, xss, dxs, dris, xs, zs, dzs;
   int64_t rows; int cols; int ngroups; int wdt; int rms; float eps; int norm_before_gate;
 };
+
+// VEC weights of a lane as fp32: 16-byte requests when the row is fp32 / 16-bit and aligned (WVEC, checked by the launcher) -- a one-shot
+// workgroup pays this prologue per row, the per-element run-time-dtype loads (sixteen scalar-branch round trips) cost it its gain
+template <int VEC, bool WVEC>
+__device__ __forceinline__ void load_w_row(const void* w, int i0, int wdt, float (&o)[VEC]) {
+  if constexpr (WVEC) {
+    static_assert(VEC == 8, "two 16-byte fp32 groups or one 16-bit group");
+    if (wdt == OMK_F32) {
+      const f32x4 v0 = reinterpret_cast<const f32x4*>((const float*)w + i0)[0], v1 = reinterpret_cast<const f32x4*>((const float*)w + i0)[1];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o[i] = v0[i]; o[4 + i] = v1[i]; }
+    } else if (wdt == OMK_BF16) load_vec<bf16_t, VEC>((const bf16_t*)w + i0, o);
+    else load_vec<f16_t, VEC>((const f16_t*)w + i0, o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) o[i] = load_rt(w, i0 + i, wdt);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // forward: y = norm(x + residual) * w + b ; residual_out = x + residual
@@ -86,14 +105,29 @@ __global__ __launch_bounds__(NORM_THREADS) void add_norm_fwd_kernel(NormArgs a) 
   TRO* ro = (TRO*)a.ro;
   const float inv_n = 1.f / (float)a.cols;
   float wreg[NCHUNK][VEC], breg[NCHUNK][VEC];   // this lane's columns never change: weights live in registers
+  if constexpr (VEC == 8) {
+    if (a.wvec) {   // (uniform) the short prologue of a short-lived workgroup: 16-byte requests
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c++)
+      for (int c = 0; c < NCHUNK; c++) {
+        load_w_row<VEC, true>(a.w, NORM_COL(c), a.wdt, wreg[c]);
+        if (a.b) load_w_row<VEC, true>(a.b, NORM_COL(c), a.bdt, breg[c]);
+        else {
 #pragma unroll
-    for (int i = 0; i < VEC; i++) {
-      const int col = NORM_COL(c) + i;
-      wreg[c][i] = col < a.cols ? load_rt(a.w, col, a.wdt) : 0.f;
-      breg[c][i] = (a.b && col < a.cols) ? load_rt(a.b, col, a.bdt) : 0.f;
+          for (int i = 0; i < VEC; i++) breg[c][i] = 0.f;
+        }
+      }
     }
+  }
+  if (VEC != 8 || !a.wvec) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        const int col = NORM_COL(c) + i;
+        wreg[c][i] = col < a.cols ? load_rt(a.w, col, a.wdt) : 0.f;
+        breg[c][i] = (a.b && col < a.cols) ? load_rt(a.b, col, a.bdt) : 0.f;
+      }
+  }
   const int64_t niter = (a.rows + RPB - 1) / RPB;
   for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
     const int64_t rraw = it * RPB + wrow;
@@ -334,24 +368,6 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_fwd_kernel(NormArgs a
         st<TX, VEC>(y + row * a.ys + g0 + col, o);
       }
     }
-  }
-}
-
-// VEC weights of a lane as fp32: 16-byte requests when the row is fp32 / 16-bit and aligned (WVEC, checked by the launcher) -- a one-shot
-// workgroup pays this prologue per row, the per-element run-time-dtype loads (sixteen scalar-branch round trips) cost it its gain
-template <int VEC, bool WVEC>
-__device__ __forceinline__ void load_w_row(const void* w, int i0, int wdt, float (&o)[VEC]) {
-  if constexpr (WVEC) {
-    static_assert(VEC == 8, "two 16-byte fp32 groups or one 16-bit group");
-    if (wdt == OMK_F32) {
-      const f32x4 v0 = reinterpret_cast<const f32x4*>((const float*)w + i0)[0], v1 = reinterpret_cast<const f32x4*>((const float*)w + i0)[1];
-#pragma unroll
-      for (int i = 0; i < 4; i++) { o[i] = v0[i]; o[4 + i] = v1[i]; }
-    } else if (wdt == OMK_BF16) load_vec<bf16_t, VEC>((const bf16_t*)w + i0, o);
-    else load_vec<f16_t, VEC>((const f16_t*)w + i0, o);
-  } else {
-#pragma unroll
-    for (int i = 0; i < VEC; i++) o[i] = load_rt(w, i0 + i, wdt);
   }
 }
 
@@ -698,7 +714,19 @@ extern "C" int omk_add_norm_fwd(const OmkAddNormFwd* p, omk_stream stream) {
   a.xs = p->x.stride[0]; a.rs = present(p->residual) ? p->residual.stride[0] : 0; a.ys = p->y.stride[0];
   a.ros = present(p->residual_out) ? p->residual_out.stride[0] : 0;
   a.rows = rows; a.cols = (int)cols; a.ngroups = 1; a.wdt = p->weight.dtype; a.bdt = p->bias.dtype; a.eps = p->eps; a.rms = p->is_rms_norm;
-  dim3 grid(norm_blocks(rows, 1, plan)), block(NORM_THREADS);
+  // short-lived workgroups (see omk_norm_gated_fwd): two block rows each, behind a prologue of 16-byte requests -- when every lane's columns exist and
+  // the weight / bias rows are aligned; otherwise the persistent grid of rounds 1 - 5
+  a.wvec = plan.vec == 8 && cols == (int64_t)plan.wpr * plan.nchunk * 64 * 8 && ((uintptr_t)p->weight.data & 15) == 0 &&
+           (!present(p->bias) || ((uintptr_t)p->bias.data & 15) == 0) && !getenv("OMK_NORM_PERSISTENT");
+  int nblk = norm_blocks(rows, 1, plan);
+  if (a.wvec) {
+    const int rpb = NORM_WAVES / plan.wpr;
+    int64_t per = (rows + rpb - 1) / rpb;
+    if (per > 2048) per = (per + 1) / 2;
+    if (const char* e = getenv("OMK_NORM_BLOCKS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20) && v < per) per = v; }   // developer A/B
+    nblk = (int)per;
+  }
+  dim3 grid(nblk), block(NORM_THREADS);
 #define LAUNCH_ADD(TX, TR, TRO) OMK_PLAN_SWITCH(plan, OMK_LAUNCH((add_norm_fwd_kernel<TX, TR, TRO, VEC, NCHUNK, WPR>), grid, block, 0, stream, a))
   OMK_DISPATCH_DTYPE(xdt, TX, {
     if (rdt == xdt && rodt == xdt) { LAUNCH_ADD(TX, TX, TX); }
