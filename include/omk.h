@@ -136,7 +136,13 @@ typedef struct {
   OmkTensor dbias;                           /* optional out (C) f32, accumulated */
   OmkTensor dinitial_states;                 /* optional out (B, C, W-1) */
   int32_t silu;
+  /* ABI 7, optional: with a workspace of omk_causal_conv1d_bwd_workspace_bytes() the long channel-last 16-bit kernel leaves one partial
+   * dweight / dbias row per (batch, 256-token tile) and a second launch adds them up in a fixed order -- the same gradients on every run
+   * and ~ 12 us less at the 1.3B slice than the fp32 atomics taken without one (NULL / too small: atomics; other layouts: unused) */
+  void* workspace;
+  size_t workspace_bytes;
 } OmkConv1dBwd;
+size_t omk_causal_conv1d_bwd_workspace_bytes(const OmkConv1dBwd* p);
 int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream);
 
 typedef struct {

@@ -58,7 +58,7 @@ NormGatedBwd = _S("OmkNormGatedBwd", [(n, _t) for n in ("dy", "x", "z", "weight"
 Conv1dFwd = _S("OmkConv1dFwd", [(n, _t) for n in ("x", "weight", "bias", "initial_states", "out", "final_states")]
                + [("silu", _i)])
 Conv1dBwd = _S("OmkConv1dBwd", [(n, _t) for n in ("x", "weight", "bias", "initial_states", "dout", "dx", "dweight",
-                                                  "dbias", "dinitial_states")] + [("silu", _i)])
+                                                  "dbias", "dinitial_states")] + [("silu", _i), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)])
 Conv1dUpdate = _S("OmkConv1dUpdate", [(n, _t) for n in ("x", "conv_state", "weight", "bias", "out")] + [("silu", _i)])
 StateUpdate = _S("OmkStateUpdate", [(n, _t) for n in ("state", "x", "dt", "A", "Bm", "Cm", "D", "z", "dt_bias", "out")]
                  + [("dt_softplus", _i)])
@@ -98,7 +98,7 @@ SYMBOLS = [
     "omk_abi_version", "omk_last_error", "omk_is_emulated", "omk_sizeof", "omk_ssd_last_kernels",
     "omk_add_norm_fwd", "omk_add_norm_bwd_workspace_bytes", "omk_add_norm_bwd",
     "omk_norm_gated_fwd", "omk_norm_gated_bwd_workspace_bytes", "omk_norm_gated_bwd",
-    "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
+    "omk_causal_conv1d_fwd", "omk_causal_conv1d_bwd_workspace_bytes", "omk_causal_conv1d_bwd", "omk_causal_conv1d_update",
     "omk_selective_state_update", "omk_norm_linear", "omk_lora_add", "omk_lora_up_bwd",
     "omk_selective_scan_fwd", "omk_selective_scan_fwd_form", "omk_selective_scan_bwd_form", "omk_selective_scan_bwd_workspace_bytes", "omk_selective_scan_bwd",
     "omk_ssd_scan_fwd_workspace_bytes", "omk_ssd_scan_fwd_window_states_bytes", "omk_ssd_scan_fwd", "omk_ssd_scan_bwd_workspace_bytes", "omk_ssd_scan_bwd",

@@ -70,6 +70,7 @@ class CausalConv1dFn(torch.autograd.Function):
         if x.numel() > 0:
             p = K.Conv1dBwd(x=K.T(x), weight=K.T(weight), bias=K.T(bias), initial_states=K.T(initial_states), dout=K.T(dout),
                             dx=K.T(dx), dweight=K.T(dw), dbias=K.T(db), dinitial_states=K.T(dinit), silu=ctx.silu)
+            ws = K.workspace(lib, "omk_causal_conv1d_bwd_workspace_bytes", p, x)   # partial dw / db rows: no atomics, the same sums on every run
             K.run(lib, "omk_causal_conv1d_bwd", p, x)
         return dx, dw.to(weight.dtype), None if bias is None else db.to(bias.dtype), dinit, None, None, None
 

@@ -17,6 +17,7 @@ constexpr int CONV_MAXW = 4;
 struct ConvArgs {
   const void* x; const void* w; const void* bias; const void* init; const void* dout;
   void* out; void* fin; void* dx; float* dw; float* db; void* dinit;
+  float* part;   // backward, optional: [B * tiles][C * (W + 1)] partial dw / db rows instead of atomics (conv1d_bwd_cl4_kernel)
   int FW;   // columns of final_states (>= W - 1)
   int64_t xsb, xsc, xsl, osb, osc, osl, isb, isc, isl, fsb, fsc, fsl, dosb, dosc, dosl, dxsb, dxsc, dxsl, disb, disc, disl;
   int64_t wsc, wsk;
@@ -662,6 +663,20 @@ __global__ __launch_bounds__(64 * NS) void conv1d_bwd_cl4_kernel(ConvArgs a) {  
     for (int k = 0; k < W; k++) sred[strip][cvl][i * (W + 1) + k] = dwacc[k][i];
   }
   block_sync();
+  if (a.part) {
+    // one partial row per (batch, tile of NS strips): the lane's VEC (W + 1) sums are consecutive floats, spread over the NS waves; a second launch
+    // (conv1d_bwd_fold_kernel) adds the rows in a fixed order -- no atomics, the same gradients on every run
+    if (cvok) {
+      float* prow = a.part + ((int64_t)b * NT4 + t4) * ((int64_t)a.C * (W + 1)) + (int64_t)c0 * (W + 1);
+      for (int j = strip; j < VEC * (W + 1); j += NS) {
+        float v = sred[0][cvl][j];
+#pragma unroll
+        for (int q = 1; q < NS; q++) v += sred[q][cvl][j];
+        prow[j] = v;
+      }
+    }
+    return;
+  }
   if (strip == 0 && cvok) {
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
@@ -675,6 +690,34 @@ __global__ __launch_bounds__(64 * NS) void conv1d_bwd_cl4_kernel(ConvArgs a) {  
         else if (a.db) atomic_add_f32(a.db + c0 + i, v);
       }
     }
+  }
+}
+
+// dw[c][k] += sum_p part[p][c (W + 1) + k], db[c] += sum_p part[p][c (W + 1) + W]: 64 columns x 16 row groups per workgroup, four requests in flight per
+// lane, rows added in a fixed order (group sums in index order)
+__global__ __launch_bounds__(1024) void conv1d_bwd_fold_kernel(const float* part, int P, int C, int W, float* dw, float* db) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t ncol = (int64_t)C * (W + 1), col = (int64_t)blockIdx.x * 64 + cl;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < ncol) {
+    for (int p0 = g; p0 < P; p0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int p = p0 + 16 * u; v[u] = p < P ? part[(int64_t)p * ncol + col] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) s[u] += v[u];
+    }
+  }
+  sh[g][cl] = (s[0] + s[1]) + (s[2] + s[3]);
+  block_sync();
+  if (g == 0 && col < ncol) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) v += sh[q][cl];
+    const int c = (int)(col / (W + 1)), k = (int)(col % (W + 1));
+    if (k < W) dw[(int64_t)c * W + k] += v;
+    else if (db) db[c] += v;
   }
 }
 
@@ -871,6 +914,17 @@ extern "C" int omk_causal_conv1d_fwd(const OmkConv1dFwd* p, omk_stream stream) {
   return finish_launch("causal_conv1d_fwd");
 }
 
+// partial dw / db rows of conv1d_bwd_cl4_kernel: one per (batch, tile of 4 x 64 tokens), C (W + 1) floats each
+static size_t conv_bwd_part_bytes(int B, int C, int L, int W) { return (size_t)B * ((L + 255) / 256) * (size_t)C * (W + 1) * 4; }
+
+extern "C" size_t omk_causal_conv1d_bwd_workspace_bytes(const OmkConv1dBwd* p) {
+  if (!p || !present(p->x) || !present(p->weight) || !present(p->dout) || !present(p->dx) || p->x.ndim != 3 || p->weight.ndim != 2) return 0;
+  if (p->x.dtype == OMK_F32) return 0;   // (the 16-bit channel-last kernels only; every other layout keeps its atomics and needs nothing)
+  const int C = (int)p->x.shape[1];
+  if (!(cl_fast_ok(p->x, C) && cl_fast_ok(p->dout, C) && cl_fast_ok(p->dx, C))) return 0;
+  return conv_bwd_part_bytes((int)p->x.shape[0], C, (int)p->x.shape[2], (int)p->weight.shape[1]);
+}
+
 extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
   OMK_REQUIRE(p && present(p->x) && present(p->weight) && present(p->dout) && present(p->dx) && present(p->dweight), "causal_conv1d_bwd: x, weight, dout, dx, dweight required");
   ConvArgs a = {};
@@ -928,10 +982,16 @@ extern "C" int omk_causal_conv1d_bwd(const OmkConv1dBwd* p, omk_stream stream) {
                         (!present(p->bias) || (p->bias.dtype == OMK_F32 && ((uintptr_t)p->bias.data & 7) == 0));
         const int CVB = (a.C / 2 + 63) / 64, NTS = (a.L + 4 * TL - 1) / (4 * TL);
         dim3 grid((unsigned)((int64_t)a.B * NTS * CVB)), blk(256);
+        const size_t pbytes = conv_bwd_part_bytes(a.B, a.C, a.L, a.W);
+        a.part = (p->workspace && p->workspace_bytes >= pbytes && !getenv("OMK_CONV_BWD_ATOMICS")) ? (float*)p->workspace : nullptr;
 #define CONV_BWD_4G(T_, W_) do { if (wf) OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, W_, TGX, 4, true>), grid, blk, 0, stream, a); \
           else OMK_LAUNCH((conv1d_bwd_cl4_kernel<T_, TL, W_, TGX, 4, false>), grid, blk, 0, stream, a); } while (0)
 #define CONV_BWD_4(T_) do { if (a.W == 4) CONV_BWD_4G(T_, 4); else if (a.W == 3) CONV_BWD_4G(T_, 3); else CONV_BWD_4G(T_, 2); } while (0)
         if (p->x.dtype == OMK_BF16) CONV_BWD_4(bf16_t); else CONV_BWD_4(f16_t);
+        if (a.part) {
+          const int64_t ncol = (int64_t)a.C * (a.W + 1);
+          OMK_LAUNCH(conv1d_bwd_fold_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(1024), 0, stream, a.part, a.B * NTS, a.C, a.W, a.dw, a.db);
+        }
 #undef CONV_BWD_4G
 #undef CONV_BWD_4
       } else if (p->x.dtype == OMK_BF16) CONV_BWD_V(bf16_t, 2, 8); else CONV_BWD_V(f16_t, 2, 8);

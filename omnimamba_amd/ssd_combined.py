@@ -508,6 +508,7 @@ class MambaSplitConv1dScanCombinedFn(torch.autograd.Function):
         p = K.Conv1dBwd(x=K.T(xBC.transpose(1, 2)), weight=K.T(conv_w), bias=K.T(conv_b), initial_states=K.T(None),
                         dout=K.T(dxBC_c.transpose(1, 2)), dx=K.T(dxBC.transpose(1, 2)), dweight=K.T(dw), dbias=K.T(db),
                         dinitial_states=K.T(None), silu=1)
+        cws = K.workspace(lib, "omk_causal_conv1d_bwd_workspace_bytes", p, zxbcdt)   # partial dw / db rows instead of atomics
         K.run(lib, "omk_causal_conv1d_bwd", p, zxbcdt)
         dinit = g["dinitial_states"]
         return (dzxbcdt, dw.to(conv_w.dtype), None if conv_b is None else db.to(conv_b.dtype),

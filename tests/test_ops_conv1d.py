@@ -81,6 +81,29 @@ def test_conv1d_long_strips_both_prologues_agree(dev, W):
     assert rel(ref[0], o0) < 6e-3
 
 
+def test_conv1d_bwd_partial_rows_are_deterministic_and_equal_the_atomics(dev, monkeypatch):
+    """Long channel-last 16-bit rows: with the workspace of omk_causal_conv1d_bwd_workspace_bytes (what the autograd nodes pass) dweight / dbias come
+    from per-tile partial rows added up in a fixed order -- the same bits on every run; OMK_CONV_BWD_ATOMICS=1 takes the fp32 atomics of rounds 1 - 5."""
+    from omnimamba_amd.causal_conv1d import causal_conv1d_fn
+    torch.manual_seed(3)
+    B, C, L, W = 3, 24, 700, 4
+    base = torch.randn(B, L, C + 8).bfloat16().to(dev)
+    w, b = torch.randn(C, W).to(dev), torch.randn(C).to(dev)
+    g = torch.randn(B, C, L).bfloat16().to(dev).transpose(1, 2).contiguous().transpose(1, 2)   # channel-last, like x
+
+    def grads():
+        x = base[:, :, 8:].transpose(1, 2).detach().requires_grad_()
+        wr, br = w.detach().requires_grad_(), b.detach().requires_grad_()
+        causal_conv1d_fn(x, wr, br, activation="silu").backward(g)
+        return x.grad.float().cpu(), wr.grad.cpu(), br.grad.cpu()
+
+    a1, a2 = grads(), grads()
+    assert all(torch.equal(u, v) for u, v in zip(a1, a2))
+    monkeypatch.setenv("OMK_CONV_BWD_ATOMICS", "1")
+    a3 = grads()
+    assert torch.equal(a1[0], a3[0]) and rel(a1[1], a3[1].double()) < 1e-5 and rel(a1[2], a3[2].double()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv1d_update(dev, dtype):
     from omnimamba_amd.causal_conv1d import causal_conv1d_update
