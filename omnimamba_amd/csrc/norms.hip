@@ -670,6 +670,75 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_gated_bwd_lean_kernel(NormB
   }
 }
 
+// The same backward for rows of exactly 8 x 64 x 8 = 4096 columns (the 1.3B d_inner) with EIGHT waves per row: one 16-byte vector per lane and
+// stream -- half the registers, twice the waves per SIMD.  tools/probe/stream3_probe.hip: 288 -> 258 us for the same bytes and arithmetic; nothing
+// else moved this kernel (prefetch, launch shape, barrier, instruction count: profiles/r06_stream_kernels.txt).  512 workgroups: 512 partial rows.
+constexpr int NORM_W8_COLS = 8 * 64 * 8, NORM_W8_BLOCKS = 512;
+__global__ __launch_bounds__(512) void norm_gated_bwd_w8_kernel(NormBwdArgs a) {
+  __shared__ float red[2][8][2];
+  __shared__ __attribute__((aligned(16))) float wsh[NORM_W8_COLS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bf16_t* x = (const bf16_t*)a.x;
+  const bf16_t* z = (const bf16_t*)a.z;
+  const bf16_t* dy = (const bf16_t*)a.dy;
+  bf16_t* dx = (bf16_t*)a.dx;
+  bf16_t* dz = (bf16_t*)a.dz;
+  const int col = (wave * 64 + lane) * 8;
+#pragma unroll
+  for (int i = 0; i < 8; i++) wsh[col + i] = load_rt(a.w, col + i, a.wdt);
+  block_sync();
+  constexpr float inv_n = 1.f / (float)NORM_W8_COLS;
+  f32x2 dwacc[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) dwacc[e] = f32x2{0.f, 0.f};
+  auto unpk = [](uint32_t w) -> f32x2 { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; };
+  int par = 0;
+  for (int64_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    u32x4 rx = *reinterpret_cast<const u32x4*>(x + row * a.xs + col);
+    u32x4 rd = *reinterpret_cast<const u32x4*>(dy + row * a.dys + col);
+    u32x4 rz = *reinterpret_cast<const u32x4*>(z + row * a.zs + col);
+    f32x2 gv[4], wdy[4], sig[4];
+    f32x2 s2v = {0.f, 0.f}, t2v = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const f32x2 zf = unpk(rz[e]);
+      const f32x2 t = zf * (-LOG2E);
+      const f32x2 q = f32x2{exp2_fast(t[0]), exp2_fast(t[1])} + 1.f;
+      sig[e] = f32x2{rcp_fast(q[0]), rcp_fast(q[1])};
+      const f32x2 wv = *reinterpret_cast<const f32x2*>(&wsh[col + 2 * e]);
+      gv[e] = unpk(rx[e]) * (zf * sig[e]);           // x silu(z): what the norm sees
+      wdy[e] = unpk(rd[e]) * wv;
+      s2v = fma_f32x2(gv[e], gv[e], s2v);
+      t2v = fma_f32x2(gv[e], wdy[e], t2v);
+    }
+    float s2 = wave_sum(s2v[0] + s2v[1]), t2 = wave_sum(t2v[0] + t2v[1]);
+    if (lane == 0) { red[par][wave][0] = s2; red[par][wave][1] = t2; }
+    block_sync();                                      // (the exchange array is double buffered by parity: one barrier per row)
+    s2 = 0.f; t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { s2 += red[par][q][0]; t2 += red[par][q][1]; }
+    par ^= 1;
+    const float rstd = rsqrtf(s2 * inv_n + a.eps);
+    const float c1 = rstd * t2 * inv_n;
+    u32x4 ox, oz;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const f32x2 xhat = gv[e] * rstd, zf = unpk(rz[e]), sg = sig[e];
+      dwacc[e] = fma_f32x2(unpk(rd[e]), xhat, dwacc[e]);
+      const f32x2 ds = (wdy[e] - xhat * c1) * rstd * sg;
+      const f32x2 vx = ds * zf, vz = ds * unpk(rx[e]) * (1.f + zf * (1.f - sg));
+      ox[e] = pack_bf16x2(vx[0], vx[1]);
+      oz[e] = pack_bf16x2(vz[0], vz[1]);
+    }
+    *reinterpret_cast<u32x4*>(dx + row * a.dxs + col) = ox;
+    *reinterpret_cast<u32x4*>(dz + row * a.dzs + col) = oz;
+  }
+  if (a.dw_part) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) *reinterpret_cast<f32x2*>(&a.dw_part[(int64_t)blockIdx.x * a.cols + col + 2 * e]) = dwacc[e];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -871,7 +940,9 @@ extern "C" size_t omk_norm_gated_bwd_workspace_bytes(const OmkNormGatedBwd* p) {
   if (!p) return 0;
   VecPlan plan; int ng;
   if (!gated_bwd_plan(p, &plan, &ng)) return 0;
-  return (size_t)norm_parts(p->x.shape[0], ng, plan) * p->x.shape[1] * 4;
+  const size_t general = (size_t)norm_parts(p->x.shape[0], ng, plan) * p->x.shape[1] * 4;
+  const size_t w8 = (size_t)NORM_W8_BLOCKS * p->x.shape[1] * 4;     // (norm_gated_bwd_w8_kernel: never more than the general form needs for >= 512 rows)
+  return general > w8 ? general : w8;
 }
 
 extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
@@ -895,6 +966,13 @@ extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
   const int64_t gsz = cols / ng;
   const bool lean = present(p->z) && present(p->dz) && !p->norm_before_gate && plan.vec == 8 && gsz == (int64_t)plan.wpr * plan.nchunk * 64 * 8 &&
                     p->x.dtype == OMK_BF16 && !getenv("OMK_NORM_NO_LEAN");
+  const bool w8 = lean && ng == 1 && cols == NORM_W8_COLS && !getenv("OMK_NORM_BWD_W8_OFF");
+  if (w8) {
+    int nb = rows < NORM_W8_BLOCKS ? (int)rows : NORM_W8_BLOCKS;
+    OMK_LAUNCH(norm_gated_bwd_w8_kernel, dim3((unsigned)nb), dim3(512), 0, stream, a);
+    if (a.dw_part) launch_reduce(a.dw_part, nb, cols, (float*)p->dweight.data, stream);
+    return finish_launch("norm_gated_bwd");
+  }
   if (lean) {
     // (measured and not kept, profiles/r06_stream_kernels.txt: the next row's requests in a second staging set -- 150 registers, three waves per
     // SIMD: 300 us against 290; the five streams with trivial arithmetic take 244 us on the same box, one-shot or persistent alike)

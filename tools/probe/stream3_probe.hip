@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void pair_row_kernel(A a) {
 //   contiguous range (one shot, grid = rows / (NG K)); the NG groups' partial sums are added in LDS before the store (NG > 1)
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct AB { const uint16_t* x; const uint16_t* z; const uint16_t* dy; uint16_t* dx; uint16_t* dz; const float* w; float* part; int64_t rows; };
-template <int NG, bool STRIDED>
+template <int NG, bool STRIDED, bool NOSYNC = false>   // NOSYNC: the row sums stay inside the wave (wrong result, same work: what the barrier costs)
 __global__ __launch_bounds__(256 * NG) void bwd_kernel(AB a, int K) {
   __shared__ float red[2][NG][4][2];
   __shared__ __attribute__((aligned(16))) float wsh[COLS];
@@ -305,11 +305,13 @@ __global__ __launch_bounds__(256 * NG) void bwd_kernel(AB a, int K) {
         s2 += gv[c][i] * gv[c][i]; t2 += gv[c][i] * wdy[c][i];
       }
     s2 = wave_sum(s2); t2 = wave_sum(t2);
-    if (lane == 0) { red[par][grp][wave][0] = s2; red[par][grp][wave][1] = t2; }
-    __syncthreads();
-    s2 = red[par][grp][0][0] + red[par][grp][1][0] + red[par][grp][2][0] + red[par][grp][3][0];
-    t2 = red[par][grp][0][1] + red[par][grp][1][1] + red[par][grp][2][1] + red[par][grp][3][1];
-    par ^= 1;
+    if (!NOSYNC) {
+      if (lane == 0) { red[par][grp][wave][0] = s2; red[par][grp][wave][1] = t2; }
+      __syncthreads();
+      s2 = red[par][grp][0][0] + red[par][grp][1][0] + red[par][grp][2][0] + red[par][grp][3][0];
+      t2 = red[par][grp][0][1] + red[par][grp][1][1] + red[par][grp][2][1] + red[par][grp][3][1];
+      par ^= 1;
+    }
     const float rstd = rsqrtf(s2 * (1.f / COLS) + 1e-5f), c1 = rstd * t2 * (1.f / COLS);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -348,6 +350,67 @@ __global__ __launch_bounds__(256 * NG) void bwd_kernel(AB a, int K) {
 #pragma unroll
       for (int i = 0; i < 8; i++) a.part[g * COLS + col[c] + i] = dw[c][i];
   }
+}
+// the same backward with EIGHT waves per row (one 16-byte vector per lane and stream: half the registers, twice the waves per SIMD), persistent, strided rows
+__global__ __launch_bounds__(512) void bwd8_kernel(AB a, int K) {
+  __shared__ float red[2][8][2];
+  __shared__ __attribute__((aligned(16))) float wsh[COLS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < COLS; i += 512) wsh[i] = a.w[i];
+  __syncthreads();
+  const int col = (wave * 64 + lane) * 8;
+  float dw[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) dw[i] = 0.f;
+  int par = 0;
+  for (int k = 0; k < K; k++) {
+    const int64_t row = blockIdx.x + (int64_t)k * gridDim.x;
+    const u32x4 rx = *reinterpret_cast<const u32x4*>(a.x + row * COLS + col);
+    const u32x4 rd = *reinterpret_cast<const u32x4*>(a.dy + row * COLS + col);
+    const u32x4 rz = *reinterpret_cast<const u32x4*>(a.z + row * ZROW + col);
+    float gv[8], wdy[8], sg[8];
+    float s2 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float zf = (i & 1) ? hi(rz[i >> 1]) : lo(rz[i >> 1]);
+      const float xf = (i & 1) ? hi(rx[i >> 1]) : lo(rx[i >> 1]);
+      const float df = (i & 1) ? hi(rd[i >> 1]) : lo(rd[i >> 1]);
+      sg[i] = __builtin_amdgcn_rcpf(1.f + __expf(-zf));
+      gv[i] = xf * (zf * sg[i]);
+      wdy[i] = df * wsh[col + i];
+      s2 += gv[i] * gv[i]; t2 += gv[i] * wdy[i];
+    }
+    s2 = wave_sum(s2); t2 = wave_sum(t2);
+    if (lane == 0) { red[par][wave][0] = s2; red[par][wave][1] = t2; }
+    __syncthreads();
+    s2 = 0.f; t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { s2 += red[par][q][0]; t2 += red[par][q][1]; }
+    par ^= 1;
+    const float rstd = rsqrtf(s2 * (1.f / COLS) + 1e-5f), c1 = rstd * t2 * (1.f / COLS);
+    u32x4 ox, oz;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float o[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int i = 2 * e + h;
+        const float zf = h ? hi(rz[e]) : lo(rz[e]);
+        const float xf = h ? hi(rx[e]) : lo(rx[e]);
+        const float df = h ? hi(rd[e]) : lo(rd[e]);
+        const float xhat = gv[i] * rstd;
+        dw[i] += df * xhat;
+        const float ds = (wdy[i] - xhat * c1) * rstd * sg[i];
+        o[0][h] = ds * zf;
+        o[1][h] = ds * xf * (1.f + zf * (1.f - sg[i]));
+      }
+      ox[e] = pack(o[0][0], o[0][1]); oz[e] = pack(o[1][0], o[1][1]);
+    }
+    *reinterpret_cast<u32x4*>(a.dx + row * COLS + col) = ox;
+    *reinterpret_cast<u32x4*>(a.dz + row * ZROW + col) = oz;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.part[(int64_t)blockIdx.x * COLS + col + i] = dw[i];
 }
 // the five streams with trivial arithmetic, one shot (the ceiling of the access pattern): UNR vectors per lane and stream
 template <int UNR>
@@ -503,6 +566,14 @@ int main(int argc, char** argv) {
     for (int G : {1024, 2048}) {
       snprintf(nm, sizeof nm, "persistent x %d, strided rows (= norms.hip)", G);
       rep(nm, time_us([&] { bwd_kernel<1, true><<<dim3(G), 256>>>(b, (int)(rows / G)); }), G);
+    }
+    for (int G : {1024, 2048}) {
+      snprintf(nm, sizeof nm, "persistent x %d, strided rows, NO workgroup barrier (row sums inside the wave)", G);
+      rep(nm, time_us([&] { bwd_kernel<1, true, true><<<dim3(G), 256>>>(b, (int)(rows / G)); }), G);
+    }
+    for (int G : {512, 1024, 2048}) {
+      snprintf(nm, sizeof nm, "persistent x %d, EIGHT waves per row (one vector per lane and stream)", G);
+      rep(nm, time_us([&] { bwd8_kernel<<<dim3(G), 512>>>(b, (int)(rows / G)); }), G);
     }
     for (int K : {4, 8, 16, 32}) {
       snprintf(nm, sizeof nm, "one shot, %d consecutive rows per workgroup (grid %d)", K, (int)(rows / K));
