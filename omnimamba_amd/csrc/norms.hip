@@ -746,7 +746,10 @@ struct VecPlan { int vec, nchunk, wpr; };
 // VEC=8 needs 16-byte aligned rows; a segment must fit WPR * NCHUNK * 64 * VEC
 static bool plan_vec(int64_t seglen, bool can8, VecPlan* out) {
   if (can8 && seglen % 8 == 0) {
-    if (seglen <= 1 * 4 * 64 * 8) { *out = {8, 4, 1}; return true; }     // <= 2048
+    if (seglen <= 1 * 2 * 64 * 8) { *out = {8, 4, 1}; return true; }     // <= 1024: a wave per row
+    // 1025 .. 2048 (the 1.3B d_model): four waves per row, ONE 16-byte vector per lane and stream -- the wave-per-row form holds 32 elements of
+    // every stream per lane (add_norm_bwd: 214 registers, two waves per SIMD); see norm_gated_bwd_w8_kernel for what registers cost these kernels
+    if (seglen <= 4 * 1 * 64 * 8) { *out = {8, 1, 4}; return true; }
     if (seglen <= 4 * 2 * 64 * 8) { *out = {8, 2, 4}; return true; }     // <= 4096 (the 1.3B gated norm): half the registers
     if (seglen <= 4 * 4 * 64 * 8) { *out = {8, 4, 4}; return true; }     // <= 8192
   }
@@ -770,6 +773,7 @@ static bool rows_ok8(const OmkTensor& t) { return !present(t) || (aligned16(t) &
 
 #define OMK_PLAN_SWITCH(plan, ...)                                                                                   \
   if (plan.vec == 8 && plan.wpr == 1) { constexpr int VEC = 8, NCHUNK = 4, WPR = 1; __VA_ARGS__; }                   \
+  else if (plan.vec == 8 && plan.nchunk == 1) { constexpr int VEC = 8, NCHUNK = 1, WPR = 4; __VA_ARGS__; }           \
   else if (plan.vec == 8 && plan.nchunk == 2) { constexpr int VEC = 8, NCHUNK = 2, WPR = 4; __VA_ARGS__; }           \
   else if (plan.vec == 8) { constexpr int VEC = 8, NCHUNK = 4, WPR = 4; __VA_ARGS__; }                               \
   else { constexpr int VEC = 1, NCHUNK = 32, WPR = 4; __VA_ARGS__; }
@@ -918,6 +922,7 @@ extern "C" int omk_norm_gated_fwd(const OmkNormGatedFwd* p, omk_stream stream) {
 #define OMK_LEAN_FWD(NC_, WPR_) do { if (wvec) OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, NC_, WPR_, true>), lgrid, block, 0, stream, a); \
       else OMK_LAUNCH((norm_gated_fwd_lean_kernel<bf16_t, 8, NC_, WPR_, false>), lgrid, block, 0, stream, a); } while (0)
     if (plan.wpr == 1) OMK_LEAN_FWD(4, 1);
+    else if (plan.nchunk == 1) OMK_LEAN_FWD(1, 4);
     else if (plan.nchunk == 2) OMK_LEAN_FWD(2, 4);
     else OMK_LEAN_FWD(4, 4);
 #undef OMK_LEAN_FWD
@@ -977,6 +982,7 @@ extern "C" int omk_norm_gated_bwd(const OmkNormGatedBwd* p, omk_stream stream) {
     // (measured and not kept, profiles/r06_stream_kernels.txt: the next row's requests in a second staging set -- 150 registers, three waves per
     // SIMD: 300 us against 290; the five streams with trivial arithmetic take 244 us on the same box, one-shot or persistent alike)
     if (plan.wpr == 1) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 1>), grid, block, 0, stream, a);
+    else if (plan.nchunk == 1) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 1, 4>), grid, block, 0, stream, a);
     else if (plan.nchunk == 2) OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 2, 4>), grid, block, 0, stream, a);
     else OMK_LAUNCH((norm_gated_bwd_lean_kernel<bf16_t, 8, 4, 4>), grid, block, 0, stream, a);
   } else
