@@ -87,9 +87,44 @@ __device__ __forceinline__ T block_incl_scan(T v, T* buf, int tid) {
   return r;
 }
 
+// inclusive scan over the lanes of a wave (any additive type the shuffles move)
+template <class T> __device__ __forceinline__ T wave_incl_scan_t(T v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const T o = shfl(v, lane >= off ? lane - off : lane); if (lane >= off) v += o; }
+  return v;
+}
+// The digit walk of a radix pass by ONE WAVE instead of one thread (a thread reading 60 - 190 counters one after the other was 2 - 8 us per pass):
+// cnt(r) for r = 0 .. 255 in WALK order, lane l holds r = 4 l .. 4 l + 3; returns in every lane the first r whose running total reaches `need`
+// by the rule `total before + cnt(r) > limit` (limit = need - 1 for "covers need keys"), and the total BEFORE it; r = 255 when none does.
+template <class T, class F> __device__ __forceinline__ void wave_find_digit(F cnt, T limit, int lane, uint32_t& r_out, T& before_out) {
+  T c[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { c[j] = cnt(4 * lane + j); s += c[j]; }
+  const T incl = wave_incl_scan_t<T>(s, lane);
+  T run = incl - s;
+  int jj = -1; T bef = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { if (jj < 0 && run + c[j] > limit) { jj = j; bef = run; } run += c[j]; }
+#ifdef OMK_EMU
+  const unsigned long long m = emu::ballot(jj >= 0 ? 1 : 0);
+#else
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(jj >= 0);
+#endif
+  if (m) {
+    const int l0 = __builtin_ctzll(m);
+    r_out = (uint32_t)(4 * l0 + shfl(jj, l0));
+    before_out = shfl(bef, l0);
+  } else {   // (the walk ends on the last digit: everything in front of it is "before")
+    r_out = 255u;
+    before_out = shfl(incl, 63) - shfl(c[3], 63);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
-  __shared__ uint32_t hist[256];
+  // eight copies of every counter, picked by the lane: the keys of a row share their top byte(s), and 64 lanes adding to ONE LDS address are 64
+  // serial atomics (copy c of digit d lives at 8 d + c: the copies of a digit sit in different banks)
+  __shared__ uint32_t hist[256 * 8];
   __shared__ uint32_t sel_prefix, sel_need, n_gt, n_eq;
   __shared__ float cval[SAMPLE_KMAX];
   __shared__ int cidx[SAMPLE_KMAX];
@@ -138,8 +173,8 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
   }
   if (a.top_k == 0 && (a.min_p > 0.f || (a.top_p > 0.f && a.top_p < 1.f))) {
     // ---- the whole vocabulary behind one of the reference's two filters (see the header)
-    __shared__ unsigned long long hm[256], sc64[2 * SNT];
-    __shared__ uint32_t hc[256], sc32[2 * SNT];
+    __shared__ unsigned long long hm[256], hm8[256 * 8], sc64[2 * SNT];   // (hm8 / hc8: eight copies per digit, picked by the lane -- see hist)
+    __shared__ uint32_t hc[256], hc8[256 * 8], sc32[2 * SNT];
     __shared__ unsigned long long s_acc, s_ztot;
     __shared__ uint32_t s_prefix, s_r;
     __shared__ float wsumf[SNW];
@@ -176,41 +211,57 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
       if (Q >= ztot) Q = ztot ? ztot - 1 : 0ull;
       for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
-        if (tid < 256) { hm[tid] = 0ull; hc[tid] = 0u; }
+        for (int i = tid; i < 256 * 8; i += SNT) { hm8[i] = 0ull; hc8[i] = 0u; }
         block_sync();
         const uint32_t pre = s_prefix, pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
         strided([&](float l, int) {
           const uint32_t k = fkey(l);
-          if ((k & pmask) == pre) { const uint32_t d = (k >> shift) & 255u; lds_add_u64(&hm[d], mass(l)); lds_fetch_add_u32(&hc[d], 1u); }
+          if ((k & pmask) == pre) { const uint32_t d = 8u * ((k >> shift) & 255u) + (uint32_t)(lane & 7); lds_add_u64(&hm8[d], mass(l)); lds_fetch_add_u32(&hc8[d], 1u); }
         });
         block_sync();
-        if (tid == 0) {   // ascending: digits whose whole mass still fits under Q are cut; the first one that does not holds the boundary
-          unsigned long long acc = s_acc; uint32_t d = 0u;
-          for (; d < 255u; d++) { if (acc + hm[d] > Q) break; acc += hm[d]; }
-          s_acc = acc; s_prefix = pre | (d << shift);
-          if (pass == 3) { const unsigned long long one = hc[d] ? hm[d] / hc[d] : 0ull; s_r = one ? (uint32_t)((Q - acc) / one) : 0u; if (s_r >= hc[d] && hc[d]) s_r = hc[d] - 1u; }
+        if (tid < 256) {
+          unsigned long long tm = 0ull; uint32_t tc = 0u;
+#pragma unroll
+          for (int c8 = 0; c8 < 8; c8++) { tm += hm8[8 * tid + c8]; tc += hc8[8 * tid + c8]; }
+          hm[tid] = tm; hc[tid] = tc;
+        }
+        block_sync();
+        if (wv == 0) {   // ascending: digits whose whole mass still fits under Q are cut; the first one that does not holds the boundary
+          const unsigned long long acc0 = s_acc;
+          uint32_t d; unsigned long long before;
+          wave_find_digit<unsigned long long>([&](int rr) -> unsigned long long { return hm[rr]; }, Q - acc0, lane, d, before);
+          if (lane == 0) {
+            const unsigned long long acc = acc0 + before;
+            s_acc = acc; s_prefix = pre | (d << shift);
+            if (pass == 3) { const unsigned long long one = hc[d] ? hm[d] / hc[d] : 0ull; s_r = one ? (uint32_t)((Q - acc) / one) : 0u; if (s_r >= hc[d] && hc[d]) s_r = hc[d] - 1u; }
+          }
         }
         block_sync();
       }
       vstar = s_prefix; rcut = s_r;
     }
-    // ---- kept mass of the thread's contiguous slice (ties at the boundary value are ranked in index order first)
+    // ---- kept mass of the thread's tokens.  Ties at the boundary value that are cut (rare) need index-order ranks: contiguous slices then;
+    // otherwise thread t owns t, t + SNT, ... (coalesced reads; the inverse CDF may lay the tokens out in any fixed order)
+    const bool contig = !use_min_p && rcut > 0u;
     uint32_t tie_before = 0u;
-    if (!use_min_p && rcut > 0u) {
+    if (contig) {
       uint32_t tc = 0u;
       for (int i = lo; i < hi; i++) tc += fkey(ld(i)) == vstar ? 1u : 0u;
       tie_before = block_incl_scan<uint32_t>(tc, sc32, tid) - tc;
     }
+    auto owned = [&](auto&& fn) {
+      if (contig) { for (int i = lo; i < hi; i++) fn(ld(i), i); }
+      else strided(fn);
+    };
     unsigned long long km = 0ull;
     {
       uint32_t rank = tie_before;
-      for (int i = lo; i < hi; i++) {
-        const float l = ld(i);
+      owned([&](float l, int) {
         bool keep;
         if (use_min_p) keep = l >= thr;
         else { const uint32_t k = fkey(l); keep = k > vstar || (k == vstar && rank++ >= rcut); }
         if (keep) km += mass(l);
-      }
+      });
     }
     const unsigned long long incl = block_incl_scan<unsigned long long>(km, sc64, tid);
     if (tid == SNT - 1) s_ztot = incl;
@@ -220,8 +271,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
     const unsigned long long target = (ktot >> 24) * u24 + (((ktot & 0xffffffull) * u24) >> 24);   // floor(u ktot), u in [0, 1): < ktot
     if (ktot > 0ull && target >= start && target < incl) {   // exactly one thread
       unsigned long long run = start; uint32_t rank = tie_before; int got = -1; bool done = false;
-      for (int i = lo; i < hi; i++) {
-        const float l = ld(i);
+      owned([&](float l, int i) {
         bool keep;
         if (use_min_p) keep = l >= thr;
         else { const uint32_t k = fkey(l); keep = k > vstar || (k == vstar && rank++ >= rcut); }
@@ -229,7 +279,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
         if (!done && e > 0ull) got = i;
         run += e;
         if (run > target) done = true;
-      }
+      });
       pick_f = got;
     }
     block_sync();
@@ -239,19 +289,19 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
   }
   if (a.top_k == 0) {
     // full-vocabulary multinomial (the reference's top_k == 0 branch with top_p outside (0, 1): softmax(logits / T), one draw).
-    // Thread t owns the contiguous slice [t c, t c + c): block maximum, slice masses, an inclusive scan of the SNT masses (the scan
-    // values tile [0, total) exactly: end_t = start_{t + 1}), one Philox number scaled to the total, and the thread whose interval
-    // holds it walks its slice in index order -- the inverse CDF in index order.
+    // Block maximum, the mass of every thread's tokens, an inclusive scan of the SNT masses (the scan values tile [0, total) exactly:
+    // end_t = start_{t + 1}), one Philox number scaled to the total, and the thread whose interval holds it walks its tokens.
     __shared__ float scf[2 * SNT];
     __shared__ float tot_s;
     __shared__ int pick_s;
-    const int c = (V + SNT - 1) / SNT, lo = tid * c < V ? tid * c : V, hi = lo + c < V ? lo + c : V;
+    // (thread t owns the tokens t, t + SNT, ...: the inverse CDF may lay the tokens out in ANY fixed order, and this one reads coalesced --
+    // contiguous slices per thread were 64 scattered lines per request: 17 -> see profiles/r06_sampler.txt)
     float m; int mi;
     if (tid == 0) pick_s = 0;
     block_argmax(m, mi);
     const float sc = a.inv_temp * LOG2E;
     float mine = 0.f;
-    for (int i = lo; i < hi; i++) mine += exp2_fast((ld(i) - m) * sc);
+    strided([&](float v, int) { mine += exp2_fast((v - m) * sc); });
     const float end = block_incl_scan<float>(mine, scf, tid);
     scf[tid] = end;                                                 // (the scan values tile [0, total): a thread starts where its neighbour ends)
     if (tid == SNT - 1) tot_s = end;
@@ -260,13 +310,13 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
     float u = (float)philox_u24() * (1.0f / 16777216.0f) * tot;   // uniform in [0, tot)
     if (u >= tot) u = tot * 0.99999994f;                            // (the product may round up to the total)
     if (u >= start && u < end) {   // exactly one thread when 0 < tot < inf
-      float run = start; int got = lo; bool done = false;
-      for (int i = lo; i < hi; i++) {
-        const float e = exp2_fast((ld(i) - m) * sc);
-        if (!done && e > 0.f) got = i;                              // rounding inside the slice: the last token with mass
+      float run = start; int got = tid < V ? tid : 0; bool done = false;
+      strided([&](float v, int i) {
+        const float e = exp2_fast((v - m) * sc);
+        if (!done && e > 0.f) got = i;                              // rounding inside the walk: the last token with mass
         run += e;
         if (run > u) done = true;
-      }
+      });
       pick_s = got;
     }
     block_sync();
@@ -278,23 +328,26 @@ __global__ __launch_bounds__(SNT) void sample_kernel(SampleArgs a) {
   if (tid == 0) { sel_prefix = 0u; sel_need = (uint32_t)K; }
   for (int pass = 0; pass < 4; pass++) {
     const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0u;
+    for (int i = tid; i < 256 * 8; i += SNT) hist[i] = 0u;
     block_sync();
     const uint32_t pre = sel_prefix, pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    strided([&](float v, int) {   // (one LDS atomic per key; aggregating the lanes of a wave per distinct digit first was slower: 55.7 -> 66.3 us)
+    strided([&](float v, int) {   // (aggregating the lanes of a wave per distinct digit with ballots instead: slower, 55.7 -> 66.3 us)
       const uint32_t k = fkey(v);
-      if ((k & pmask) == pre) lds_fetch_add_u32(&hist[(k >> shift) & 255u], 1u);
+      if ((k & pmask) == pre) lds_fetch_add_u32(&hist[8u * ((k >> shift) & 255u) + (uint32_t)(lane & 7)], 1u);
     });
     block_sync();
-    if (tid == 0) {   // walk the digits from the top until `need` keys are covered
-      uint32_t need = sel_need, d = 255u;
-      for (;; d--) {
-        const uint32_t c = hist[d];
-        if (c >= need || d == 0u) break;
-        need -= c;
-      }
-      sel_prefix = pre | (d << shift);
-      sel_need = need;
+    if (tid < 256) {
+      uint32_t t = 0u;
+#pragma unroll
+      for (int c = 0; c < 8; c++) t += hist[8 * tid + c];
+      hist[8 * tid] = t;
+    }
+    block_sync();
+    if (wv == 0) {   // walk the digits from the top until `need` keys are covered
+      const uint32_t need = sel_need;
+      uint32_t r, before;
+      wave_find_digit<uint32_t>([&](int rr) -> uint32_t { return hist[8u * (255u - (uint32_t)rr)]; }, need - 1u, lane, r, before);
+      if (lane == 0) { sel_prefix = pre | ((255u - r) << shift); sel_need = need - before; }
     }
     block_sync();
   }
