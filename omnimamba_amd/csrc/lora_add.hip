@@ -13,7 +13,7 @@ namespace omk {
 
 constexpr int LA_MAXR = 16;
 struct LoraAddArgs {
-  void* out; const void* h; const void* B; const uint8_t* mask; int64_t os, hs, bs, ms; int T, N, R, tokens_per_block, bdt; float scale;
+  void* out; const void* h; const void* B; const uint8_t* mask; int64_t os, hs, bs, ms; int T, N, R, tokens_per_block, bdt; float scale; int bvec;
 };
 
 // MASK: one byte per element of `out`; elements whose byte is zero keep their value
@@ -27,10 +27,34 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
   if (cv >= nvec) return;
   const int n0 = cv * VEC;
   float bw[VEC][RR];
+  if (a.bvec) {   // (uniform) contiguous, 16-byte aligned B rows: the lane's VEC x RR weights are consecutive -- 16-byte requests instead of VEC x RR
+                  // run-time-dtype element loads (a workgroup lives for 64 tokens: the element prologue was as many requests as its token walk)
 #pragma unroll
-  for (int i = 0; i < VEC; i++)
+    for (int i = 0; i < VEC; i++) {
+      if (a.bdt == OMK_F32) {
 #pragma unroll
-    for (int r = 0; r < RR; r++) bw[i][r] = a.scale * load_rt(a.B, (int64_t)(n0 + i) * a.bs + r, a.bdt);
+        for (int q = 0; q < RR / 4; q++) {
+          const f32x4 v = reinterpret_cast<const f32x4*>((const float*)a.B + (int64_t)(n0 + i) * RR)[q];
+#pragma unroll
+          for (int e = 0; e < 4; e++) bw[i][4 * q + e] = a.scale * v[e];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < RR / 8; q++) {
+          float tmp[8];
+          if (a.bdt == OMK_BF16) load_vec<bf16_t, 8>((const bf16_t*)a.B + (int64_t)(n0 + i) * RR + 8 * q, tmp);
+          else load_vec<f16_t, 8>((const f16_t*)a.B + (int64_t)(n0 + i) * RR + 8 * q, tmp);
+#pragma unroll
+          for (int e = 0; e < 8; e++) bw[i][8 * q + e] = a.scale * tmp[e];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i++)
+#pragma unroll
+      for (int r = 0; r < RR; r++) bw[i][r] = a.scale * load_rt(a.B, (int64_t)(n0 + i) * a.bs + r, a.bdt);
+  }
   const int t0 = tb * a.tokens_per_block, t1 = t0 + a.tokens_per_block < a.T ? t0 + a.tokens_per_block : a.T;
   TO* out = (TO*)a.out + n0;
   const TO* h = (const TO*)a.h;
@@ -194,6 +218,7 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
     return fail(OMK_EUNSUPPORTED, "lora_add: rank must be 8 or 16 and rows 16-byte aligned (use addmm otherwise)");
   a.out = p->out.data; a.h = p->h.data; a.B = p->lora_b.data; a.os = p->out.stride[0]; a.hs = p->h.stride[0]; a.bs = p->lora_b.stride[0];
   a.bdt = p->lora_b.dtype; a.scale = p->scale;
+  a.bvec = (a.bs == a.R && ((uintptr_t)p->lora_b.data & 15) == 0 && !getenv("OMK_LORA_ADD_NOVEC")) ? 1 : 0;
   if (present(p->mask)) {
     OMK_REQUIRE(p->mask.dtype == OMK_U8 && p->mask.ndim == 2 && p->mask.shape[0] == a.T && p->mask.shape[1] == a.N && p->mask.stride[1] == 1,
                 "lora_add: mask must be u8 (T, N) with contiguous rows");
