@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
   const int t0 = tb * a.tokens_per_block, t1 = t0 + a.tokens_per_block < a.T ? t0 + a.tokens_per_block : a.T;
   TO* out = (TO*)a.out + n0;
   const TO* h = (const TO*)a.h;
-  constexpr int UN = RR == 8 ? 8 : 4;         // tokens in flight per thread
+#ifndef OMK_LORA_ADD_UN
+#define OMK_LORA_ADD_UN 8
+#endif
+  constexpr int UN = RR == 8 ? OMK_LORA_ADD_UN : 4;         // tokens in flight per thread
   for (int t = t0; t < t1; t += UN) {
     float o[UN][VEC], hv[UN][RR];
     uint8_t mk[UN][VEC];
@@ -226,7 +229,8 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
   }
   const int nvec = a.N / vec, cvb = (nvec + 255) / 256;
   // few tokens (a 72-token prefill: 18 workgroups of 64 tokens took 19 us): cut the token blocks until the chip has work
-  a.tokens_per_block = 64;
+  a.tokens_per_block = 32;   // (round 6, behind the 16-byte weight prologue: 128 / 64 / 32 / 16 / 8 tokens = 120 / 112 / 109.5 / 119 / 144 us at 16384 x 8512)
+  if (const char* e = getenv("OMK_LORA_ADD_TPB")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) a.tokens_per_block = v; }   // developer A/B
   while (a.tokens_per_block > 8 && (int64_t)cvb * ((a.T + a.tokens_per_block - 1) / a.tokens_per_block) < 256) a.tokens_per_block >>= 1;
   const int tbs = (a.T + a.tokens_per_block - 1) / a.tokens_per_block;
   dim3 grid((unsigned)((int64_t)cvb * tbs)), block(256);
