@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void lora_add_kernel(LoraAddArgs a) {
 // The partials are plain stores (every workgroup owns its slots) and the caller adds them up: deterministic, and cheaper than the
 // 4.5 M fp32 atomics of the first version (16 of its 89 us).
 // Both MFMAs are 16x16x32 with the rank in the N dimension (8 of 16 columns used): the kernel is a pure stream over dy.
-// 16 k tokens x 8512: 84 us (+ 9 us for the two reductions of the partials) against 112 - 128 us for the two library GEMMs; the
+// 16 k tokens x 8512: 84 us (round 6: 60 us, see lora_up_plan) + 9 us for the two reductions of the partials, against 112 - 128 us for the two library GEMMs; the
 // load / stage / barrier skeleton alone is 68 us (4.1 TB/s), both MFMA parts together 3 us (OMK_LORA_UP_DBG).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LU_TT = 64, LU_TN = 256, LU_LD = LU_TN + 8;
@@ -119,15 +119,33 @@ __global__ __launch_bounds__(256) void lora_up_bwd_kernel(LoraUpBwdArgs a) {
   const int tc = blockIdx.x % nchunk, nb = blockIdx.x / nchunk;   // (which of the two runs fastest makes no difference: measured)
   const int n0 = nb * LU_TN, tb = tc * a.tchunk, te = tb + a.tchunk < a.T ? tb + a.tchunk : a.T;
   // lora_b fragments of the eight 32-column steps: B[k = n0 + 32 ks + 8 g16 + j][r = t16]
+  // (round 6: the workgroup's 256 x R block of B goes through LDS -- a row per thread, 16-byte requests when the rows are contiguous fp32 -- instead
+  // of 64 run-time-dtype element requests per lane: the prologue decided how short a workgroup may live, profiles/r06_stream_kernels.txt)
   s16x8 bfr[LU_TN / 32];
+  {
+    float* sB = reinterpret_cast<float*>(sY);                 // [256][16] fp32, before the first tile lands in sY
+    const int n = n0 + tid;
+    float row[16];
 #pragma unroll
-  for (int ks = 0; ks < LU_TN / 32; ks++)
+    for (int r = 0; r < 16; r++) row[r] = 0.f;
+    if (n < a.N) {
+      if (a.bdt == OMK_F32 && a.bs == 8 && a.R == 8 && (((uintptr_t)a.B) & 15) == 0) {
+        const f32x4 v0 = reinterpret_cast<const f32x4*>((const float*)a.B + (int64_t)n * 8)[0], v1 = reinterpret_cast<const f32x4*>((const float*)a.B + (int64_t)n * 8)[1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int n = n0 + 32 * ks + 8 * g16 + j;
-      const float v = (t16 < a.R && n < a.N) ? load_rt(a.B, (int64_t)n * a.bs + t16, a.bdt) : 0.f;
-      bfr[ks][j] = (short)f32_to_bf16(v);
+        for (int e = 0; e < 4; e++) { row[e] = v0[e]; row[4 + e] = v1[e]; }
+      } else {
+        for (int r = 0; r < a.R; r++) row[r] = load_rt(a.B, (int64_t)n * a.bs + r, a.bdt);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) reinterpret_cast<f32x4*>(sB + tid * 16)[q] = f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]};
+    block_sync();
+#pragma unroll
+    for (int ks = 0; ks < LU_TN / 32; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) bfr[ks][j] = (short)f32_to_bf16(sB[(32 * ks + 8 * g16 + j) * 16 + t16]);
+    block_sync();
+  }
   for (int i = tid; i < 16 * LU_TT; i += 256) sH[i] = 0;
   f32x4 accB[4];
 #pragma unroll
@@ -245,8 +263,12 @@ extern "C" int omk_lora_add(const OmkLoraAdd* p, omk_stream stream) {
 
 static void lora_up_plan(int64_t T, int64_t N, int* NB, int* tchunk, int* chunks) {
   *NB = (int)((N + LU_TN - 1) / LU_TN);
-  // token chunks: enough workgroups for two to three per CU, at least four tiles each
-  int c = (768 + *NB - 1) / *NB;
+  // token chunks: ONE resident round -- 188 registers = two workgroups per CU, so as many workgroups as fit 512 slots and no more (round 6: 748
+  // workgroups were 1.46 rounds, the second one half empty: 81.5 us; 510: 63.3, with the B block through LDS 59.8; 1020 / 1530 / 2040: 63 / 69 / 75 --
+  // every further workgroup pays a prologue and a partial dB slab), at least four tiles each
+  int target = 512;
+  if (const char* e = getenv("OMK_LORA_UP_WGS")) { const int v = atoi(e); if (v >= 64 && v <= 16384) target = v; }   // developer A/B
+  int c = target / *NB;
   const int max_chunks = (int)((T + 4 * LU_TT - 1) / (4 * LU_TT));
   if (c > max_chunks) c = max_chunks;
   if (c < 1) c = 1;
